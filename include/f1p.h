@@ -1,0 +1,259 @@
+/*
+ * f1p.h -- C-ABI of libf1p.so, the MI355X (gfx950) batched trajectory-sampling planner.
+ *
+ * This is the drop-in boundary for the ONE data-parallel hot path of f1tenth/f1tenth_planning
+ * (SURVEY.md section 8): pure-pursuit tracking, the lattice planner's sample -> clothoid -> cost ->
+ * argmin -> track loop, and the kinematic-bicycle rollout of the kinematic MPC run as random shooting.
+ * Every entry point names the reference interface (file:line under the reference tree) it replaces.
+ * The reference is pure Python, so the binding a maintainer adds is a ctypes stub.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; `hipStream_t` never crosses the boundary;
+ *   - every function returns 0 (F1P_OK) or a negative F1P_E* code and never throws or aborts;
+ *     the message is available from f1p_last_error();
+ *   - one ctx <-> one device <-> one HIP stream.  A ctx is not thread-safe; distinct ctxs are;
+ *   - `*_batch`  : caller-owned HOST pointers, synchronous (H2D, kernels, D2H, stream sync);
+ *     `*_dev`    : caller-owned DEVICE pointers (from f1p_dev_alloc), asynchronous on the ctx stream;
+ *   - all floating-point payloads are IEEE binary64 unless the name says f32 -- the reference computes
+ *     in numpy fp64 and the index decisions (nearest segment, look-ahead segment, best candidate) are
+ *     required bit-exact;
+ *   - row-major arrays, E = number of egos (independent vehicles) in the batch.
+ */
+#ifndef F1P_H
+#define F1P_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F1P_VERSION_STRING "0.1.0"
+
+/* error codes */
+#define F1P_OK 0
+#define F1P_EINVAL (-1)    /* bad argument (shape, NULL, range) -> ValueError in the shims            */
+#define F1P_ENODEV (-2)    /* no usable HIP device / device index out of range                         */
+#define F1P_EHIP (-3)      /* a HIP runtime call failed (message carries hipGetErrorString)            */
+#define F1P_ESTATE (-4)    /* call order: waypoints / grid / communicator not set                      */
+#define F1P_ENOMEM (-5)    /* device or host allocation failed                                         */
+#define F1P_ECOMM (-6)     /* RCCL could not be loaded or a collective failed                          */
+
+/* per-ego status written by the batch calls (a batch never fails because of one bad ego) */
+#define F1P_ST_INTERSECT 0      /* look-ahead circle intersected the path   (pure_pursuit.py:70-79)   */
+#define F1P_ST_REACQUIRE 1      /* nearest waypoint used, dist < max_reacquire (pure_pursuit.py:80-81) */
+#define F1P_ST_NO_LOOKAHEAD 2   /* no look-ahead point: (0.0, 0.0) + warning (pure_pursuit.py:112-114) */
+#define F1P_ST_ALL_BLOCKED 3    /* lattice: every candidate is in collision / infeasible               */
+
+/* limits of the fixed-size config structs */
+#define F1P_MAX_LOOKAHEADS 64
+#define F1P_MAX_WIDTHS 64
+
+typedef struct f1p_ctx f1p_ctx;
+
+/* ------------------------------------------------------------------------------------------------
+ * Lattice planner configuration.  Mirrors what the reference spreads over
+ * LatticePlanner.plan (planning/lattice_planner/lattice_planner.py:174-214: 100 stations, tracker
+ * look-ahead 0.8), sample_lookahead_square (:223-260: lookahead_distances, widths) and the example cost
+ * functions (:268-296: inverse length, max |kappa|, mean |kappa|, heading similarity to the previous path).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct f1p_lattice_cfg {
+    int32_t n_stations;      /* S: stations per candidate, sample_traj npts (utils/utils.py:286-295); >= 2  */
+    int32_t n_lookahead;     /* n_l: number of look-ahead distances (device-sampled goals)                  */
+    int32_t n_width;         /* n_w: number of lateral offsets; candidates C = n_l * n_w, c = l*n_w + k     */
+    int32_t n_shift;         /* N_SHIFT of get_similarity_cost (lattice_planner.py:287-296)                 */
+    int32_t n_cull;          /* N_CULL  of get_similarity_cost; >= 0 here (0 keeps the whole tail)          */
+    int32_t check_collision; /* 1: a station in an occupied / out-of-map cell makes the cost +inf           */
+    int32_t cand_begin;      /* candidate shard [cand_begin, cand_begin + cand_count) evaluated by this     */
+    int32_t cand_count;      /*   call; 0 count = all C (used when one ego's candidates span ranks)         */
+    double lookahead[F1P_MAX_LOOKAHEADS]; /* metres, circle radii for intersect_point                       */
+    double width[F1P_MAX_WIDTHS];         /* metres, lateral offsets along the path normal                  */
+    double w_length;         /* weight of 1/L                 (get_length_cost     :268-271)                */
+    double w_max_kappa;      /* weight of max_i |kappa(s_i)|  (get_max_curvature   :273-278)                */
+    double w_mean_kappa;     /* weight of mean_i |kappa(s_i)| (get_mean_curvature  :280-285)                */
+    double w_similarity;     /* weight of sum (theta_new - theta_prev)^2 (get_similarity_cost :287-296)     */
+    double track_lookahead;  /* tracker look-ahead, 0.8 in the reference (lattice_planner.py:211)           */
+    double wheelbase;        /* tracker wheelbase; the reference tracker uses 0.33 (lattice_planner.py:55)  */
+    double max_reacquire;    /* PurePursuitPlanner.max_reacquire = 20.0 (pure_pursuit.py:52)                */
+} f1p_lattice_cfg;
+
+/* ------------------------------------------------------------------------------------------------
+ * Kinematic-MPC shooting configuration: the numeric content of `mpc_config`
+ * (control/kinematic_mpc/kinematic_mpc.py:40-68) that the rollout and the objective use.
+ * State order is the reference's z = [x, y, v, yaw]; input order u = [accel, steer].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct f1p_kmpc_cfg {
+    int32_t horizon;         /* TK (8 in the reference, 30 in BASELINE config 4)                            */
+    int32_t n_rollouts;      /* R candidate control sequences per ego                                       */
+    double dt;               /* DTK = 0.1                                                                   */
+    double wheelbase;        /* WB = 0.33                                                                   */
+    double max_steer;        /* MAX_STEER = 0.4189 (MIN_STEER = -MAX_STEER)                                 */
+    double max_dsteer;       /* MAX_DSTEER = pi rad/s; per-step bound is max_dsteer*dt (:391-394)           */
+    double max_speed;        /* MAX_SPEED = 6                                                               */
+    double min_speed;        /* MIN_SPEED = 0                                                               */
+    double max_accel;        /* MAX_ACCEL = 3                                                               */
+    double q[4];             /* diag Qk  = [13.5, 13.5, 5.5, 13.0]                                          */
+    double qf[4];            /* diag Qfk = [13.5, 13.5, 5.5, 13.0]                                          */
+    double r[2];             /* diag Rk  = [0.01, 100]                                                      */
+    double rd[2];            /* diag Rdk = [0.01, 100]                                                      */
+} f1p_kmpc_cfg;
+
+/* fill the structs with the reference defaults (lattice: 4 look-aheads x 7 widths, S = 100) */
+void f1p_lattice_cfg_default(f1p_lattice_cfg* cfg);
+void f1p_kmpc_cfg_default(f1p_kmpc_cfg* cfg);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context, errors, device memory
+ * ---------------------------------------------------------------------------------------------- */
+const char* f1p_version(void);
+/* number of visible HIP devices, or a negative error code.  Does not create a context. */
+int f1p_device_count(void);
+/* create a context bound to HIP device `device` (0-based) with its own non-blocking stream */
+int f1p_create(f1p_ctx** out, int device);
+void f1p_destroy(f1p_ctx* ctx);
+/* last error message of this ctx (or of the last failed f1p_create when ctx == NULL) */
+const char* f1p_last_error(const f1p_ctx* ctx);
+/* device name / compute units / gcn arch string of the ctx device, for reports */
+int f1p_device_info(const f1p_ctx* ctx, char* name, size_t name_len, int32_t* compute_units, char* arch, size_t arch_len);
+
+/* caller-visible device buffers for the *_dev entry points (HBM-resident inputs / outputs) */
+int f1p_dev_alloc(f1p_ctx* ctx, void** dptr, size_t bytes);
+int f1p_dev_free(f1p_ctx* ctx, void* dptr);
+int f1p_h2d(f1p_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);  /* async on the ctx stream */
+int f1p_d2h(f1p_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);  /* async on the ctx stream */
+int f1p_memset(f1p_ctx* ctx, void* dst_dev, int value, size_t bytes);          /* async on the ctx stream */
+int f1p_sync(f1p_ctx* ctx);                                                    /* hipStreamSynchronize   */
+
+/* HIP-event timing on the ctx stream (the stream the kernels are launched on):
+ * f1p_timer_begin records an event, f1p_timer_end records a second one, synchronises it and returns the
+ * elapsed milliseconds between the two. */
+int f1p_timer_begin(f1p_ctx* ctx);
+int f1p_timer_end(f1p_ctx* ctx, float* elapsed_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Static scene: waypoints (raceline / centreline) and the occupancy grid.  Copied to the device; no host
+ * pointer is retained.  Replaces the `self.waypoints` attribute of every planner
+ * (pure_pursuit.py:51-54, lattice_planner.py:44-49) and the `map` argument of the stub
+ * map_collision (utils/utils.py:297-301).
+ * ---------------------------------------------------------------------------------------------- */
+/* wp: row-major [n][ncols] fp64; col_* select x, y, speed, heading.  col_psi < 0: no heading column
+ * (pure pursuit only).  Pure pursuit / lattice rows are [x, y, v, psi, kappa]
+ * (examples/control/Spielberg_raceline.csv:1), i.e. cols 0,1,2,3. */
+int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
+                      int32_t col_v, int32_t col_psi);
+/* img: row-major [h][w] u8, row 0 = TOP of the image (ROS map_server layout,
+ * examples/control/Spielberg_map.yaml:1-6); cell (gx, gy) with gx = floor((x-ox)/res), gy = floor((y-oy)/res)
+ * reads img[h-1-gy][gx]; a cell is occupied iff its value < occupied_below; outside the image is occupied. */
+int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
+                 int32_t occupied_below);
+
+/* ------------------------------------------------------------------------------------------------
+ * Leaf kernels of utils/utils.py, batched over E query points against the ctx waypoints.
+ * ---------------------------------------------------------------------------------------------- */
+/* nearest_point (utils/utils.py:37-67).  pts [E][2] -> proj [E][2], dist [E], t [E], idx [E] (segment index
+ * in [0, n-2], first minimum wins).  Any output pointer may be NULL. */
+int f1p_nearest_point_batch(f1p_ctx* ctx, const double* pts, int32_t E, double* proj, double* dist, double* t,
+                            int32_t* idx);
+/* intersect_point (utils/utils.py:69-151).  pts [E][2], start_t [E] (the `t` argument, i + t), one radius,
+ * wrap flag -> first_p [E][2], first_i [E] (may be -1 in the wrap loop), first_t [E], found [E] (0 = None). */
+int f1p_intersect_point_batch(f1p_ctx* ctx, const double* pts, const double* start_t, int32_t E, double radius,
+                              int32_t wrap, double* first_p, int32_t* first_i, double* first_t, int32_t* found);
+
+/* ------------------------------------------------------------------------------------------------
+ * PurePursuitPlanner.plan (control/pure_pursuit/pure_pursuit.py:85-122) for E egos.
+ * poses [E][3] = (x, y, theta).  Outputs: steer [E], speed [E] (the reference returns (steer, speed),
+ * :122), near_idx [E] (nearest segment), la_idx [E] (look-ahead segment i2, may be -1; INT32_MIN when not
+ * in the intersect branch), status [E] (F1P_ST_*).  near_idx / la_idx / status may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int f1p_pure_pursuit_batch(f1p_ctx* ctx, const double* poses, int32_t E, double lookahead, double wheelbase,
+                           double max_reacquire, double* steer, double* speed, int32_t* near_idx,
+                           int32_t* la_idx, int32_t* status);
+int f1p_pure_pursuit_dev(f1p_ctx* ctx, const double* d_poses, int32_t E, double lookahead, double wheelbase,
+                         double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near_idx,
+                         int32_t* d_la_idx, int32_t* d_status);
+
+/* ------------------------------------------------------------------------------------------------
+ * LatticePlanner.plan (planning/lattice_planner/lattice_planner.py:174-214) for E egos, one fused launch:
+ * goal sampling (intent of sample_lookahead_square :223-260) -> G1 clothoid fit (pyclothoids
+ * Clothoid.G1Hermite, :196) -> sample_traj at S stations (utils/utils.py:286-295) -> occupancy check
+ * (map_collision stub, utils/utils.py:297-301) -> eval weighted cost (:130-156) -> select argmin
+ * (:159-172) -> PurePursuitPlanner.plan on the winner (:208-212).
+ *
+ *   poses      [E][4]       (x, y, theta, velocity), map frame
+ *   goals      [E][C][3]    optional host/device-supplied goals (x, y, theta) in the EGO frame, as the
+ *                           G1Hermite(0,0,0, ...) call implies; NULL = sample on the device from
+ *                           cfg.lookahead x cfg.width along the ctx waypoints
+ *   prev_theta [E][S]       optional heading column of the previous plan's winner (similarity cost);
+ *                           NULL = no previous path (term = 0)
+ * Outputs (any may be NULL except steer/speed/best_idx):
+ *   steer, speed [E]; best_idx [E] (global candidate index, np.argmin first-minimum rule);
+ *   best_cost [E]; status [E]; near_idx [E] (nearest raceline segment);
+ *   best_traj [E][S][4] rows (x, y, theta, |kappa|) in the ego frame -- the third return value of plan();
+ *   all_cost [E][C] and all_traj [E][C][S][4]: the materialised data flow of the reference (:194-201),
+ *   needed by host-side Python cost callables; leave NULL for the fused path.
+ * ---------------------------------------------------------------------------------------------- */
+int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                           int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                           int32_t* best_idx, double* best_cost, int32_t* status, int32_t* near_idx,
+                           double* best_traj, double* all_cost, double* all_traj);
+int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                         int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                         int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
+                         double* d_best_traj, double* d_all_cost, double* d_all_traj);
+/* Re-generate candidate `cand_idx[e]` of each ego and track it: the "emit" half of plan(), used after a
+ * cross-rank argmin when one ego's candidates are sharded over several GPUs. */
+int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,
+                         const f1p_lattice_cfg* cfg, const int32_t* d_cand_idx, const double* d_cand_cost,
+                         double* d_steer, double* d_speed, int32_t* d_status, int32_t* d_near_idx,
+                         double* d_best_traj);
+
+/* Clothoid leaf: G1 Hermite fit from (0,0,0) to each goal (x, y, theta) -- what
+ * pyclothoids.Clothoid.G1Hermite(0,0,0,x,y,theta) returns (lattice_planner.py:196).
+ * goals [n][3] -> kappa0 [n], dkappa [n], length [n], ok [n] (0 = Newton did not converge / degenerate). */
+int f1p_clothoid_g1_batch(f1p_ctx* ctx, const double* goals, int32_t n, double* kappa0, double* dkappa,
+                          double* length, int32_t* ok);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kinematic MPC by random shooting for E egos: R open-loop rollouts of
+ * predict_motion_kinematic / update_state_kinematic (control/kinematic_mpc/kinematic_mpc.py:208-243),
+ * the objective of :324-334 evaluated on the nonlinear rollout, argmin, output map of :506-508.
+ *   x0       [E][4]          (x, y, v, yaw)                       fp64
+ *   ref      [E][4][T+1]     calc_ref_trajectory_kinematic output (:162-206), rows x, y, v, yaw   fp64
+ *   controls [E][T][2][R]    f32, (accel, steer) candidates, rollout index fastest (coalesced)
+ * Outputs: steer [E] = delta_0 of the winner, speed [E] = v + a_0*DTK, best_idx [E], best_cost [E],
+ *   best_seq [E][T][2] (the winner's applied accel/steer after bound projection; may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int f1p_kmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, const float* controls, int32_t E,
+                         const f1p_kmpc_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
+                         double* best_cost, double* best_seq);
+int f1p_kmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,
+                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                       double* d_best_cost, double* d_best_seq);
+/* calc_ref_trajectory_kinematic (:162-206) for E egos against the ctx waypoints (cols x, y, v, psi):
+ * states [E][4] = (x, y, v, yaw) -> ref [E][4][T+1].  The reference's in-place fix-up of cyaw (:198-203) is
+ * applied to a per-ego view, never to the stored waypoints. */
+int f1p_kmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl,
+                       double* ref);
+/* fill controls [E][T][2][R] f32 on the device from a counter-based generator (seeded, reproducible):
+ * accel ~ clip(N(0, sigma_a), +-max_accel), steer ~ clip(N(0, sigma_d), +-max_steer) */
+int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const f1p_kmpc_cfg* cfg,
+                                 uint64_t seed, double sigma_accel, double sigma_steer);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: egos shard with no communication (one ctx per rank).  Only when ONE ego's candidate set is
+ * split over ranks is there an exchange step: all-reduce(min) of the per-ego best cost, then
+ * all-reduce(min) of the candidate index among the ranks that hold that cost (np.argmin first-minimum
+ * rule, lattice_planner.py:170), both RCCL collectives enqueued on the ctx stream.
+ * ---------------------------------------------------------------------------------------------- */
+#define F1P_COMM_ID_BYTES 128
+int f1p_comm_unique_id(f1p_ctx* ctx, uint8_t id[F1P_COMM_ID_BYTES]);              /* rank 0, then broadcast */
+int f1p_comm_init(f1p_ctx* ctx, const uint8_t id[F1P_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+int f1p_comm_destroy(f1p_ctx* ctx);
+/* in place on device buffers: d_cost [E] fp64 <- global min; d_idx [E] int32 <- lowest index with that cost */
+int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F1P_H */

@@ -1,0 +1,613 @@
+/*
+ * f1p_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A scalar fp64 CPU restatement of the reference's algorithms on the hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call this file;
+ * the product path (f1tenth_planning_amd -> libf1p.so) never does and fails loudly without its HIP library.
+ *
+ * Parity pinning (DESIGN.md "Oracle"):
+ *   - rows that restate runnable reference code (nearest_point, intersect_point, get_actuation,
+ *     PurePursuitPlanner.plan, update_state_kinematic, predict_motion_kinematic,
+ *     calc_ref_trajectory_kinematic, pi_2_pi, LatticePlanner.eval/select, sample_traj layout) are PINNED
+ *     against golden vectors captured from the imported reference (tools/gen_golden.py -> tests/golden/);
+ *   - the clothoid arithmetic lives in the third-party wheel pyclothoids==0.1.4 (requirements.txt:14, C++
+ *     "Clothoids" library by Bertolazzi & Frego), absent from /root/reference: PARITY UNPINNED for that
+ *     row.  It restates the published algorithm (Bertolazzi & Frego, "G1 fitting with clothoids", Math.
+ *     Meth. Appl. Sci. 2015) and is pinned by closed-form known answers instead (tests/test_oracle_clothoid.py);
+ *   - the lattice glue (goal sampling, cost terms, collision, tracking frame) and the shooting-MPC driver
+ *     are BUILD-DEFINED because the reference's own glue does not execute; their
+ *     semantics are written down in DESIGN.md and restated here.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).  -ffp-contract=off keeps the operation
+ * order of the numpy reference (no fused multiply-add).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/f1p.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* np.dot of two length-2 fp64 vectors.  numpy hands it to OpenBLAS ddot, whose scalar tail is compiled with
+ * FMA3 on x86-64: the result is fma(a1, b1, a0*b0), ONE rounding for the second product (measured in this
+ * container: 100000/100000 random pairs match this form, 75% match the unfused a0*b0 + a1*b1).  The golden
+ * vectors pin this, including the degenerate closing segment of the Spielberg loop where the difference
+ * decides first_i.  fma() from libm is correctly rounded on every host.  Elementwise numpy expressions
+ * (x**2 + y**2, np.sum(t*t)) are NOT fused. */
+static inline double dot2(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* utils/utils.py:37-67  nearest_point(point, trajectory)                                            */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API void orc_nearest_point(double px, double py, const double* wx, const double* wy, int n, double* proj,
+                               double* dist_out, double* t_out, int* idx_out) {
+    double best_d = 0.0, best_t = 0.0, best_px = 0.0, best_py = 0.0;
+    int best_i = -1;
+    for (int i = 0; i < n - 1; ++i) {
+        double dx = wx[i + 1] - wx[i]; /* diffs            :53 */
+        double dy = wy[i + 1] - wy[i];
+        double l2 = dx * dx + dy * dy;                      /* :54 */
+        double dot = dot2(px - wx[i], py - wy[i], dx, dy);      /* :57 np.dot */
+        double t = dot / l2;                                /* :58 */
+        if (t < 0.0) t = 0.0;                               /* :59 */
+        if (t > 1.0) t = 1.0;                               /* :60 */
+        double qx = wx[i] + t * dx;                         /* :61 */
+        double qy = wy[i] + t * dy;
+        double ex = px - qx, ey = py - qy; /* :64 */
+        double d = sqrt(ex * ex + ey * ey); /* :65 */
+        /* np.argmin (:66): first minimum wins; a NaN is returned as soon as it is met */
+        int take = 0;
+        if (best_i < 0) take = 1;
+        else if (!isnan(best_d) && (isnan(d) || d < best_d)) take = 1;
+        if (take) { best_d = d; best_t = t; best_px = qx; best_py = qy; best_i = i; }
+    }
+    if (proj) { proj[0] = best_px; proj[1] = best_py; }
+    if (dist_out) *dist_out = best_d;
+    if (t_out) *t_out = best_t;
+    if (idx_out) *idx_out = best_i;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* utils/utils.py:69-151  intersect_point(point, radius, trajectory, t, wrap)                        */
+/* returns 1 when a point was found (first_p/first_i/first_t set), 0 for the reference's None        */
+/* ------------------------------------------------------------------------------------------------ */
+static int orc_seg_hit(double px, double py, double radius, double sx, double sy, double ex, double ey,
+                       int is_start_seg, double start_t, double* t_hit, double* hx, double* hy) {
+    ex = ex + 1e-6; /* :86 / :127  end = trajectory[i+1,:] + 1e-6 */
+    ey = ey + 1e-6;
+    double vx = ex - sx, vy = ey - sy;
+    double a = dot2(vx, vy, vx, vy);                               /* :89 */
+    double b = 2.0 * dot2(vx, vy, sx - px, sy - py);               /* :90 */
+    double c = dot2(sx, sy, sx, sy) + dot2(px, py, px, py) - 2.0 * dot2(sx, sy, px, py) - radius * radius; /* :91 */
+    double disc = b * b - 4 * a * c;                               /* :92 */
+    if (disc < 0) return 0;                                        /* :94 */
+    disc = sqrt(disc);                                             /* :99 */
+    double t1 = (-b - disc) / (2.0 * a);                           /* :100 */
+    double t2 = (-b + disc) / (2.0 * a);                           /* :101 */
+    if (is_start_seg) {                                            /* :102-112 */
+        if (t1 >= 0.0 && t1 <= 1.0 && t1 >= start_t) { *t_hit = t1; *hx = sx + t1 * vx; *hy = sy + t1 * vy; return 1; }
+        if (t2 >= 0.0 && t2 <= 1.0 && t2 >= start_t) { *t_hit = t2; *hx = sx + t2 * vx; *hy = sy + t2 * vy; return 1; }
+        return 0;
+    }
+    if (t1 >= 0.0 && t1 <= 1.0) { *t_hit = t1; *hx = sx + t1 * vx; *hy = sy + t1 * vy; return 1; } /* :113-117 */
+    if (t2 >= 0.0 && t2 <= 1.0) { *t_hit = t2; *hx = sx + t2 * vx; *hy = sy + t2 * vy; return 1; } /* :118-122 */
+    return 0;
+}
+
+ORC_API int orc_intersect_point(double px, double py, double radius, const double* wx, const double* wy, int n,
+                                double t, int wrap, double* first_p, int* first_i, double* first_t) {
+    int start_i = (int)t;          /* :78 */
+    double start_t = fmod(t, 1.0); /* :79  t % 1.0 (t >= 0 at every call site) */
+    double th = 0, hx = 0, hy = 0;
+    for (int i = start_i; i < n - 1; ++i) { /* :84 */
+        if (orc_seg_hit(px, py, radius, wx[i], wy[i], wx[i + 1], wy[i + 1], i == start_i, start_t, &th, &hx, &hy)) {
+            if (first_p) { first_p[0] = hx; first_p[1] = hy; }
+            if (first_i) *first_i = i;
+            if (first_t) *first_t = th;
+            return 1;
+        }
+    }
+    if (wrap) { /* :124-149 */
+        for (int i = -1; i < start_i; ++i) {
+            int i0 = ((i % n) + n) % n, i1 = (((i + 1) % n) + n) % n; /* Python modulo */
+            if (orc_seg_hit(px, py, radius, wx[i0], wy[i0], wx[i1], wy[i1], 0, 0.0, &th, &hx, &hy)) {
+                if (first_p) { first_p[0] = hx; first_p[1] = hy; }
+                if (first_i) *first_i = i; /* may be -1 */
+                if (first_t) *first_t = th;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* utils/utils.py:153-161  get_actuation                                                              */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API void orc_get_actuation(double pose_theta, const double* lookahead_point /*x,y,speed*/, const double* position,
+                               double lookahead_distance, double wheelbase, double* speed, double* steer) {
+    double wy = dot2(sin(-pose_theta), cos(-pose_theta), lookahead_point[0] - position[0],
+                     lookahead_point[1] - position[1]);                /* :155 np.dot */
+    *speed = lookahead_point[2];                                       /* :156 */
+    if (fabs(wy) < 1e-6) { *steer = 0.0; return; }                     /* :157-158 */
+    double radius = 1 / (2.0 * wy / (lookahead_distance * lookahead_distance)); /* :159 */
+    *steer = atan(wheelbase / radius);                                 /* :160 */
+}
+
+/* utils/utils.py:276-283 pi_2_pi: a single wrap, not a modulo */
+ORC_API double orc_pi_2_pi(double angle) {
+    if (angle > M_PI) return angle - 2.0 * M_PI;
+    if (angle < -M_PI) return angle + 2.0 * M_PI;
+    return angle;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* control/pure_pursuit/pure_pursuit.py:56-122  _get_current_waypoint + plan                          */
+/* wv = waypoints[:, 2].  Returns the status (F1P_ST_*).                                              */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API int orc_pure_pursuit_plan(double x, double y, double theta, double lookahead, double wheelbase,
+                                  double max_reacquire, const double* wx, const double* wy, const double* wv, int n,
+                                  double* steer, double* speed, int* near_idx, int* la_idx) {
+    double dist, t;
+    int i;
+    orc_nearest_point(x, y, wx, wy, n, NULL, &dist, &t, &i); /* :69 */
+    if (near_idx) *near_idx = i;
+    if (la_idx) *la_idx = INT32_MIN;
+    double cur[3];
+    int status;
+    if (dist < lookahead) { /* :70 */
+        int i2;
+        if (!orc_intersect_point(x, y, lookahead, wx, wy, n, (double)i + t, 1, NULL, &i2, NULL)) { /* :71-77 */
+            *steer = 0.0; *speed = 0.0; return F1P_ST_NO_LOOKAHEAD;                                /* :112-114 */
+        }
+        if (la_idx) *la_idx = i2;
+        int r = i2 < 0 ? i2 + n : i2; /* numpy negative index: row -1 is the last row */
+        cur[0] = wx[r]; cur[1] = wy[r]; cur[2] = wv[i]; /* :78 */
+        status = F1P_ST_INTERSECT;
+    } else if (dist < max_reacquire) { /* :80-81 */
+        cur[0] = wx[i]; cur[1] = wy[i]; cur[2] = wv[i];
+        status = F1P_ST_REACQUIRE;
+    } else { /* :82-83 -> :112-114 */
+        *steer = 0.0; *speed = 0.0; return F1P_ST_NO_LOOKAHEAD;
+    }
+    double pos[2] = {x, y};
+    orc_get_actuation(theta, cur, pos, lookahead, wheelbase, speed, steer); /* :116-122 */
+    return status;
+}
+
+ORC_API void orc_pure_pursuit_batch(const double* poses, int E, double lookahead, double wheelbase, double max_reacquire,
+                                    const double* wx, const double* wy, const double* wv, int n, double* steer,
+                                    double* speed, int32_t* near_idx, int32_t* la_idx, int32_t* status, int nthreads) {
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        int ni, li;
+        int st = orc_pure_pursuit_plan(poses[3 * e], poses[3 * e + 1], poses[3 * e + 2], lookahead, wheelbase,
+                                       max_reacquire, wx, wy, wv, n, &steer[e], &speed[e], &ni, &li);
+        if (near_idx) near_idx[e] = ni;
+        if (la_idx) la_idx[e] = li;
+        if (status) status[e] = st;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Clothoid (pyclothoids==0.1.4, not vendored: PARITY UNPINNED -- published algorithm restated)       */
+/* ------------------------------------------------------------------------------------------------ */
+static const double GL16_X[16] = {
+    0.005299532504175031, 0.0277124884633837,  0.06718439880608412, 0.1222977958224985,
+    0.19106187779867811,  0.2709916111713863,  0.35919822461037054, 0.4524937450811813,
+    0.5475062549188188,   0.6408017753896295,  0.7290083888286136,  0.8089381222013219,
+    0.8777022041775016,   0.9328156011939159,  0.9722875115366163,  0.994700467495825};
+static const double GL16_W[16] = {
+    0.013576229705877019, 0.031126761969323853, 0.047579255841246296, 0.062314485627767015,
+    0.07479799440828838,  0.08457825969750131,  0.0913017075224618,   0.09472530522753429,
+    0.09472530522753429,  0.0913017075224618,   0.08457825969750131,  0.07479799440828838,
+    0.062314485627767015, 0.047579255841246296, 0.031126761969323853, 0.013576229705877019};
+
+/* IC[k] = int_0^1 tau^k cos(a tau^2 + b tau + c) dtau,  IS[k] likewise with sin, k = 0..2
+ * (the "generalized Fresnel integrals" of the paper).  Composite 16-point Gauss-Legendre; the number of
+ * panels grows with the phase excursion so every panel sees at most ~2 rad of phase. */
+ORC_API void orc_fresnel_moments(double a, double b, double c, double IC[3], double IS[3]) {
+    int panels = (int)ceil((fabs(a) + fabs(b)) / 2.0);
+    if (panels < 1) panels = 1;
+    if (panels > 4096) panels = 4096;
+    double h = 1.0 / panels;
+    for (int k = 0; k < 3; ++k) { IC[k] = 0.0; IS[k] = 0.0; }
+    for (int p = 0; p < panels; ++p) {
+        double t0 = p * h;
+        for (int j = 0; j < 16; ++j) {
+            double tau = t0 + h * GL16_X[j];
+            double w = h * GL16_W[j];
+            double ph = (a * tau + b) * tau + c;
+            double cs = cos(ph), sn = sin(ph);
+            IC[0] += w * cs;             IS[0] += w * sn;
+            IC[1] += w * tau * cs;       IS[1] += w * tau * sn;
+            IC[2] += w * tau * tau * cs; IS[2] += w * tau * tau * sn;
+        }
+    }
+}
+
+static double orc_range_symm(double a) { /* into [-pi, pi] */
+    return remainder(a, 2.0 * M_PI);
+}
+
+/* G1 Hermite interpolation from (0,0,0) to (x1,y1,th1): what Clothoid.G1Hermite(0,0,0,x,y,theta) computes
+ * (call site lattice_planner.py:196).  Returns 1 on success. */
+ORC_API int orc_clothoid_g1(double x1, double y1, double th1, double* kappa0, double* dkappa, double* length) {
+    static const double CF[6] = {2.989696028701907,  0.716228953608281,  -0.458969738821509,
+                                 -0.502821153340377, 0.261062141752652,  -0.045854475238709};
+    double r = hypot(x1, y1);
+    *kappa0 = 0.0; *dkappa = 0.0; *length = 0.0;
+    if (!(r > 1e-12) || !isfinite(r) || !isfinite(th1)) return 0;
+    double phi = atan2(y1, x1);
+    double phi0 = orc_range_symm(0.0 - phi);
+    double phi1 = orc_range_symm(th1 - phi);
+    double delta = phi1 - phi0;
+    /* initial guess (paper eq. for the fitted polynomial) */
+    double X = phi0 / M_PI, Y = phi1 / M_PI;
+    double xy = X * Y;
+    double X2 = X * X, Y2 = Y * Y;
+    double A = (phi0 + phi1) * (CF[0] + xy * (CF[1] + xy * CF[2]) + (CF[3] + xy * CF[4]) * (X2 + Y2) +
+                                CF[5] * (X2 * X2 + Y2 * Y2));
+    double IC[3], IS[3];
+    int ok = 0;
+    for (int it = 0; it < 20; ++it) {
+        orc_fresnel_moments(A, delta - A, phi0, IC, IS);
+        double g = IS[0];
+        double dg = IC[2] - IC[1];
+        if (fabs(g) <= 1e-13) { ok = 1; break; }
+        if (dg == 0.0 || !isfinite(dg)) break;
+        A -= g / dg;
+        if (!isfinite(A)) break;
+    }
+    if (!ok) {
+        orc_fresnel_moments(A, delta - A, phi0, IC, IS);
+        if (fabs(IS[0]) <= 1e-10) ok = 1;
+    }
+    if (!ok) return 0;
+    orc_fresnel_moments(A, delta - A, phi0, IC, IS);
+    double L = r / IC[0];
+    if (!(L > 0.0) || !isfinite(L)) return 0; /* the solution on the wrong branch (negative length) */
+    *length = L;
+    *kappa0 = (delta - A) / L;
+    *dkappa = 2.0 * A / (L * L);
+    return 1;
+}
+
+/* pose of the clothoid (start (0,0,0), kappa0, dkappa) at arc length s: X(s), Y(s), Theta(s), and
+ * sqrt(XDD^2 + YDD^2) exactly as sample_traj combines them (utils/utils.py:290-293) */
+ORC_API void orc_clothoid_eval(double kappa0, double dkappa, double s, double out[4]) {
+    double IC[3], IS[3];
+    orc_fresnel_moments(0.5 * dkappa * s * s, kappa0 * s, 0.0, IC, IS);
+    double th = s * (kappa0 + 0.5 * s * dkappa);
+    double k = kappa0 + dkappa * s;
+    double xdd = -sin(th) * k, ydd = cos(th) * k;
+    out[0] = s * IC[0];
+    out[1] = s * IS[0];
+    out[2] = th;
+    out[3] = sqrt(xdd * xdd + ydd * ydd);
+}
+
+/* utils/utils.py:286-295 sample_traj(clothoid, npts): traj [npts][4] */
+ORC_API void orc_sample_traj(double kappa0, double dkappa, double length, int npts, double* traj) {
+    int den = npts - 1 > 1 ? npts - 1 : 1; /* max(npts - 1, 1) :289 */
+    for (int i = 0; i < npts; ++i) {
+        double s = i * (length / den);
+        orc_clothoid_eval(kappa0, dkappa, s, &traj[4 * i]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Occupancy grid (map_collision is a stub in the reference, utils/utils.py:297-301: BUILD-DEFINED)  */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct orc_grid {
+    const uint8_t* img; /* [h][w], row 0 = top (ROS map_server image layout) */
+    int32_t w, h;
+    double res, ox, oy;
+    int32_t occupied_below;
+} orc_grid;
+
+ORC_API int orc_cell_occupied(const orc_grid* g, double x, double y) {
+    double fx = floor((x - g->ox) / g->res);
+    double fy = floor((y - g->oy) / g->res);
+    if (!(fx >= 0.0) || !(fy >= 0.0) || !(fx < (double)g->w) || !(fy < (double)g->h)) return 1; /* outside / NaN */
+    int gx = (int)fx, gy = (int)fy;
+    return g->img[(size_t)(g->h - 1 - gy) * g->w + gx] < g->occupied_below;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Lattice planner (planning/lattice_planner/lattice_planner.py:174-214 + intent of :223-296)         */
+/* ------------------------------------------------------------------------------------------------ */
+/* goal sampling: the intent of sample_lookahead_square (:223-260).  goals [C][3] in the ego frame,
+ * valid [C].  near (i, t) from nearest_point on the raceline. */
+ORC_API void orc_lattice_goals(double px, double py, double theta, const double* wx, const double* wy,
+                               const double* wpsi, int n, const f1p_lattice_cfg* cfg, int near_i, double near_t,
+                               double* goals, uint8_t* valid) {
+    double ct = cos(theta), st = sin(theta);
+    for (int l = 0; l < cfg->n_lookahead; ++l) {
+        int i2 = 0;
+        int found = orc_intersect_point(px, py, cfg->lookahead[l], wx, wy, n, (double)near_i + near_t, 1, NULL, &i2, NULL); /* :250 */
+        int r = i2 < 0 ? i2 + n : i2;
+        for (int k = 0; k < cfg->n_width; ++k) {
+            int c = l * cfg->n_width + k;
+            if (!found) { valid[c] = 0; goals[3 * c] = goals[3 * c + 1] = goals[3 * c + 2] = 0.0; continue; }
+            double cx = wx[r], cy = wy[r], psi = wpsi[r];  /* waypoints[i2, [0, 1, 3]]  :251 */
+            double w = cfg->width[k];
+            double gx = cx + w * (-sin(psi));              /* lateral offset along the path normal (:256 intent) */
+            double gy = cy + w * cos(psi);
+            double dx = gx - px, dy = gy - py;
+            goals[3 * c + 0] = ct * dx + st * dy;          /* rotate into the ego frame (:258-259 intent) */
+            goals[3 * c + 1] = -st * dx + ct * dy;
+            goals[3 * c + 2] = remainder(psi - theta, 2.0 * M_PI);
+            valid[c] = 1;
+        }
+    }
+}
+
+/* tracker on the winner: PurePursuitPlanner.plan(0, 0, 0, L, best_traj) in the ego frame
+ * (lattice_planner.py:208-212), speed column replaced by `speed_cmd` (the reference reads theta there) */
+static int orc_track_traj(const double* traj, int S, double lookahead, double wheelbase, double max_reacquire,
+                          double speed_cmd, double* steer, double* speed) {
+    double* tx = (double*)malloc(sizeof(double) * 3 * (size_t)S);
+    double *ty = tx + S, *tv = ty + S;
+    for (int i = 0; i < S; ++i) { tx[i] = traj[4 * i]; ty[i] = traj[4 * i + 1]; tv[i] = speed_cmd; }
+    int st = orc_pure_pursuit_plan(0.0, 0.0, 0.0, lookahead, wheelbase, max_reacquire, tx, ty, tv, S, steer, speed, NULL, NULL);
+    free(tx);
+    return st;
+}
+
+/* one candidate: fit, sample, cost.  Returns the cost (+inf when infeasible / in collision).
+ * traj_out may be NULL. */
+static double orc_lattice_candidate(const double* goal, int goal_valid, double px, double py, double ct, double st,
+                                    const f1p_lattice_cfg* cfg, const orc_grid* grid, const double* prev_theta,
+                                    double* traj_out /*[S][4]*/, double* scratch /*[S][4]*/) {
+    int S = cfg->n_stations;
+    double* tr = traj_out ? traj_out : scratch;
+    double k0, dk, L;
+    if (!goal_valid || !orc_clothoid_g1(goal[0], goal[1], goal[2], &k0, &dk, &L)) {
+        for (int i = 0; i < 4 * S; ++i) tr[i] = 0.0;
+        return INFINITY;
+    }
+    orc_sample_traj(k0, dk, L, S, tr);
+    double maxk = 0.0, sumk = 0.0, sim = 0.0;
+    int collide = 0;
+    for (int i = 0; i < S; ++i) {
+        double ak = fabs(tr[4 * i + 3]);
+        if (ak > maxk) maxk = ak;
+        sumk += ak;
+        if (cfg->check_collision && grid && grid->img) {
+            double xm = px + (ct * tr[4 * i] - st * tr[4 * i + 1]);
+            double ym = py + (st * tr[4 * i] + ct * tr[4 * i + 1]);
+            if (orc_cell_occupied(grid, xm, ym)) collide = 1;
+        }
+    }
+    if (prev_theta) { /* get_similarity_cost :287-296 with N = S */
+        int m = S - cfg->n_shift - cfg->n_cull;
+        for (int j = 0; j < m; ++j) {
+            double d = tr[4 * j + 2] - prev_theta[j + cfg->n_shift];
+            sim += d * d;
+        }
+    }
+    double cost = 0.0; /* eval :150-155: cost = 0; cost += w_i * f_i */
+    cost += cfg->w_length * (1.0 / L);
+    cost += cfg->w_max_kappa * maxk;
+    cost += cfg->w_mean_kappa * (sumk / S);
+    cost += cfg->w_similarity * sim;
+    if (collide) cost = INFINITY;
+    return cost;
+}
+
+/* LatticePlanner.plan for one ego.  goals_in NULL = device-style sampling from cfg. */
+ORC_API int orc_lattice_plan(const double* pose /*x,y,theta,v*/, const double* goals_in, const double* prev_theta,
+                             const double* wx, const double* wy, const double* wv, const double* wpsi, int n,
+                             const orc_grid* grid, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                             int32_t* best_idx, double* best_cost, int32_t* near_idx, double* best_traj /*[S][4]*/,
+                             double* all_cost /*[C]*/, double* all_traj /*[C][S][4]*/) {
+    int C = cfg->n_lookahead * cfg->n_width, S = cfg->n_stations;
+    double px = pose[0], py = pose[1], theta = pose[2];
+    double ndist, nt;
+    int ni;
+    orc_nearest_point(px, py, wx, wy, n, NULL, &ndist, &nt, &ni);
+    if (near_idx) *near_idx = ni;
+    double* goals = (double*)malloc(sizeof(double) * 3 * (size_t)C);
+    uint8_t* valid = (uint8_t*)malloc((size_t)C);
+    if (goals_in) {
+        memcpy(goals, goals_in, sizeof(double) * 3 * (size_t)C);
+        for (int c = 0; c < C; ++c) valid[c] = isfinite(goals[3 * c]) && isfinite(goals[3 * c + 1]) && isfinite(goals[3 * c + 2]);
+    } else {
+        orc_lattice_goals(px, py, theta, wx, wy, wpsi, n, cfg, ni, nt, goals, valid);
+    }
+    double ct = cos(theta), st = sin(theta);
+    double* scratch = (double*)malloc(sizeof(double) * 4 * (size_t)S);
+    int c0 = cfg->cand_begin, c1 = cfg->cand_count > 0 ? cfg->cand_begin + cfg->cand_count : C;
+    double bc = 0.0;
+    int bi = -1;
+    for (int c = c0; c < c1; ++c) {
+        double* tr = all_traj ? &all_traj[(size_t)c * S * 4] : NULL;
+        double cost = orc_lattice_candidate(&goals[3 * c], valid[c], px, py, ct, st, cfg, grid, prev_theta, tr, scratch);
+        if (all_cost) all_cost[c] = cost;
+        if (bi < 0 || cost < bc) { bc = cost; bi = c; } /* np.argmin: first minimum (:170) */
+    }
+    *best_idx = bi;
+    if (best_cost) *best_cost = bc;
+    int status;
+    double* bt = best_traj ? best_traj : scratch;
+    (void)orc_lattice_candidate(&goals[3 * bi], valid[bi], px, py, ct, st, cfg, NULL, NULL, bt, scratch);
+    if (isinf(bc)) {
+        *steer = 0.0; *speed = 0.0; status = F1P_ST_ALL_BLOCKED;
+    } else {
+        status = orc_track_traj(bt, S, cfg->track_lookahead, cfg->wheelbase, cfg->max_reacquire, wv[ni], steer, speed);
+    }
+    free(scratch); free(valid); free(goals);
+    return status;
+}
+
+ORC_API void orc_lattice_plan_batch(const double* poses, const double* goals, const double* prev_theta, int E,
+                                    const double* wx, const double* wy, const double* wv, const double* wpsi, int n,
+                                    const orc_grid* grid, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                                    int32_t* best_idx, double* best_cost, int32_t* status, int32_t* near_idx,
+                                    double* best_traj, double* all_cost, double* all_traj, int nthreads) {
+    int C = cfg->n_lookahead * cfg->n_width, S = cfg->n_stations;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        double bc;
+        int32_t ni;
+        int st = orc_lattice_plan(&poses[4 * e], goals ? &goals[(size_t)e * C * 3] : NULL,
+                                  prev_theta ? &prev_theta[(size_t)e * S] : NULL, wx, wy, wv, wpsi, n, grid, cfg,
+                                  &steer[e], &speed[e], &best_idx[e], &bc, &ni,
+                                  best_traj ? &best_traj[(size_t)e * S * 4] : NULL,
+                                  all_cost ? &all_cost[(size_t)e * C] : NULL,
+                                  all_traj ? &all_traj[(size_t)e * C * S * 4] : NULL);
+        if (best_cost) best_cost[e] = bc;
+        if (status) status[e] = st;
+        if (near_idx) near_idx[e] = ni;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Kinematic MPC rollout (control/kinematic_mpc/kinematic_mpc.py)                                    */
+/* ------------------------------------------------------------------------------------------------ */
+/* update_state_kinematic :223-243; state = [x, y, v, yaw] */
+ORC_API void orc_update_state_kinematic(double* s, double a, double delta, const f1p_kmpc_cfg* c) {
+    if (delta >= c->max_steer) delta = c->max_steer;          /* :226-229 */
+    else if (delta <= -c->max_steer) delta = -c->max_steer;
+    double x = s[0], y = s[1], v = s[2], yaw = s[3];
+    s[0] = x + v * cos(yaw) * c->dt;                          /* :231 */
+    s[1] = y + v * sin(yaw) * c->dt;                          /* :232 */
+    s[3] = yaw + (v / c->wheelbase) * tan(delta) * c->dt;     /* :233-235 */
+    v = v + a * c->dt;                                        /* :236 */
+    if (v > c->max_speed) v = c->max_speed;                   /* :238-241 */
+    else if (v < c->min_speed) v = c->min_speed;
+    s[2] = v;
+}
+
+/* predict_motion_kinematic :208-221: path [4][T+1] */
+ORC_API void orc_predict_motion_kinematic(const double* x0, const double* oa, const double* od, const f1p_kmpc_cfg* c,
+                                          double* path) {
+    int T = c->horizon;
+    double s[4] = {x0[0], x0[1], x0[2], x0[3]};
+    for (int k = 0; k < 4; ++k) path[k * (T + 1)] = x0[k];
+    for (int i = 1; i <= T; ++i) {
+        orc_update_state_kinematic(s, oa[i - 1], od[i - 1], c);
+        for (int k = 0; k < 4; ++k) path[k * (T + 1) + i] = s[k];
+    }
+}
+
+/* calc_ref_trajectory_kinematic :162-206.  cyaw_work [n] is a scratch copy that receives the in-place
+ * fix-up of :198-203 (pass a copy: the reference mutates its input). ref [4][T+1] */
+ORC_API void orc_calc_ref_trajectory(double sx, double sy, double sv, double syaw, const double* cx, const double* cy,
+                                     double* cyaw_work, const double* sp, int n, int T, double dt, double dl,
+                                     double* ref) {
+    int ind;
+    orc_nearest_point(sx, sy, cx, cy, n, NULL, NULL, NULL, &ind); /* :180 */
+    double travel = fabs(sv) * dt;                                /* :189 */
+    double dind = travel / dl;                                    /* :190 */
+    for (int i = 0; i < n; ++i) {                                 /* :198-203 */
+        if (cyaw_work[i] - syaw > 4.5) cyaw_work[i] = fabs(cyaw_work[i] - (2 * M_PI));
+    }
+    for (int i = 0; i < n; ++i) {
+        if (cyaw_work[i] - syaw < -4.5) cyaw_work[i] = fabs(cyaw_work[i] + (2 * M_PI));
+    }
+    double cum = 0.0;
+    for (int j = 0; j <= T; ++j) { /* :191-194  int(ind) + insert(cumsum(repeat(dind, T)), 0, 0).astype(int) */
+        if (j > 0) cum += dind;
+        int il = ind + (int)cum;
+        if (il >= n) il -= n;
+        ref[0 * (T + 1) + j] = cx[il];
+        ref[1 * (T + 1) + j] = cy[il];
+        ref[2 * (T + 1) + j] = sp[il];
+        ref[3 * (T + 1) + j] = cyaw_work[il];
+    }
+}
+
+/* Shooting-MPC objective for one rollout (BUILD-DEFINED driver; arithmetic of :324-334 on the nonlinear
+ * rollout of :208-243).  ctrl_a/ctrl_d are the raw candidates (stride `stride` between time steps).
+ * Bound projection (:391-401): a <- clip(a, +-max_accel), delta <- clip(delta, +-max_steer), then
+ * |delta_t - delta_{t-1}| <= max_dsteer*dt by clipping delta_t against the previous APPLIED delta.
+ * seq_out [T][2] (nullable) receives the applied controls. */
+ORC_API double orc_kmpc_rollout_cost(const double* x0, const double* ref /*[4][T+1]*/, const float* ctrl_a,
+                                     const float* ctrl_d, size_t stride, const f1p_kmpc_cfg* c, double* seq_out) {
+    int T = c->horizon;
+    double s[4] = {x0[0], x0[1], x0[2], x0[3]};
+    double cost = 0.0;
+    double pa = 0.0, pd = 0.0;
+    double dmax = c->max_dsteer * c->dt;
+    for (int t = 0; t < T; ++t) {
+        double a = (double)ctrl_a[(size_t)t * stride];
+        double d = (double)ctrl_d[(size_t)t * stride];
+        if (a > c->max_accel) a = c->max_accel; else if (a < -c->max_accel) a = -c->max_accel;
+        if (d > c->max_steer) d = c->max_steer; else if (d < -c->max_steer) d = -c->max_steer;
+        if (t > 0) {
+            if (d > pd + dmax) d = pd + dmax; else if (d < pd - dmax) d = pd - dmax;
+        }
+        /* state error at step t (Q) -- objective 2 (:331) */
+        double e0 = s[0] - ref[0 * (T + 1) + t], e1 = s[1] - ref[1 * (T + 1) + t];
+        double e2 = s[2] - ref[2 * (T + 1) + t], e3 = s[3] - ref[3 * (T + 1) + t];
+        cost += ((c->q[0] * e0 * e0 + c->q[1] * e1 * e1) + c->q[2] * e2 * e2) + c->q[3] * e3 * e3;
+        /* input cost -- objective 1 (:328) */
+        cost += c->r[0] * a * a + c->r[1] * d * d;
+        /* input difference -- objective 3 (:334) */
+        if (t > 0) {
+            double da = a - pa, dd = d - pd;
+            cost += c->rd[0] * da * da + c->rd[1] * dd * dd;
+        }
+        if (seq_out) { seq_out[2 * t] = a; seq_out[2 * t + 1] = d; }
+        orc_update_state_kinematic(s, a, d, c);
+        pa = a; pd = d;
+    }
+    {
+        double e0 = s[0] - ref[0 * (T + 1) + T], e1 = s[1] - ref[1 * (T + 1) + T];
+        double e2 = s[2] - ref[2 * (T + 1) + T], e3 = s[3] - ref[3 * (T + 1) + T];
+        cost += ((c->qf[0] * e0 * e0 + c->qf[1] * e1 * e1) + c->qf[2] * e2 * e2) + c->qf[3] * e3 * e3;
+    }
+    return cost;
+}
+
+/* x0 [E][4], ref [E][4][T+1], controls [E][T][2][R] f32 */
+ORC_API void orc_kmpc_shoot_batch(const double* x0, const double* ref, const float* controls, int E,
+                                  const f1p_kmpc_cfg* c, double* steer, double* speed, int32_t* best_idx,
+                                  double* best_cost, double* best_seq, double* all_cost, int nthreads) {
+    int T = c->horizon, R = c->n_rollouts;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        const float* ce = &controls[(size_t)e * T * 2 * R];
+        const double* re = &ref[(size_t)e * 4 * (T + 1)];
+        double bc = 0.0;
+        int bi = -1;
+        for (int r = 0; r < R; ++r) {
+            double cost = orc_kmpc_rollout_cost(&x0[4 * e], re, ce + r, ce + R + r, (size_t)2 * R, c, NULL);
+            if (all_cost) all_cost[(size_t)e * R + r] = cost;
+            if (bi < 0 || cost < bc || (isnan(cost) && !isnan(bc))) { bc = cost; bi = r; }
+        }
+        double* seq = (double*)malloc(sizeof(double) * 2 * (size_t)T);
+        (void)orc_kmpc_rollout_cost(&x0[4 * e], re, ce + bi, ce + R + bi, (size_t)2 * R, c, seq);
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+        steer[e] = seq[1];                          /* :506  steer_output = odelta_v[0]            */
+        speed[e] = x0[4 * e + 2] + seq[0] * c->dt;  /* :508  speed_output = v + oa[0]*DTK          */
+        if (best_seq) memcpy(&best_seq[(size_t)e * T * 2], seq, sizeof(double) * 2 * (size_t)T);
+        free(seq);
+    }
+}
+
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,136 @@
+"""The CPU oracle against golden vectors captured from the imported reference (tools/gen_golden.py).
+
+These pin every oracle row that restates runnable reference code: indices exact; nearest_point and
+intersect_point floats BIT-exact (the oracle reproduces the fused multiply-add inside np.dot, see dot2 in
+oracle/f1p_oracle.c); values that pass through numpy's sin/cos/arctan to 1e-12.
+"""
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd._abi import kmpc_cfg
+
+TOL = 1e-12
+
+
+@pytest.mark.parametrize("name,cols", [("spielberg", (0, 1)), ("levine", (1, 2))])
+def test_nearest_point_golden(orc, golden, tracks, name, cols):
+    g = golden("g1_g2_nearest_intersect.npz")
+    wp = tracks[name][:, list(cols)]
+    pts = g[f"{name}_pts"]
+    for j in range(len(pts)):
+        proj, d, t, i = orc.nearest_point(pts[j], wp)
+        assert i == g[f"{name}_idx"][j], j
+        assert d == g[f"{name}_dist"][j] and t == g[f"{name}_t"][j]          # bit-exact fp64
+        np.testing.assert_array_equal(proj, g[f"{name}_proj"][j])
+
+
+@pytest.mark.parametrize("name,cols", [("spielberg", (0, 1)), ("levine", (1, 2))])
+def test_intersect_point_golden(orc, golden, tracks, name, cols):
+    g = golden("g1_g2_nearest_intersect.npz")
+    wp = tracks[name][:, list(cols)]
+    pts = g[f"{name}_pts"]; idx = g[f"{name}_idx"]; tt = g[f"{name}_t"]
+    radii = g[f"{name}_int_radii"]
+    n_none = n_hit = 0
+    for a, j in enumerate(g[f"{name}_int_sel"]):
+        for b, r in enumerate(radii):
+            for c, wrap in enumerate((False, True)):
+                p, i2, t2 = orc.intersect_point(pts[j], r, wp, idx[j] + tt[j], wrap=wrap)
+                gi = g[f"{name}_int_i"][a, b, c]
+                if gi == -9999:
+                    assert i2 is None; n_none += 1
+                else:
+                    assert i2 == gi, (j, r, wrap); n_hit += 1
+                    assert t2 == g[f"{name}_int_t"][a, b, c]                   # bit-exact fp64
+                    np.testing.assert_array_equal(p, g[f"{name}_int_p"][a, b, c])
+    assert n_none > 0 and n_hit > 0
+    # explicit start indices: long scans, wrap, start past the end
+    for a in range(g[f"{name}_int2_i"].shape[0]):
+        for b, st in enumerate(g[f"{name}_int2_starts"]):
+            p, i2, t2 = orc.intersect_point(pts[a], 0.8, wp, st, wrap=True)
+            gi = g[f"{name}_int2_i"][a, b]
+            assert (i2 is None) if gi == -9999 else (i2 == gi)
+    # closing segment: first_i == -1
+    seen_neg = 0
+    for a, q in enumerate(g[f"{name}_int3_pts"]):
+        p, i2, t2 = orc.intersect_point(q, 0.8, wp, len(wp) - 1.0, wrap=True)
+        gi = g[f"{name}_int3_i"][a]
+        assert (i2 is None) if gi == -9999 else (i2 == gi)
+        if gi == -1:
+            seen_neg += 1
+            assert abs(t2 - g[f"{name}_int3_t"][a]) <= 1e-6
+    assert seen_neg > 0
+
+
+def test_get_actuation_and_angles_golden(orc, golden):
+    g = golden("g3_g9_actuation_angles.npz")
+    for j in range(len(g["theta"])):
+        sp, st = orc.get_actuation(g["theta"][j], g["lookahead_point"][j], g["position"][j], g["L"][j], g["wheelbase"][j])
+        assert abs(sp - g["speed_steer"][j, 0]) <= TOL and abs(st - g["speed_steer"][j, 1]) <= TOL
+    assert (g["speed_steer"][:8, 1] == 0).all()           # the |y| < 1e-6 rows
+    for a, w in zip(g["angles"], g["pi_2_pi"]):
+        assert orc.pi_2_pi(a) == w
+    assert abs(orc.pi_2_pi(7.0) - 0.7168146928204138) < 1e-15   # single wrap, not a modulo
+
+
+def test_pure_pursuit_plan_golden(orc, golden, tracks):
+    g = golden("g4_pure_pursuit.npz")
+    spl = tracks["spielberg"]
+    for L in np.unique(g["lookahead"]):
+        m = g["lookahead"] == L
+        out = orc.pure_pursuit_batch(g["poses"][m], spl, L)
+        np.testing.assert_allclose(out["steer"], g["steer_speed"][m, 0], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["speed"], g["steer_speed"][m, 1], rtol=0, atol=1e-12)
+    out = orc.pure_pursuit_batch(g["poses"][:3], spl, 0.8)
+    assert list(out["status"]) == [0, 1, 2]                  # intersect / reacquire / none branches
+    assert out["near_idx"][0] == 1690                        # SURVEY section 4 probe
+    assert abs(out["steer"][0] - (-0.00035935558090650324)) < 1e-12 and out["speed"][0] == 8.0
+    assert abs(out["steer"][1] - (-1.4495958413349037)) < 1e-12
+    lev3 = tracks["levine"][:, [1, 2, 5]]
+    out = orc.pure_pursuit_batch(g["lev_poses"], lev3, 0.6, wheelbase=float(g["lev_wheelbase"]))
+    np.testing.assert_allclose(out["steer"], g["lev_steer_speed"][:, 0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["speed"], g["lev_steer_speed"][:, 1], rtol=0, atol=1e-12)
+    assert (out["la_idx"] == -1).any() or (out["la_idx"] == 0).any()   # seam rows were exercised
+
+
+def test_kmpc_rollout_golden(orc, golden):
+    g = golden("g5_g6_kmpc.npz")
+    cfg = kmpc_cfg()
+    sc = g["cfg_scalars"]
+    assert (sc == np.array([cfg.horizon, cfg.dt, 0.03, cfg.wheelbase, cfg.max_steer, cfg.max_dsteer, cfg.max_speed,
+                            cfg.min_speed, cfg.max_accel])).all()
+    assert (np.diag(g["cfg_Qk"]) == np.array(cfg.q[:])).all() and (np.diag(g["cfg_Qfk"]) == np.array(cfg.qf[:])).all()
+    assert (np.diag(g["cfg_Rk"]) == np.array(cfg.r[:])).all() and (np.diag(g["cfg_Rdk"]) == np.array(cfg.rd[:])).all()
+    for j in range(len(g["step_a"])):
+        s = orc.update_state_kinematic(g["step_state"][j], g["step_a"][j], g["step_delta"][j], cfg)
+        np.testing.assert_allclose(s, g["step_out"][j], rtol=0, atol=1e-13)
+    for T in (8, 30):
+        c = kmpc_cfg(horizon=T)
+        for j in range(len(g[f"roll{T}_x0"])):
+            path = orc.predict_motion_kinematic(g[f"roll{T}_x0"][j], g[f"roll{T}_oa"][j], g[f"roll{T}_od"][j], c)
+            np.testing.assert_allclose(path, g[f"roll{T}_path"][j], rtol=0, atol=1e-11)
+    p = orc.predict_motion_kinematic([2.51, 3.29, 1.0, 1.58], [1.0] * 8, [0.1] * 8, kmpc_cfg())
+    np.testing.assert_allclose(p[:, -1], [2.34684922, 4.35313074, 1.8, 1.90836802], atol=1e-8)   # SURVEY 8c probe
+
+
+def test_kmpc_ref_trajectory_golden(orc, golden, tracks):
+    g = golden("g5_g6_kmpc.npz")
+    lev = tracks["levine"]
+    cx, cy, cyaw, sp = lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5]
+    for T in (8, 30):
+        st = g[f"ref{T}_state"]
+        for j in range(len(st)):
+            ref, cw = orc.calc_ref_trajectory(st[j], cx, cy, cyaw, sp, T)
+            np.testing.assert_array_equal(ref, g[f"ref{T}_out"][j])       # pure gathers: exact
+            assert bool(np.any(cw != cyaw)) == bool(g[f"ref{T}_cyaw_changed"][j])
+            if j == 5:
+                np.testing.assert_array_equal(cw, g[f"ref{T}_cyaw_after5"])
+            if j == 6:
+                np.testing.assert_array_equal(cw, g[f"ref{T}_cyaw_after6"])
+
+
+def test_sample_traj_layout_golden(orc, golden):
+    g = golden("g7_g8_lattice.npz")
+    R, L = float(g["arc_R"]), float(g["arc_L"])
+    np.testing.assert_allclose(orc.sample_traj(1.0 / R, 0.0, L, 50), g["arc_traj"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(orc.sample_traj(1.0 / R, 0.0, L, 1), g["arc_traj1"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(orc.sample_traj(0.0, 0.0, float(g["line_L"]), 100), g["line_traj"], rtol=0, atol=1e-13)
