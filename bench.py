@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate-trajectory-steps/sec of the batched lattice planner on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one batched LatticePlanner.plan() over a batch of synthetic egos (BASELINE.json configs[2]:
+4096 egos x 256 candidates x 50 stations) through the C-ABI, inputs already resident in HBM when the timed
+region starts.  Egos are independent, so with N ranks every rank plans its own 4096 egos on its own GPU with no
+data-path collective (weak scaling); the ranks only meet in the barrier around the timed region and in the
+max-over-ranks of the elapsed time (gloo, CPU tensors -- torch never touches the GPU in this process).
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  roofline     -- the dominant kernel (k_lattice) against the HBM roofline: algorithmic bytes per launch / the
+                  kernel's average duration from HIP events on the ctx stream; the kernel is fp64-VALU bound by
+                  construction (0.14 B per candidate-step), so the fp64 VALU fraction is reported next to it
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the same
+                  workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from f1tenth_planning_amd import _abi, synth  # noqa: E402
+from f1tenth_planning_amd.runtime import Context  # noqa: E402  (loads libf1p.so before torch is imported)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64
+
+
+def algorithmic_bytes_lattice(E, C, S, n_wp, grid_w, grid_h, device_goals=True):
+    """SURVEY.md 8(d), fp64 payloads: poses in, (goals in), waypoints + bit-packed grid once, scalars + best_traj out."""
+    b = E * 32                                   # poses [E][4] f64
+    if not device_goals:
+        b += E * C * 24                          # goals [E][C][3] f64
+    b += n_wp * 32                               # waypoints x, y, v, psi f64 (read once, then cache-resident)
+    b += ((grid_w + 31) // 32) * 4 * grid_h      # bit-packed occupancy (read once)
+    b += E * (8 + 8 + 4 + 8 + 4 + 4)             # steer, speed, best_idx, best_cost, status, near_idx
+    b += E * S * 32                              # best_traj [E][S][4] f64
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--egos", type=int, default=4096)
+    ap.add_argument("--cands", type=int, default=256)
+    ap.add_argument("--stations", type=int, default=50)
+    ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    E, C, S = args.egos, args.cands, args.stations
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    rl = synth.make_raceline(seed=0)
+    res = 0.058
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=res)
+    poses = synth.make_egos(rl, E, seed=1 + rank)          # every rank plans its own egos
+
+    ctx = Context(local_rank)
+    ctx.set_waypoints(rl)
+    ctx.set_grid(img, res, origin, 206)
+    d_poses = ctx.to_device(poses)
+    d_steer, d_speed = ctx.alloc(8 * E), ctx.alloc(8 * E)
+    d_bidx, d_bcost, d_status, d_near = ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E)
+    d_traj = ctx.alloc(8 * E * S * 4)
+
+    def step():
+        ctx.lattice_plan_dev(d_poses, E, cfg, d_steer, d_speed, d_bidx, d_bcost, d_status, d_near, d_traj)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod   # CPU-only use: gloo barrier + max
+        dist = dist_mod
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    if dist:
+        dist.barrier()
+    ctx.timer_begin()                                       # HIP events on the stream the kernel runs on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms_total = ctx.timer_end()                       # synchronises the stream
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # parity gate that travels with every measurement: a seeded subset against the oracle (rank 0)
+    steer = d_steer.download(np.float64, (E,))
+    bidx = d_bidx.download(np.int32, (E,))
+    status = d_status.download(np.int32, (E,))
+
+    out = None
+    if rank == 0:
+        steps_total = float(E) * C * S * args.steps * world
+        value = steps_total / elapsed
+        kernel_ms = kernel_ms_total / args.steps
+        abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0])
+        achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9
+        # fp64 op-equivalents per candidate-step, counted from the kernel source (DESIGN.md "K3 work"):
+        #   station body ~40 + 4 sincos(~50 each) per interval, G1 fit ~4 Newton evaluations x 16 sincos per candidate
+        flop_per_step = 40 + 4 * 50 + (4 * 16 * 60) / S
+        valu_tflops = flop_per_step * E * C * S / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "candidate-trajectory-steps/sec per GPU; p50 plan() latency @4096 egos",
+            "value": value, "unit": "candidate-trajectory-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batched lattice: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[2])",
+                       "egos_per_gpu": E, "candidates": C, "stations": S, "raceline_points": int(rl.shape[0]),
+                       "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16),
+                       "parallelism": f"egos sharded over {world} GPU(s), no collective"},
+            "per_gpu_value": value / world,
+            "p50_plan_latency_ms": elapsed / args.steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_lattice",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                         "bytes_per_candidate_step": abytes / (E * C * S),
+                         "note": "fused kernel is fp64-VALU/transcendental bound by construction; HBM fraction is tiny",
+                         "valu_fp64": {"achieved_tflops_equiv": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                                       "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
+                                       "op_equivalents_per_step": flop_per_step}},
+            "blocked_egos": int((status == _abi.ST_ALL_BLOCKED).sum()),
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle   # the checker / CPU baseline leg only
+            nthr = oracle.max_threads()
+            grid = (img, res, origin[0], origin[1], 206)
+            n_cpu = args.cpu_egos
+            if n_cpu <= 0:
+                t1 = time.perf_counter()
+                oracle.lattice_plan_batch(poses[:nthr], rl, cfg, grid=grid, nthreads=nthr)
+                per_ego = (time.perf_counter() - t1) / nthr
+                n_cpu = int(min(E, max(nthr, (12.0 / max(per_ego, 1e-6)) // nthr * nthr)))
+            t1 = time.perf_counter()
+            want = oracle.lattice_plan_batch(poses[:n_cpu], rl, cfg, grid=grid, nthreads=nthr)
+            cpu_s = time.perf_counter() - t1
+            mism = int((want["best_idx"] != bidx[:n_cpu]).sum())
+            dsteer = float(np.abs(want["steer"] - steer[:n_cpu]).max())
+            out["cpu_baseline"] = {"value": n_cpu * C * S / cpu_s, "unit": "candidate-trajectory-steps/s", "cores": nthr,
+                                   "kind": "port",
+                                   "sample": f"first {n_cpu} of the {E} egos x {C} candidates x {S} stations, oracle/f1p_oracle.c "
+                                             f"(fp64 C, OpenMP over egos, {nthr} threads), {cpu_s:.1f} s"}
+            out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": mism, "max_abs_dsteer": dsteer}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,582 @@
+// f1p_api.hip -- the extern "C" surface of libf1p.so (include/f1p.h): context, device memory, scene upload,
+// host-pointer wrappers around the kernel launchers, and the RCCL exchange step.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "f1p_internal.h"
+
+static thread_local std::string g_create_error;
+
+namespace f1p {
+
+int set_error(f1p_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int check_hip(f1p_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return F1P_OK;
+    const int code = (e == hipErrorOutOfMemory) ? F1P_ENOMEM : F1P_EHIP;
+    return set_error(ctx, code, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int arena_reset(f1p_ctx* ctx, size_t need_bytes) {
+    ctx->arena_used = 0;
+    if (need_bytes <= ctx->arena_bytes) return F1P_OK;
+    if (ctx->d_arena) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_arena); ctx->d_arena = nullptr; ctx->arena_bytes = 0; }
+    size_t want = need_bytes + (need_bytes >> 2) + 4096;
+    F1P_HIP(ctx, hipMalloc((void**)&ctx->d_arena, want));
+    ctx->arena_bytes = want;
+    return F1P_OK;
+}
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+void* arena_take(f1p_ctx* ctx, size_t bytes) {
+    void* p = ctx->d_arena + ctx->arena_used;
+    ctx->arena_used += al256(bytes);
+    return p;
+}
+
+GridDev grid_dev(const f1p_ctx* ctx) {
+    GridDev g;
+    g.bits = ctx->d_bits; g.w = ctx->gw; g.h = ctx->gh; g.wwords = ctx->gwwords;
+    g.inv_res = ctx->inv_res; g.ox = ctx->ox; g.oy = ctx->oy;
+    return g;
+}
+
+// staged host<->device transfer plan for the *_batch wrappers
+struct Stage {
+    f1p_ctx* ctx;
+    struct Out { void* host; void* dev; size_t bytes; };
+    std::vector<Out> outs;
+    size_t total = 0;
+    explicit Stage(f1p_ctx* c) : ctx(c) {}
+    void need(size_t bytes, bool used = true) { if (used) total += al256(bytes); }
+    int begin() { return arena_reset(ctx, total); }
+    template <typename T> int in(const T* host, size_t count, const T** dev) {
+        *dev = nullptr;
+        if (!host || count == 0) return F1P_OK;
+        T* d = (T*)arena_take(ctx, count * sizeof(T));
+        F1P_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        *dev = d;
+        return F1P_OK;
+    }
+    template <typename T> T* out(T* host, size_t count) {
+        if (!host || count == 0) return nullptr;
+        T* d = (T*)arena_take(ctx, count * sizeof(T));
+        outs.push_back({(void*)host, (void*)d, count * sizeof(T)});
+        return d;
+    }
+    int finish() {
+        for (auto& o : outs) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return F1P_OK;
+    }
+};
+
+static int validate_lattice(f1p_ctx* ctx, const f1p_lattice_cfg* cfg, int E, bool device_goals, bool need_outputs_ok) {
+    if (!cfg) return set_error(ctx, F1P_EINVAL, "cfg is NULL");
+    if (E < 0) return set_error(ctx, F1P_EINVAL, "E must be >= 0");
+    if (!need_outputs_ok) return set_error(ctx, F1P_EINVAL, "steer, speed and best_idx outputs are required");
+    if (cfg->n_stations < 2 || cfg->n_stations > 1024) return set_error(ctx, F1P_EINVAL, "n_stations must be in [2, 1024]");
+    if (cfg->n_lookahead < 1 || cfg->n_lookahead > F1P_MAX_LOOKAHEADS || cfg->n_width < 1 || cfg->n_width > F1P_MAX_WIDTHS)
+        return set_error(ctx, F1P_EINVAL, "n_lookahead / n_width out of range [1, 64]");
+    if (cfg->n_shift < 0 || cfg->n_cull < 0) return set_error(ctx, F1P_EINVAL, "n_shift and n_cull must be >= 0");
+    const int C = cfg->n_lookahead * cfg->n_width;
+    if (cfg->cand_begin < 0 || cfg->cand_count < 0 || cfg->cand_begin + cfg->cand_count > C || (cfg->cand_count == 0 && cfg->cand_begin != 0))
+        return set_error(ctx, F1P_EINVAL, "candidate shard [cand_begin, cand_begin+cand_count) outside [0, C)");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "waypoints not set: call f1p_set_waypoints first");
+    if (device_goals && !ctx->has_psi) return set_error(ctx, F1P_ESTATE, "device goal sampling needs a heading column (col_psi >= 0)");
+    return F1P_OK;
+}
+
+static int validate_kmpc(f1p_ctx* ctx, const f1p_kmpc_cfg* cfg, int E) {
+    if (!cfg) return set_error(ctx, F1P_EINVAL, "cfg is NULL");
+    if (E < 0) return set_error(ctx, F1P_EINVAL, "E must be >= 0");
+    if (cfg->horizon < 1 || cfg->horizon > 4096) return set_error(ctx, F1P_EINVAL, "horizon must be in [1, 4096]");
+    if (cfg->n_rollouts < 1) return set_error(ctx, F1P_EINVAL, "n_rollouts must be >= 1");
+    if (!(cfg->dt > 0) || !(cfg->wheelbase > 0)) return set_error(ctx, F1P_EINVAL, "dt and wheelbase must be > 0");
+    return F1P_OK;
+}
+
+}  // namespace f1p
+
+using namespace f1p;
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL, loaded with dlopen so libf1p.so itself has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------------
+typedef struct { char internal[F1P_COMM_ID_BYTES]; } rccl_unique_id;
+typedef int (*pfn_ncclGetUniqueId)(rccl_unique_id*);
+typedef int (*pfn_ncclCommInitRank)(void**, int, rccl_unique_id, int);
+typedef int (*pfn_ncclCommDestroy)(void*);
+typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*pfn_ncclGetErrorString)(int);
+enum { RCCL_INT32 = 2, RCCL_FLOAT64 = 8, RCCL_MIN = 3 };   // ncclInt32, ncclFloat64, ncclMin (nccl.h enums)
+
+static int rccl_open(f1p_ctx* ctx) {
+    if (ctx->rccl_lib) return F1P_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        ctx->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (ctx->rccl_lib) return F1P_OK;
+    }
+    return set_error(ctx, F1P_ECOMM, std::string("cannot load librccl.so: ") + dlerror());
+}
+
+template <typename F> static F rccl_sym(f1p_ctx* ctx, const char* name) { return (F)dlsym(ctx->rccl_lib, name); }
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+void f1p_lattice_cfg_default(f1p_lattice_cfg* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->n_stations = 100;                                   // lattice_planner.py:197
+    cfg->n_lookahead = 4;                                    // :228
+    cfg->n_width = 7;                                        // :229
+    const double la[4] = {0.4, 0.6, 0.8, 1.0};
+    for (int i = 0; i < 4; ++i) cfg->lookahead[i] = la[i];
+    for (int i = 0; i < 7; ++i) cfg->width[i] = -1.0 + (2.0 / 6.0) * i;   // np.linspace(-1, 1, 7)
+    cfg->width[6] = 1.0;
+    cfg->n_shift = 1; cfg->n_cull = 1;
+    cfg->check_collision = 1;
+    cfg->w_length = 1.0;                                     // the only example cost that runs (:268-271)
+    cfg->track_lookahead = 0.8;                              // :211
+    cfg->wheelbase = 0.33;                                   // :55 (tracker default)
+    cfg->max_reacquire = 20.0;                               // pure_pursuit.py:52
+}
+
+void f1p_kmpc_cfg_default(f1p_kmpc_cfg* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->horizon = 8; cfg->n_rollouts = 512;
+    cfg->dt = 0.1; cfg->wheelbase = 0.33; cfg->max_steer = 0.4189; cfg->max_dsteer = 3.141592653589793;
+    cfg->max_speed = 6.0; cfg->min_speed = 0.0; cfg->max_accel = 3.0;
+    const double q[4] = {13.5, 13.5, 5.5, 13.0};
+    for (int i = 0; i < 4; ++i) { cfg->q[i] = q[i]; cfg->qf[i] = q[i]; }
+    cfg->r[0] = 0.01; cfg->r[1] = 100.0; cfg->rd[0] = 0.01; cfg->rd[1] = 100.0;
+}
+
+const char* f1p_version(void) { return F1P_VERSION_STRING; }
+
+int f1p_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return F1P_ENODEV; }
+    return n;
+}
+
+int f1p_create(f1p_ctx** out, int device) {
+    if (!out) return set_error(nullptr, F1P_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(nullptr, F1P_ENODEV, std::string("no HIP device visible (") + hipGetErrorString(e) + "): libf1p.so has no CPU fallback");
+    if (device < 0 || device >= n) return set_error(nullptr, F1P_ENODEV, "device index out of range");
+    f1p_ctx* ctx = new (std::nothrow) f1p_ctx();
+    if (!ctx) return set_error(nullptr, F1P_ENOMEM, "out of host memory");
+    ctx->device = device;
+    int rc = F1P_OK;
+    do {
+        if ((e = hipSetDevice(device)) != hipSuccess) { rc = check_hip(nullptr, e, "hipSetDevice"); break; }
+        if ((e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess) { rc = check_hip(nullptr, e, "hipGetDeviceProperties"); break; }
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { rc = check_hip(nullptr, e, "hipStreamCreate"); break; }
+        if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) { rc = check_hip(nullptr, e, "hipEventCreate"); break; }
+        if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) { rc = check_hip(nullptr, e, "hipEventCreate"); break; }
+    } while (0);
+    if (rc != F1P_OK) { f1p_destroy(ctx); return rc; }
+    *out = ctx;
+    return F1P_OK;
+}
+
+void f1p_destroy(f1p_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    f1p_comm_destroy(ctx);
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->rccl_lib) dlclose(ctx->rccl_lib);
+    delete ctx;
+}
+
+const char* f1p_last_error(const f1p_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int f1p_device_info(const f1p_ctx* ctx, char* name, size_t name_len, int32_t* compute_units, char* arch, size_t arch_len) {
+    if (!ctx) return F1P_EINVAL;
+    if (name && name_len) { strncpy(name, ctx->prop.name, name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (arch && arch_len) { strncpy(arch, ctx->prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return F1P_OK;
+}
+
+#define F1P_ENTER(ctx)                                              \
+    if (!(ctx)) return F1P_EINVAL;                                  \
+    F1P_HIP((ctx), hipSetDevice((ctx)->device))
+
+int f1p_dev_alloc(f1p_ctx* ctx, void** dptr, size_t bytes) {
+    F1P_ENTER(ctx);
+    if (!dptr) return set_error(ctx, F1P_EINVAL, "dptr is NULL");
+    *dptr = nullptr;
+    F1P_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return F1P_OK;
+}
+int f1p_dev_free(f1p_ctx* ctx, void* dptr) {
+    F1P_ENTER(ctx);
+    if (dptr) F1P_HIP(ctx, hipFree(dptr));
+    return F1P_OK;
+}
+int f1p_h2d(f1p_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    F1P_ENTER(ctx);
+    if (bytes && (!dst_dev || !src_host)) return set_error(ctx, F1P_EINVAL, "NULL pointer");
+    if (bytes) F1P_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return F1P_OK;
+}
+int f1p_d2h(f1p_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    F1P_ENTER(ctx);
+    if (bytes && (!dst_host || !src_dev)) return set_error(ctx, F1P_EINVAL, "NULL pointer");
+    if (bytes) F1P_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return F1P_OK;
+}
+int f1p_memset(f1p_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+    F1P_ENTER(ctx);
+    if (bytes) F1P_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return F1P_OK;
+}
+int f1p_sync(f1p_ctx* ctx) {
+    F1P_ENTER(ctx);
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F1P_OK;
+}
+int f1p_timer_begin(f1p_ctx* ctx) {
+    F1P_ENTER(ctx);
+    F1P_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return F1P_OK;
+}
+int f1p_timer_end(f1p_ctx* ctx, float* elapsed_ms) {
+    F1P_ENTER(ctx);
+    F1P_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    F1P_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    F1P_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return F1P_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
+                      int32_t col_v, int32_t col_psi) {
+    F1P_ENTER(ctx);
+    if (!wp) return set_error(ctx, F1P_EINVAL, "waypoints pointer is NULL");
+    if (n < 2) return set_error(ctx, F1P_EINVAL, "at least 2 waypoints are required");
+    if (ncols < 3) return set_error(ctx, F1P_EINVAL, "Waypoints needs to be a (Nxm), m >= 3, numpy array!");   // pure_pursuit.py:101-102
+    auto bad = [&](int c) { return c < 0 || c >= ncols; };
+    if (bad(col_x) || bad(col_y) || bad(col_v) || (col_psi >= 0 && bad(col_psi))) return set_error(ctx, F1P_EINVAL, "column index out of range");
+    std::vector<double> soa((size_t)4 * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        soa[i] = wp[(size_t)i * ncols + col_x];
+        soa[(size_t)n + i] = wp[(size_t)i * ncols + col_y];
+        soa[(size_t)2 * n + i] = wp[(size_t)i * ncols + col_v];
+        soa[(size_t)3 * n + i] = col_psi >= 0 ? wp[(size_t)i * ncols + col_psi] : 0.0;
+    }
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n != ctx->n_wp) {
+        double** ps[] = {&ctx->d_wx, &ctx->d_wy, &ctx->d_wv, &ctx->d_wpsi};
+        for (double** p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        ctx->n_wp = 0;
+        for (double** p : ps) F1P_HIP(ctx, hipMalloc((void**)p, sizeof(double) * (size_t)n));
+    }
+    const size_t b = sizeof(double) * (size_t)n;
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wx, soa.data(), b, hipMemcpyHostToDevice));
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wy, soa.data() + n, b, hipMemcpyHostToDevice));
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wv, soa.data() + 2 * (size_t)n, b, hipMemcpyHostToDevice));
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wpsi, soa.data() + 3 * (size_t)n, b, hipMemcpyHostToDevice));
+    ctx->n_wp = n;
+    ctx->has_psi = col_psi >= 0;
+    return F1P_OK;
+}
+
+int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
+                 int32_t occupied_below) {
+    F1P_ENTER(ctx);
+    if (!img) {   // clear
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_bits) (void)hipFree(ctx->d_bits);
+        ctx->d_bits = nullptr; ctx->has_grid = false;
+        return F1P_OK;
+    }
+    if (w < 1 || h < 1 || w > 65535 || h > 65535) return set_error(ctx, F1P_EINVAL, "grid size out of range");
+    if (!(res > 0.0)) return set_error(ctx, F1P_EINVAL, "resolution must be > 0");
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_bits) { (void)hipFree(ctx->d_bits); ctx->d_bits = nullptr; ctx->has_grid = false; }
+    ctx->gw = w; ctx->gh = h; ctx->gwwords = (w + 31) / 32;
+    ctx->res = res; ctx->inv_res = 1.0 / res; ctx->ox = ox; ctx->oy = oy;
+    uint8_t* d_img = nullptr;
+    F1P_HIP(ctx, hipMalloc((void**)&d_img, (size_t)w * h));
+    int rc = check_hip(ctx, hipMalloc((void**)&ctx->d_bits, sizeof(uint32_t) * (size_t)ctx->gwwords * h), "hipMalloc(bits)");
+    if (rc == F1P_OK) rc = check_hip(ctx, hipMemcpyAsync(d_img, img, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(img)");
+    if (rc == F1P_OK) rc = launch_pack_grid(ctx, d_img, w, h, occupied_below);
+    if (rc == F1P_OK) rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    (void)hipFree(d_img);
+    if (rc != F1P_OK) { if (ctx->d_bits) (void)hipFree(ctx->d_bits); ctx->d_bits = nullptr; return rc; }
+    ctx->has_grid = true;
+    return F1P_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int f1p_nearest_point_batch(f1p_ctx* ctx, const double* pts, int32_t E, double* proj, double* dist, double* t, int32_t* idx) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && !pts)) return set_error(ctx, F1P_EINVAL, "bad pts / E");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "waypoints not set");
+    Stage s(ctx);
+    s.need(sizeof(double) * 2 * E); s.need(sizeof(double) * 2 * E, proj); s.need(sizeof(double) * E, dist);
+    s.need(sizeof(double) * E, t); s.need(sizeof(int32_t) * E, idx);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_pts;
+    if ((rc = s.in(pts, (size_t)2 * E, &d_pts))) return rc;
+    double* d_proj = s.out(proj, (size_t)2 * E); double* d_dist = s.out(dist, E); double* d_t = s.out(t, E);
+    int32_t* d_idx = s.out(idx, E);
+    if ((rc = launch_nearest(ctx, d_pts, E, d_proj, d_dist, d_t, d_idx))) return rc;
+    return s.finish();
+}
+
+int f1p_intersect_point_batch(f1p_ctx* ctx, const double* pts, const double* start_t, int32_t E, double radius,
+                              int32_t wrap, double* first_p, int32_t* first_i, double* first_t, int32_t* found) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!pts || !start_t))) return set_error(ctx, F1P_EINVAL, "bad pts / start_t / E");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "waypoints not set");
+    for (int i = 0; i < E; ++i)
+        if (!(start_t[i] >= 0.0) || !(start_t[i] <= (double)ctx->n_wp)) return set_error(ctx, F1P_EINVAL, "start_t must be in [0, n]");
+    Stage s(ctx);
+    s.need(sizeof(double) * 2 * E); s.need(sizeof(double) * E); s.need(sizeof(double) * 2 * E, first_p);
+    s.need(sizeof(int32_t) * E, first_i); s.need(sizeof(double) * E, first_t); s.need(sizeof(int32_t) * E, found);
+    int rc = s.begin(); if (rc) return rc;
+    const double *d_pts, *d_st;
+    if ((rc = s.in(pts, (size_t)2 * E, &d_pts))) return rc;
+    if ((rc = s.in(start_t, (size_t)E, &d_st))) return rc;
+    double* d_p = s.out(first_p, (size_t)2 * E); int32_t* d_i = s.out(first_i, E); double* d_t = s.out(first_t, E);
+    int32_t* d_f = s.out(found, E);
+    if ((rc = launch_intersect(ctx, d_pts, d_st, E, radius, wrap, d_p, d_i, d_t, d_f))) return rc;
+    return s.finish();
+}
+
+int f1p_pure_pursuit_dev(f1p_ctx* ctx, const double* d_poses, int32_t E, double lookahead, double wheelbase,
+                         double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near_idx,
+                         int32_t* d_la_idx, int32_t* d_status) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!d_poses || !d_steer || !d_speed))) return set_error(ctx, F1P_EINVAL, "poses, steer and speed are required");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "Please set waypoints to track during planner instantiation or when calling plan()");
+    return launch_pure_pursuit(ctx, d_poses, E, lookahead, wheelbase, max_reacquire, d_steer, d_speed, d_near_idx, d_la_idx, d_status);
+}
+
+int f1p_pure_pursuit_batch(f1p_ctx* ctx, const double* poses, int32_t E, double lookahead, double wheelbase,
+                           double max_reacquire, double* steer, double* speed, int32_t* near_idx, int32_t* la_idx,
+                           int32_t* status) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!poses || !steer || !speed))) return set_error(ctx, F1P_EINVAL, "poses, steer and speed are required");
+    Stage s(ctx);
+    s.need(sizeof(double) * 3 * E); s.need(sizeof(double) * E); s.need(sizeof(double) * E);
+    s.need(sizeof(int32_t) * E, near_idx); s.need(sizeof(int32_t) * E, la_idx); s.need(sizeof(int32_t) * E, status);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_poses;
+    if ((rc = s.in(poses, (size_t)3 * E, &d_poses))) return rc;
+    double* d_steer = s.out(steer, E); double* d_speed = s.out(speed, E);
+    int32_t* d_n = s.out(near_idx, E); int32_t* d_l = s.out(la_idx, E); int32_t* d_s = s.out(status, E);
+    if ((rc = f1p_pure_pursuit_dev(ctx, d_poses, E, lookahead, wheelbase, max_reacquire, d_steer, d_speed, d_n, d_l, d_s))) return rc;
+    return s.finish();
+}
+
+// ---------------------------------------------------------------------------------------------------
+int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                         int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                         int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
+                         double* d_best_traj, double* d_all_cost, double* d_all_traj) {
+    F1P_ENTER(ctx);
+    int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_best_idx && (cfg && cfg->cand_count > 0 ? true : (d_steer && d_speed))));
+    if (rc) return rc;
+    // a candidate shard evaluates only (cost + index); the emit half runs after the cross-rank argmin
+    const int mode = cfg->cand_count > 0 ? LATTICE_EVAL : LATTICE_FULL;
+    return launch_lattice(ctx, mode, d_poses, d_goals, d_prev_theta, E, cfg, nullptr, nullptr, d_steer, d_speed, d_best_idx,
+                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj);
+}
+
+int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,
+                         const f1p_lattice_cfg* cfg, const int32_t* d_cand_idx, const double* d_cand_cost,
+                         double* d_steer, double* d_speed, int32_t* d_status, int32_t* d_near_idx, double* d_best_traj) {
+    F1P_ENTER(ctx);
+    int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_cand_idx && d_steer && d_speed));
+    if (rc) return rc;
+    return launch_lattice(ctx, LATTICE_EMIT, d_poses, d_goals, nullptr, E, cfg, d_cand_idx, d_cand_cost, d_steer, d_speed,
+                          nullptr, nullptr, d_status, d_near_idx, d_best_traj, nullptr, nullptr);
+}
+
+int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                           int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
+                           double* best_cost, int32_t* status, int32_t* near_idx, double* best_traj,
+                           double* all_cost, double* all_traj) {
+    F1P_ENTER(ctx);
+    int rc = validate_lattice(ctx, cfg, E, goals == nullptr, E == 0 || (poses && steer && speed && best_idx));
+    if (rc) return rc;
+    const size_t C = (size_t)cfg->n_lookahead * cfg->n_width, S = cfg->n_stations, e = E;
+    Stage s(ctx);
+    s.need(8 * 4 * e); s.need(8 * e * C * 3, goals); s.need(8 * e * S, prev_theta);
+    s.need(8 * e); s.need(8 * e); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
+    s.need(8 * e * S * 4, best_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
+    if ((rc = s.begin())) return rc;
+    const double *d_poses, *d_goals, *d_prev;
+    if ((rc = s.in(poses, 4 * e, &d_poses))) return rc;
+    if ((rc = s.in(goals, e * C * 3, &d_goals))) return rc;
+    if ((rc = s.in(prev_theta, e * S, &d_prev))) return rc;
+    double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
+    double* d_bc = s.out(best_cost, e); int32_t* d_st = s.out(status, e); int32_t* d_ni = s.out(near_idx, e);
+    double* d_bt = s.out(best_traj, e * S * 4); double* d_ac = s.out(all_cost, e * C); double* d_at = s.out(all_traj, e * C * S * 4);
+    if ((rc = f1p_lattice_plan_dev(ctx, d_poses, d_goals, d_prev, E, cfg, d_steer, d_speed, d_bi, d_bc, d_st, d_ni, d_bt, d_ac, d_at))) return rc;
+    return s.finish();
+}
+
+int f1p_clothoid_g1_batch(f1p_ctx* ctx, const double* goals, int32_t n, double* kappa0, double* dkappa, double* length, int32_t* ok) {
+    F1P_ENTER(ctx);
+    if (n < 0 || (n > 0 && !goals)) return set_error(ctx, F1P_EINVAL, "bad goals / n");
+    Stage s(ctx);
+    s.need(8 * 3 * (size_t)n); s.need(8 * (size_t)n, kappa0); s.need(8 * (size_t)n, dkappa); s.need(8 * (size_t)n, length); s.need(4 * (size_t)n, ok);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_g;
+    if ((rc = s.in(goals, (size_t)3 * n, &d_g))) return rc;
+    double* d_k0 = s.out(kappa0, n); double* d_dk = s.out(dkappa, n); double* d_L = s.out(length, n); int32_t* d_ok = s.out(ok, n);
+    if ((rc = launch_clothoid_g1(ctx, d_g, n, d_k0, d_dk, d_L, d_ok))) return rc;
+    return s.finish();
+}
+
+// ---------------------------------------------------------------------------------------------------
+int f1p_kmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,
+                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                       double* d_best_cost, double* d_best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!d_x0 || !d_ref || !d_controls || !d_steer || !d_speed || !d_best_idx))
+        return set_error(ctx, F1P_EINVAL, "x0, ref, controls, steer, speed and best_idx are required");
+    return launch_kmpc_shoot(ctx, d_x0, d_ref, d_controls, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
+}
+
+int f1p_kmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, const float* controls, int32_t E,
+                         const f1p_kmpc_cfg* cfg, double* steer, double* speed, int32_t* best_idx, double* best_cost,
+                         double* best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!x0 || !ref || !controls || !steer || !speed || !best_idx))
+        return set_error(ctx, F1P_EINVAL, "x0, ref, controls, steer, speed and best_idx are required");
+    const size_t T = cfg->horizon, R = cfg->n_rollouts, e = E;
+    Stage s(ctx);
+    s.need(8 * 4 * e); s.need(8 * e * 4 * (T + 1)); s.need(4 * e * T * 2 * R);
+    s.need(8 * e); s.need(8 * e); s.need(4 * e); s.need(8 * e, best_cost); s.need(8 * e * T * 2, best_seq);
+    if ((rc = s.begin())) return rc;
+    const double *d_x0, *d_ref; const float* d_c;
+    if ((rc = s.in(x0, 4 * e, &d_x0))) return rc;
+    if ((rc = s.in(ref, e * 4 * (T + 1), &d_ref))) return rc;
+    if ((rc = s.in(controls, e * T * 2 * R, &d_c))) return rc;
+    double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
+    double* d_bc = s.out(best_cost, e); double* d_bs = s.out(best_seq, e * T * 2);
+    if ((rc = launch_kmpc_shoot(ctx, d_x0, d_ref, d_c, E, cfg, d_steer, d_speed, d_bi, d_bc, d_bs))) return rc;
+    return s.finish();
+}
+
+int f1p_kmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl, double* ref) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!states || !ref))) return set_error(ctx, F1P_EINVAL, "bad states / ref / E");
+    if (horizon < 1 || !(dt > 0) || !(dl > 0)) return set_error(ctx, F1P_EINVAL, "horizon, dt and dl must be positive");
+    if (ctx->n_wp < 2 || !ctx->has_psi) return set_error(ctx, F1P_ESTATE, "waypoints with a heading column are required");
+    Stage s(ctx);
+    s.need(8 * 4 * (size_t)E); s.need(8 * (size_t)E * 4 * (horizon + 1));
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_s;
+    if ((rc = s.in(states, (size_t)4 * E, &d_s))) return rc;
+    double* d_ref = s.out(ref, (size_t)E * 4 * (horizon + 1));
+    if ((rc = launch_kmpc_ref(ctx, d_s, E, horizon, dt, dl, d_ref))) return rc;
+    return s.finish();
+}
+
+int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const f1p_kmpc_cfg* cfg, uint64_t seed,
+                                 double sigma_accel, double sigma_steer) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && !d_controls) return set_error(ctx, F1P_EINVAL, "controls is NULL");
+    return launch_kmpc_sample(ctx, d_controls, E, cfg, seed, sigma_accel, sigma_steer);
+}
+
+int f1p_comm_unique_id(f1p_ctx* ctx, uint8_t id[F1P_COMM_ID_BYTES]) {
+    F1P_ENTER(ctx);
+    int rc = rccl_open(ctx); if (rc) return rc;
+    auto fn = rccl_sym<pfn_ncclGetUniqueId>(ctx, "ncclGetUniqueId");
+    if (!fn) return set_error(ctx, F1P_ECOMM, "ncclGetUniqueId not found");
+    rccl_unique_id uid;
+    int r = fn(&uid);
+    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclGetUniqueId failed");
+    memcpy(id, uid.internal, F1P_COMM_ID_BYTES);
+    return F1P_OK;
+}
+
+int f1p_comm_init(f1p_ctx* ctx, const uint8_t id[F1P_COMM_ID_BYTES], int32_t nranks, int32_t rank) {
+    F1P_ENTER(ctx);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(ctx, F1P_EINVAL, "bad nranks / rank");
+    int rc = rccl_open(ctx); if (rc) return rc;
+    if (ctx->comm) f1p_comm_destroy(ctx);
+    auto fn = rccl_sym<pfn_ncclCommInitRank>(ctx, "ncclCommInitRank");
+    if (!fn) return set_error(ctx, F1P_ECOMM, "ncclCommInitRank not found");
+    rccl_unique_id uid;
+    memcpy(uid.internal, id, F1P_COMM_ID_BYTES);
+    int r = fn(&ctx->comm, nranks, uid, rank);
+    if (r != 0) { ctx->comm = nullptr; return set_error(ctx, F1P_ECOMM, "ncclCommInitRank failed with code " + std::to_string(r)); }
+    ctx->comm_rank = rank; ctx->comm_nranks = nranks;
+    return F1P_OK;
+}
+
+int f1p_comm_destroy(f1p_ctx* ctx) {
+    if (!ctx) return F1P_EINVAL;
+    if (ctx->comm && ctx->rccl_lib) {
+        auto fn = rccl_sym<pfn_ncclCommDestroy>(ctx, "ncclCommDestroy");
+        if (fn) (void)fn(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    return F1P_OK;
+}
+
+int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E) {
+    F1P_ENTER(ctx);
+    if (!ctx->comm) return set_error(ctx, F1P_ESTATE, "communicator not initialised: call f1p_comm_init");
+    if (E < 0 || (E > 0 && (!d_cost || !d_idx))) return set_error(ctx, F1P_EINVAL, "bad cost / idx / E");
+    if (E == 0) return F1P_OK;
+    if (E > ctx->comm_cap) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_comm_cost) (void)hipFree(ctx->d_comm_cost);
+        if (ctx->d_comm_idx) (void)hipFree(ctx->d_comm_idx);
+        ctx->d_comm_cost = nullptr; ctx->d_comm_idx = nullptr; ctx->comm_cap = 0;
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_cost, sizeof(double) * (size_t)E));
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_idx, sizeof(int32_t) * (size_t)E));
+        ctx->comm_cap = E;
+    }
+    auto ar = rccl_sym<pfn_ncclAllReduce>(ctx, "ncclAllReduce");
+    if (!ar) return set_error(ctx, F1P_ECOMM, "ncclAllReduce not found");
+    // 1. global minimum cost per ego
+    int r = ar(d_cost, ctx->d_comm_cost, (size_t)E, RCCL_FLOAT64, RCCL_MIN, ctx->comm, ctx->stream);
+    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclAllReduce(min, f64) failed with code " + std::to_string(r));
+    // 2. ranks that hold that cost keep their index, the others contribute INT32_MAX
+    int rc = launch_mask_idx(ctx, d_cost, ctx->d_comm_cost, d_idx, ctx->d_comm_idx, E); if (rc) return rc;
+    // 3. lowest index among the holders (np.argmin first-minimum rule)
+    r = ar(ctx->d_comm_idx, d_idx, (size_t)E, RCCL_INT32, RCCL_MIN, ctx->comm, ctx->stream);
+    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclAllReduce(min, i32) failed with code " + std::to_string(r));
+    F1P_HIP(ctx, hipMemcpyAsync(d_cost, ctx->d_comm_cost, sizeof(double) * (size_t)E, hipMemcpyDeviceToDevice, ctx->stream));
+    return F1P_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,242 @@
+// f1p_device.h -- device-side building blocks shared by the gfx950 kernels of libf1p.so.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): everything that decides an index is IEEE binary64 with the
+// reference's operation order.  The library is compiled with -ffp-contract=off, so a*b+c is two roundings
+// unless the code says fma() -- which it does exactly where the reference's np.dot does (OpenBLAS ddot fuses
+// the second product of a length-2 dot: fma(a1, b1, a0*b0); pinned by tests/golden).
+// Wavefront = 64 lanes on CDNA4; every cross-lane idiom below is written for 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/f1p.h"
+
+#define F1P_WAVE 64
+#define F1P_PI 3.14159265358979323846
+#define F1P_LA_NONE INT32_MIN
+
+namespace f1p {
+
+// ---------------------------------------------------------------------------------------------------
+// cross-lane helpers (wave64)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, F1P_WAVE);
+    hi = __shfl(hi, src, F1P_WAVE);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, F1P_WAVE);
+    hi = __shfl_xor(hi, mask, F1P_WAVE);
+    return __hiloint2double(hi, lo);
+}
+
+// np.argmin ordering on (value, index): the first minimum wins; a NaN is "smaller" than any number
+// (np.argmin returns the first NaN).  true when (da, ia) must replace (db, ib).
+__device__ __forceinline__ bool argmin_better(double da, int ia, double db, int ib) {
+    const bool na = da != da, nb = db != db;
+    if (na | nb) return (na & nb) ? (ia < ib) : na;
+    return (da < db) | ((da == db) & (ia < ib));
+}
+
+// wave-wide argmin by xor-butterfly; every lane ends with the winner
+__device__ __forceinline__ void wave_argmin(double& d, int& i) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double od = shfl_xor_d(d, m);
+        const int oi = __shfl_xor(i, m, F1P_WAVE);
+        if (argmin_better(od, oi, d, i)) { d = od; i = oi; }
+    }
+}
+
+// block-wide argmin; `sd`/`si` are LDS scratch of >= blockDim.x/64 entries.  All threads get the result.
+__device__ __forceinline__ void block_argmin(double& d, int& i, double* sd, int* si) {
+    wave_argmin(d, i);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { sd[wave] = d; si[wave] = i; }
+    __syncthreads();
+    d = sd[0]; i = si[0];
+    for (int w = 1; w < nw; ++w)
+        if (argmin_better(sd[w], si[w], d, i)) { d = sd[w]; i = si[w]; }
+}
+
+// np.dot of two 2-vectors as OpenBLAS evaluates it (see the header comment)
+__device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) {
+    return __builtin_fma(a1, b1, a0 * b0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// nearest_point  (utils/utils.py:37-67)
+// ---------------------------------------------------------------------------------------------------
+struct SegProj { double t, qx, qy, d; };
+
+// one segment of the polyline: clipped projection parameter, projection and distance (:53-65)
+__device__ __forceinline__ SegProj seg_project(double px, double py, double ax, double ay, double bx, double by) {
+    SegProj r;
+    const double dx = bx - ax, dy = by - ay;      // :53
+    const double l2 = dx * dx + dy * dy;          // :54
+    const double dot = dot2(px - ax, py - ay, dx, dy);  // :57
+    double t = dot / l2;                          // :58
+    if (t < 0.0) t = 0.0;                         // :59
+    if (t > 1.0) t = 1.0;                         // :60
+    r.t = t;
+    r.qx = ax + t * dx;                           // :61
+    r.qy = ay + t * dy;
+    const double ex = px - r.qx, ey = py - r.qy;  // :64
+    r.d = __builtin_sqrt(ex * ex + ey * ey);      // :65
+    return r;
+}
+
+// `nthreads` cooperating threads (id `tid`) scan the n-1 segments of (wx, wy); each keeps its first minimum.
+__device__ __forceinline__ void nearest_scan(double px, double py, const double* __restrict__ wx,
+                                             const double* __restrict__ wy, int n, int tid, int nthreads, double& best_d,
+                                             int& best_i) {
+    best_d = __builtin_huge_val();
+    best_i = 0x7fffffff;
+    for (int i = tid; i < n - 1; i += nthreads) {
+        const SegProj s = seg_project(px, py, wx[i], wy[i], wx[i + 1], wy[i + 1]);
+        if (argmin_better(s.d, i, best_d, best_i)) { best_d = s.d; best_i = i; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// intersect_point  (utils/utils.py:69-151)
+// ---------------------------------------------------------------------------------------------------
+struct SegHit { bool hit; double t, x, y; };
+
+// circle (p, radius) against the segment start -> end+1e-6 (:86-122 / :126-149)
+__device__ __forceinline__ SegHit seg_hit(double px, double py, double radius, double sx, double sy, double ex, double ey,
+                                          bool is_start_seg, double start_t) {
+    SegHit h;
+    h.hit = false; h.t = 0.0; h.x = 0.0; h.y = 0.0;
+    ex = ex + 1e-6;
+    ey = ey + 1e-6;
+    const double vx = ex - sx, vy = ey - sy;
+    const double a = dot2(vx, vy, vx, vy);                                           // :89
+    const double b = 2.0 * dot2(vx, vy, sx - px, sy - py);                           // :90
+    const double c = dot2(sx, sy, sx, sy) + dot2(px, py, px, py) - 2.0 * dot2(sx, sy, px, py) - radius * radius;  // :91
+    double disc = b * b - 4 * a * c;                                                 // :92
+    if (disc < 0) return h;                                                          // :94 (NaN falls through like numpy)
+    disc = __builtin_sqrt(disc);                                                     // :99
+    const double t1 = (-b - disc) / (2.0 * a);                                       // :100
+    const double t2 = (-b + disc) / (2.0 * a);                                       // :101
+    const bool ok1 = (t1 >= 0.0) & (t1 <= 1.0) & (!is_start_seg | (t1 >= start_t));
+    const bool ok2 = (t2 >= 0.0) & (t2 <= 1.0) & (!is_start_seg | (t2 >= start_t));
+    if (ok1) { h.hit = true; h.t = t1; }
+    else if (ok2) { h.hit = true; h.t = t2; }
+    if (h.hit) { h.x = sx + h.t * vx; h.y = sy + h.t * vy; }
+    return h;
+}
+
+struct Intersect { bool found; int i; double t, x, y; };
+
+// One WAVE scans the polyline in the reference's order, 64 segments per step: ballot + first set lane is the
+// first hit of the sequential loop.  All 64 lanes of the wave must call this with the same arguments.
+// `ld(i)` style access is avoided: wx/wy may point to global memory or LDS.
+__device__ __forceinline__ Intersect wave_intersect(double px, double py, double radius, const double* wx, const double* wy,
+                                                    int n, double tstart, bool wrap) {
+    const int lane = threadIdx.x & 63;
+    const int start_i = (int)tstart;                      // :78
+    const double start_t = tstart - __builtin_trunc(tstart);  // :79  t % 1.0 for t >= 0 (exact)
+    Intersect r;
+    r.found = false; r.i = 0; r.t = 0.0; r.x = 0.0; r.y = 0.0;
+    for (int base = start_i; base < n - 1; base += 64) {  // :84
+        const int i = base + lane;
+        SegHit h;
+        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
+        if (i < n - 1) h = seg_hit(px, py, radius, wx[i], wy[i], wx[i + 1], wy[i + 1], i == start_i, start_t);
+        const unsigned long long m = __ballot(h.hit);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            r.found = true; r.i = base + first;
+            r.t = shfl_d(h.t, first); r.x = shfl_d(h.x, first); r.y = shfl_d(h.y, first);
+            return r;
+        }
+    }
+    if (wrap) {                                           // :124-149
+        for (int base = -1; base < start_i; base += 64) {
+            const int i = base + lane;
+            SegHit h;
+            h.hit = false; h.t = 0; h.x = 0; h.y = 0;
+            if (i < start_i) {
+                const int i0 = i < 0 ? i + n : i;          // Python modulo for i in [-1, n-1]
+                int i1 = i + 1; if (i1 >= n) i1 -= n;
+                h = seg_hit(px, py, radius, wx[i0], wy[i0], wx[i1], wy[i1], false, 0.0);
+            }
+            const unsigned long long m = __ballot(h.hit);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1;
+                r.found = true; r.i = base + first;       // may be -1
+                r.t = shfl_d(h.t, first); r.x = shfl_d(h.x, first); r.y = shfl_d(h.y, first);
+                return r;
+            }
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// get_actuation  (utils/utils.py:153-161)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void get_actuation(double pose_theta, double lx, double ly, double lspeed, double px, double py,
+                                              double lookahead, double wheelbase, double& speed, double& steer) {
+    const double wy = dot2(sin(-pose_theta), cos(-pose_theta), lx - px, ly - py);  // :155
+    speed = lspeed;                                                                // :156
+    if (fabs(wy) < 1e-6) { steer = 0.0; return; }                                  // :157
+    const double radius = 1 / (2.0 * wy / (lookahead * lookahead));                // :159
+    steer = atan(wheelbase / radius);                                              // :160
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PurePursuitPlanner._get_current_waypoint + plan (pure_pursuit.py:56-122), executed by ONE wave on a
+// polyline (wx, wy) with speed column wv (wv == nullptr: constant speed `v_const`).
+// near (i, t, dist) is the result of nearest_point.  Lane 0's outputs are the valid ones (all lanes agree).
+// ---------------------------------------------------------------------------------------------------
+struct Track { double steer, speed; int la_idx, status; };
+
+__device__ __forceinline__ Track wave_pursuit(double px, double py, double theta, double lookahead, double wheelbase,
+                                              double max_reacquire, const double* wx, const double* wy, const double* wv,
+                                              double v_const, int n, int near_i, double near_t, double near_d) {
+    Track o;
+    o.steer = 0.0; o.speed = 0.0; o.la_idx = F1P_LA_NONE; o.status = F1P_ST_NO_LOOKAHEAD;
+    double cx, cy, cv;
+    if (near_d < lookahead) {                                                     // :70
+        const Intersect it = wave_intersect(px, py, lookahead, wx, wy, n, (double)near_i + near_t, true);  // :71-75
+        if (!it.found) return o;                                                  // :76-77 -> :112-114
+        o.la_idx = it.i;
+        const int r = it.i < 0 ? it.i + n : it.i;                                 // numpy row -1 = last row
+        cx = wx[r]; cy = wy[r]; cv = wv ? wv[near_i] : v_const;                   // :78
+        o.status = F1P_ST_INTERSECT;
+    } else if (near_d < max_reacquire) {                                          // :80-81
+        cx = wx[near_i]; cy = wy[near_i]; cv = wv ? wv[near_i] : v_const;
+        o.status = F1P_ST_REACQUIRE;
+    } else {
+        return o;                                                                 // :82-83 -> :112-114
+    }
+    get_actuation(theta, cx, cy, cv, px, py, lookahead, wheelbase, o.speed, o.steer);  // :116-120
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Occupancy grid: bit-packed on the device (1 = occupied), row index = gy (the image is flipped once at
+// f1p_set_grid), 32 cells per word.
+// ---------------------------------------------------------------------------------------------------
+struct GridDev {
+    const uint32_t* bits;   // [h][wwords]
+    int32_t w, h, wwords;
+    double inv_res, ox, oy;
+};
+
+__device__ __forceinline__ bool cell_of(const GridDev& g, double x, double y, int& gx, int& gy) {
+    const double fx = __builtin_floor((x - g.ox) * g.inv_res);
+    const double fy = __builtin_floor((y - g.oy) * g.inv_res);
+    const bool inside = (fx >= 0.0) & (fy >= 0.0) & (fx < (double)g.w) & (fy < (double)g.h);  // NaN -> outside
+    gx = inside ? (int)fx : -1;
+    gy = inside ? (int)fy : -1;
+    return inside;
+}
+
+}  // namespace f1p

@@ -1,0 +1,83 @@
+// f1p_internal.h -- host-side context and launch declarations shared by the translation units of libf1p.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/f1p.h"
+#include "f1p_device.h"
+
+struct f1p_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // waypoints, struct-of-arrays fp64 (coalesced lane-consecutive loads in nearest_scan / wave_intersect)
+    int n_wp = 0;
+    bool has_psi = false;
+    double *d_wx = nullptr, *d_wy = nullptr, *d_wv = nullptr, *d_wpsi = nullptr;
+
+    // occupancy grid, bit-packed and row-flipped
+    bool has_grid = false;
+    uint32_t* d_bits = nullptr;
+    int gw = 0, gh = 0, gwwords = 0;
+    double res = 0, inv_res = 0, ox = 0, oy = 0;
+
+    // scratch arena for the host-pointer (*_batch) wrappers
+    char* d_arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+
+    // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int comm_rank = 0, comm_nranks = 0;
+    double* d_comm_cost = nullptr;
+    int32_t* d_comm_idx = nullptr;
+    int comm_cap = 0;
+};
+
+namespace f1p {
+
+int set_error(f1p_ctx* ctx, int code, const std::string& msg);
+int check_hip(f1p_ctx* ctx, hipError_t e, const char* what);
+
+#define F1P_HIP(ctx, call)                                   \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return f1p::check_hip((ctx), _e, #call); \
+    } while (0)
+
+// device arena for the *_batch wrappers: bump allocation, reset per call
+int arena_reset(f1p_ctx* ctx, size_t need_bytes);
+void* arena_take(f1p_ctx* ctx, size_t bytes);
+
+GridDev grid_dev(const f1p_ctx* ctx);
+
+// kernel launchers (k_pursuit.hip / k_lattice.hip / k_kmpc.hip); all asynchronous on ctx->stream
+int launch_nearest(f1p_ctx* ctx, const double* d_pts, int E, double* d_proj, double* d_dist, double* d_t, int32_t* d_idx);
+int launch_intersect(f1p_ctx* ctx, const double* d_pts, const double* d_start_t, int E, double radius, int wrap,
+                     double* d_p, int32_t* d_i, double* d_t, int32_t* d_found);
+int launch_pure_pursuit(f1p_ctx* ctx, const double* d_poses, int E, double lookahead, double wheelbase,
+                        double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near, int32_t* d_la,
+                        int32_t* d_status);
+int launch_pack_grid(f1p_ctx* ctx, const uint8_t* d_img, int w, int h, int occupied_below);
+
+enum LatticeMode { LATTICE_FULL = 0, LATTICE_EVAL = 1, LATTICE_EMIT = 2 };
+int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                   int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
+                   double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
+                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj);
+int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok);
+
+int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
+                      const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                      double* d_best_cost, double* d_best_seq);
+int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);
+int launch_kmpc_sample(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, uint64_t seed, double sigma_a,
+                       double sigma_d);
+int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E);
+
+}  // namespace f1p

@@ -1,0 +1,202 @@
+// k_kmpc.hip -- K4: kinematic-bicycle random-shooting MPC, plus the reference-trajectory extraction.
+//
+// Replaces predict_motion_kinematic / update_state_kinematic (control/kinematic_mpc/kinematic_mpc.py:208-243),
+// the objective of :324-334 evaluated on the nonlinear rollout, the bounds of :391-401 applied as a projection
+// of each sampled control sequence, and the output map of :506-508; calc_ref_trajectory_kinematic (:162-206).
+//
+// Mapping: one 256-thread workgroup per ego, one thread per rollout (strided when R > 256).  Controls are
+// f32 in HBM laid out [ego][t][accel|steer][rollout]: at every time step a wave64 reads two contiguous 256-B
+// lines, so the stream is fully coalesced; x0 and the reference trajectory are workgroup-uniform (LDS).
+// State, cost and the previous applied control stay in registers for the whole horizon.  This is the
+// HBM-streaming kernel of the path: 8 B of controls per rollout-step, fp64 arithmetic on them.
+#include "f1p_internal.h"
+
+namespace f1p {
+
+struct KmpcStep { double x, y, v, yaw; };
+
+// update_state_kinematic :223-243 (delta already clamped by the caller's projection; the clamp is repeated
+// here because the reference does it inside the step)
+__device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, const f1p_kmpc_cfg& c) {
+    if (delta >= c.max_steer) delta = c.max_steer;             // :226-229
+    else if (delta <= -c.max_steer) delta = -c.max_steer;
+    double sn, cs;
+    sincos(s.yaw, &sn, &cs);
+    const double x = s.x + s.v * cs * c.dt;                    // :231
+    const double y = s.y + s.v * sn * c.dt;                    // :232
+    const double yaw = s.yaw + (s.v / c.wheelbase) * tan(delta) * c.dt;   // :233-235
+    double v = s.v + a * c.dt;                                 // :236
+    if (v > c.max_speed) v = c.max_speed;                      // :238-241
+    else if (v < c.min_speed) v = c.min_speed;
+    s.x = x; s.y = y; s.yaw = yaw; s.v = v;
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
+
+__global__ __launch_bounds__(256) void k_kmpc_shoot(const double* __restrict__ x0, const double* __restrict__ ref,
+                                                    const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
+                                                    double* __restrict__ steer, double* __restrict__ speed,
+                                                    int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
+                                                    double* __restrict__ best_seq) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double* sref = reinterpret_cast<double*>(lds_raw);   // [4][T+1]
+    double* red_d = sref + 4 * (cfg.horizon + 1);         // [4]
+    int* red_i = reinterpret_cast<int*>(red_d + 4);       // [4]
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x;
+    for (int q = tid; q < 4 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 4 * (T + 1) + q];
+    __syncthreads();
+    const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
+    const float* ce = controls + (size_t)e * T * 2 * R;
+    const double dmax = cfg.max_dsteer * cfg.dt;
+
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    for (int r = tid; r < R; r += blockDim.x) {
+        KmpcStep s;
+        s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
+        double cost = 0.0, pa = 0.0, pd = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double a = (double)ce[((size_t)t * 2 + 0) * R + r];
+            double d = (double)ce[((size_t)t * 2 + 1) * R + r];
+            a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
+            d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
+            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
+            const double e0 = s.x - sref[0 * (T + 1) + t], e1 = s.y - sref[1 * (T + 1) + t];
+            const double e2 = s.v - sref[2 * (T + 1) + t], e3 = s.yaw - sref[3 * (T + 1) + t];
+            cost += ((cfg.q[0] * e0 * e0 + cfg.q[1] * e1 * e1) + cfg.q[2] * e2 * e2) + cfg.q[3] * e3 * e3;   // :331
+            cost += cfg.r[0] * a * a + cfg.r[1] * d * d;                                                     // :328
+            if (t > 0) {
+                const double da = a - pa, dd = d - pd;
+                cost += cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                                           // :334
+            }
+            kmpc_step(s, a, d, cfg);
+            pa = a; pd = d;
+        }
+        const double e0 = s.x - sref[0 * (T + 1) + T], e1 = s.y - sref[1 * (T + 1) + T];
+        const double e2 = s.v - sref[2 * (T + 1) + T], e3 = s.yaw - sref[3 * (T + 1) + T];
+        cost += ((cfg.qf[0] * e0 * e0 + cfg.qf[1] * e1 * e1) + cfg.qf[2] * e2 * e2) + cfg.qf[3] * e3 * e3;
+        if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
+    }
+    block_argmin(bc, bi, red_d, red_i);
+    if (tid == 0) {
+        // the winner's applied sequence: clamp, then the sequential rate limit
+        double pd = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
+            double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
+            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
+            if (t == 0) {
+                steer[e] = d;                       // :506  steer_output = odelta_v[0]
+                speed[e] = sv + a * cfg.dt;         // :508  speed_output = v + oa[0] * DTK
+            }
+            if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
+            else if (t == 0) break;
+            pd = d;
+        }
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+    }
+}
+
+// calc_ref_trajectory_kinematic :162-206.  states [E][4] = (x, y, v, yaw); waypoints of the ctx are
+// (cx, cy, sp, cyaw) = (wx, wy, wv, wpsi).  ref [E][4][T+1].
+__global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
+                                                  const double* __restrict__ wx, const double* __restrict__ wy,
+                                                  const double* __restrict__ wv, const double* __restrict__ wpsi, int n,
+                                                  double* __restrict__ ref) {
+    __shared__ double sd[4];
+    __shared__ int si[4];
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    const double px = states[4 * e], py = states[4 * e + 1], v = states[4 * e + 2], yaw = states[4 * e + 3];
+    double bd; int ind;
+    nearest_scan(px, py, wx, wy, n, threadIdx.x, blockDim.x, bd, ind);   // :180
+    block_argmin(bd, ind, sd, si);
+    const double travel = fabs(v) * dt;   // :189
+    const double dind = travel / dl;      // :190
+    for (int j = threadIdx.x; j <= T; j += blockDim.x) {
+        double cum = 0.0;                 // np.cumsum(np.repeat(dind, TK)): sequential adds  :191-193
+        for (int q = 0; q < j; ++q) cum += dind;
+        int il = ind + (int)cum;
+        if (il >= n) il -= n;             // :194 single wrap
+        if (il < 0 || il >= n) il = il < 0 ? 0 : n - 1;   // the reference would raise IndexError; clamp instead
+        double cyw = wpsi[il];            // in-place fix-up of :198-203 applied to the gathered view
+        if (cyw - yaw > 4.5) cyw = fabs(cyw - (2 * F1P_PI));
+        if (cyw - yaw < -4.5) cyw = fabs(cyw + (2 * F1P_PI));
+        double* r = ref + (size_t)e * 4 * (T + 1);
+        r[0 * (T + 1) + j] = wx[il];
+        r[1 * (T + 1) + j] = wy[il];
+        r[2 * (T + 1) + j] = wv[il];
+        r[3 * (T + 1) + j] = cyw;
+    }
+}
+
+// counter-based sampler: splitmix64 hash of (seed, flat index) -> two uniforms -> Box-Muller
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_kmpc_sample(float* __restrict__ controls, size_t n_pairs, int R, uint64_t seed,
+                                                     float sigma_a, float sigma_d, float max_a, float max_d) {
+    // one thread per (ego, t, rollout): writes the accel and the steer sample
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const size_t et = i / R, r = i - et * R;
+    const uint64_t h = splitmix64(seed ^ splitmix64(i));
+    const float u1 = ((float)((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);              // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    float a = sigma_a * rad * cs, d = sigma_d * rad * sn;
+    a = fminf(fmaxf(a, -max_a), max_a);
+    d = fminf(fmaxf(d, -max_d), max_d);
+    controls[(et * 2 + 0) * R + r] = a;
+    controls[(et * 2 + 1) * R + r] = d;
+}
+
+__global__ void k_mask_idx(const double* __restrict__ cost, const double* __restrict__ gmin, const int32_t* __restrict__ idx,
+                           int32_t* __restrict__ masked, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    masked[e] = (cost[e] == gmin[e]) ? idx[e] : 0x7fffffff;
+}
+
+int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
+                      const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                      double* d_best_cost, double* d_best_seq) {
+    if (E <= 0) return F1P_OK;
+    const size_t lds = sizeof(double) * (4 * (size_t)(cfg->horizon + 1) + 4) + sizeof(int) * 4;
+    hipLaunchKernelGGL(k_kmpc_shoot, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
+                       *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot launch");
+}
+
+int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_kmpc_ref, dim3(E), dim3(256), 0, ctx->stream, d_states, E, horizon, dt, dl, ctx->d_wx, ctx->d_wy,
+                       ctx->d_wv, ctx->d_wpsi, ctx->n_wp, d_ref);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_ref launch");
+}
+
+int launch_kmpc_sample(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, uint64_t seed, double sigma_a,
+                       double sigma_d) {
+    const size_t n_pairs = (size_t)E * cfg->horizon * cfg->n_rollouts;
+    if (n_pairs == 0) return F1P_OK;
+    hipLaunchKernelGGL(k_kmpc_sample, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_controls,
+                       n_pairs, cfg->n_rollouts, seed, (float)sigma_a, (float)sigma_d, (float)cfg->max_accel,
+                       (float)cfg->max_steer);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_sample launch");
+}
+
+int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_mask_idx, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_cost, d_gmin, d_idx, d_masked, E);
+    return check_hip(ctx, hipGetLastError(), "k_mask_idx launch");
+}
+
+}  // namespace f1p

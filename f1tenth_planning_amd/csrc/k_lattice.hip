@@ -1,0 +1,446 @@
+// k_lattice.hip -- K3: the fused lattice planner, one launch per batched plan().
+//
+// Replaces, for E egos at once, LatticePlanner.plan (planning/lattice_planner/lattice_planner.py:174-214):
+//   sample()  -> goals from look-ahead x width grid (intent of sample_lookahead_square :223-260)
+//   Clothoid.G1Hermite(0,0,0,x,y,theta) (:196, pyclothoids) -> g1_fit (Bertolazzi & Frego 2015)
+//   sample_traj(clothoid, S) (utils/utils.py:286-295)        -> station loop, rows (x, y, theta, |kappa|)
+//   map_collision (stub, utils/utils.py:297-301)             -> bit-packed occupancy, ego-centred LDS tile
+//   eval() weighted sum (:130-156), select() argmin (:159-172)
+//   tracker.plan(..., 0.8, best_traj) (:208-212)             -> wave_pursuit on the winner in LDS
+//
+// Mapping (CDNA4): one 256-thread workgroup (4 wave64) per ego, one thread per candidate (strided when
+// C > 256).  Nothing per-candidate ever goes to HBM in the fused mode: 32 B of pose come in, the winner's
+// S x 32 B trajectory and 40 B of scalars go out.  The occupancy tile around the ego (<= 256 x 256 cells,
+// <= 9.2 KB of the 160 KB LDS) is staged once per workgroup with row-contiguous word loads; samples that
+// leave the tile fall back to the global bitmap (500 KB for a 2000 x 2000 map: L2 resident).
+// The argmin is a wave64 xor-butterfly on (cost, index) followed by a 4-entry LDS pass.
+// Roofline: fp64 VALU + transcendental issue (no dense contraction -> no MFMA); HBM traffic is
+// ~0.14 B per candidate-step and is reported as such.
+#include "f1p_internal.h"
+
+namespace f1p {
+
+// Gauss-Legendre nodes / weights on [0, 1]
+__constant__ double c_gl16_x[16] = {
+    0.005299532504175031, 0.0277124884633837,  0.06718439880608412, 0.1222977958224985,
+    0.19106187779867811,  0.2709916111713863,  0.35919822461037054, 0.4524937450811813,
+    0.5475062549188188,   0.6408017753896295,  0.7290083888286136,  0.8089381222013219,
+    0.8777022041775016,   0.9328156011939159,  0.9722875115366163,  0.994700467495825};
+__constant__ double c_gl16_w[16] = {
+    0.013576229705877019, 0.031126761969323853, 0.047579255841246296, 0.062314485627767015,
+    0.07479799440828838,  0.08457825969750131,  0.0913017075224618,   0.09472530522753429,
+    0.09472530522753429,  0.0913017075224618,   0.08457825969750131,  0.07479799440828838,
+    0.062314485627767015, 0.047579255841246296, 0.031126761969323853, 0.013576229705877019};
+#define GL4_X0 0.06943184420297371
+#define GL4_X1 0.33000947820757187
+#define GL4_X2 0.6699905217924281
+#define GL4_X3 0.9305681557970262
+#define GL4_W0 0.17392742256872684
+#define GL4_W1 0.3260725774312731
+
+struct Moments { double c0, s0, c1, c2; };
+
+// c_k = int_0^1 tau^k cos(a tau^2 + b tau + c) dtau, s_0 likewise with sin.  16-point Gauss-Legendre per
+// panel is exact to 1e-14 while the phase excursion |a| + |b| per panel is <= 8 rad.
+__device__ __forceinline__ Moments fresnel_moments(double a, double b, double c) {
+    Moments m;
+    m.c0 = 0.0; m.s0 = 0.0; m.c1 = 0.0; m.c2 = 0.0;
+    int panels = (int)__builtin_ceil((fabs(a) + fabs(b)) * 0.125);
+    panels = panels < 1 ? 1 : (panels > 1024 ? 1024 : panels);
+    const double h = 1.0 / (double)panels;
+    for (int p = 0; p < panels; ++p) {
+        const double t0 = (double)p * h;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double tau = __builtin_fma(h, c_gl16_x[j], t0);
+            const double ph = __builtin_fma(__builtin_fma(a, tau, b), tau, c);
+            double sn, cs;
+            sincos(ph, &sn, &cs);
+            const double w = h * c_gl16_w[j];
+            const double wc = w * cs;
+            m.c0 += wc;
+            m.s0 = __builtin_fma(w, sn, m.s0);
+            m.c1 = __builtin_fma(wc, tau, m.c1);
+            m.c2 = __builtin_fma(wc * tau, tau, m.c2);
+        }
+    }
+    return m;
+}
+
+struct Clothoid { double k0, dk, L; bool ok; };
+
+// G1 Hermite interpolation (0,0,0) -> (x1, y1, th1): Newton on A for int_0^1 sin(A t^2 + (delta-A) t + phi0) dt = 0
+__device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
+    Clothoid cl;
+    cl.k0 = 0.0; cl.dk = 0.0; cl.L = 0.0; cl.ok = false;
+    const double r = hypot(x1, y1);
+    if (!(r > 1e-12) || !isfinite(r) || !isfinite(th1)) return cl;
+    const double phi = atan2(y1, x1);
+    const double phi0 = remainder(0.0 - phi, 2.0 * F1P_PI);
+    const double phi1 = remainder(th1 - phi, 2.0 * F1P_PI);
+    const double delta = phi1 - phi0;
+    const double X = phi0 / F1P_PI, Y = phi1 / F1P_PI;
+    const double xy = X * Y, X2 = X * X, Y2 = Y * Y;
+    double A = (phi0 + phi1) * (2.989696028701907 + xy * (0.716228953608281 + xy * -0.458969738821509) +
+                                (-0.502821153340377 + xy * 0.261062141752652) * (X2 + Y2) +
+                                -0.045854475238709 * (X2 * X2 + Y2 * Y2));
+    Moments m;
+    bool ok = false;
+    for (int it = 0; it < 20; ++it) {
+        m = fresnel_moments(A, delta - A, phi0);
+        const double g = m.s0;
+        const double dg = m.c2 - m.c1;
+        if (fabs(g) <= 1e-13) { ok = true; break; }
+        if (dg == 0.0 || !isfinite(dg)) break;
+        A -= g / dg;
+        if (!isfinite(A)) break;
+    }
+    if (!ok) {
+        m = fresnel_moments(A, delta - A, phi0);
+        if (fabs(m.s0) <= 1e-10) ok = true;
+    }
+    if (!ok) return cl;
+    const double L = r / m.c0;
+    if (!(L > 0.0) || !isfinite(L)) return cl;
+    cl.L = L;
+    cl.k0 = (delta - A) / L;
+    cl.dk = 2.0 * A / (L * L);
+    cl.ok = true;
+    return cl;
+}
+
+// (dx, dy) = int_s^{s+ds} (cos, sin)(theta(u)) du with theta(u) = u (k0 + u dk / 2).
+// 4-point Gauss-Legendre per sub-interval; `nsub` keeps the heading change per sub-interval below 0.35 rad
+// (error < 1e-13 ds).  Depends only on (k0, dk, s, ds, nsub): the winner re-emission reproduces the
+// evaluation loop bit for bit.
+__device__ __forceinline__ void interval_increment(double k0, double dk, double s, double ds, int nsub, double& dx,
+                                                   double& dy) {
+    const double hs = ds / (double)nsub;
+    double ax = 0.0, ay = 0.0;
+    for (int q = 0; q < nsub; ++q) {
+        const double s0 = __builtin_fma((double)q, hs, s);
+        double sn, cs, ix, iy;
+        double u = __builtin_fma(hs, GL4_X0, s0);
+        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        ix = GL4_W0 * cs; iy = GL4_W0 * sn;
+        u = __builtin_fma(hs, GL4_X1, s0);
+        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
+        u = __builtin_fma(hs, GL4_X2, s0);
+        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
+        u = __builtin_fma(hs, GL4_X3, s0);
+        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        ix = __builtin_fma(GL4_W0, cs, ix); iy = __builtin_fma(GL4_W0, sn, iy);
+        ax = __builtin_fma(hs, ix, ax);
+        ay = __builtin_fma(hs, iy, ay);
+    }
+    dx = ax; dy = ay;
+}
+
+__device__ __forceinline__ int clothoid_nsub(double k0, double dk, double L, double ds) {
+    const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
+    const double turn = kmax * ds;
+    int nsub = (int)__builtin_ceil(turn * (1.0 / 0.35));
+    return nsub < 1 ? 1 : (nsub > 4096 ? 4096 : nsub);
+}
+
+struct LatticeArgs {
+    const double* poses;       // [E][4]
+    const double* goals;       // [E][C][3] or null
+    const double* prev_theta;  // [E][S] or null
+    int E, mode;
+    const double *wx, *wy, *wv, *wpsi;
+    int n;
+    GridDev grid;
+    int has_grid;
+    const int32_t* emit_idx;   // LATTICE_EMIT
+    const double* emit_cost;
+    double *steer, *speed;
+    int32_t* best_idx;
+    double* best_cost;
+    int32_t *status, *near_idx;
+    double *best_traj, *all_cost, *all_traj;
+    int tile_rows, tile_words;  // LDS occupancy tile: rows x (32-cell words)
+};
+
+// goal of candidate c in the ego frame; false when it has no goal (look-ahead circle missed the raceline)
+__device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_lattice_cfg& cfg, int e, int c, int C,
+                                               double px, double py, double theta, double ct, double st,
+                                               const double* cen_x, const double* cen_y, const double* cen_psi,
+                                               const int* cen_ok, double& gx, double& gy, double& gth) {
+    if (a.goals) {
+        const double* g = a.goals + ((size_t)e * C + c) * 3;
+        gx = g[0]; gy = g[1]; gth = g[2];
+        return isfinite(gx) && isfinite(gy) && isfinite(gth);
+    }
+    const int l = c / cfg.n_width, k = c - l * cfg.n_width;
+    if (!cen_ok[l]) { gx = 0.0; gy = 0.0; gth = 0.0; return false; }
+    const double psi = cen_psi[l];
+    const double w = cfg.width[k];
+    const double mx = cen_x[l] + w * (-sin(psi));
+    const double my = cen_y[l] + w * cos(psi);
+    const double dx = mx - px, dy = my - py;
+    gx = ct * dx + st * dy;
+    gy = -st * dx + ct * dy;
+    gth = remainder(psi - theta, 2.0 * F1P_PI);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
+    double* red_d = reinterpret_cast<double*>(lds_raw);          // [4]
+    double* cen_x = red_d + 4;                                   // [64]
+    double* cen_y = cen_x + F1P_MAX_LOOKAHEADS;                  // [64]
+    double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;                // [64]
+    const int S = cfg.n_stations;
+    double* tr_x = cen_psi + F1P_MAX_LOOKAHEADS;                 // [S] winner x (ego frame)
+    double* tr_y = tr_x + S;                                     // [S]
+    double* inc_x = tr_y + S;                                    // [S]
+    double* inc_y = inc_x + S;                                   // [S]
+    int* red_i = reinterpret_cast<int*>(inc_y + S);              // [4]
+    int* cen_ok = red_i + 4;                                     // [64]
+    uint32_t* tile = reinterpret_cast<uint32_t*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [tile_rows][tile_words]
+
+    const int e = blockIdx.x;
+    if (e >= a.E) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int C = cfg.n_lookahead * cfg.n_width;
+    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
+
+    // ---- 1. nearest raceline segment (K1 logic) ------------------------------------------------------
+    double nd; int ni;
+    nearest_scan(px, py, a.wx, a.wy, a.n, tid, blockDim.x, nd, ni);
+    block_argmin(nd, ni, red_d, red_i);
+    const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
+
+    // ---- 2. look-ahead centres (K2 logic), one wave per look-ahead distance --------------------------
+    if (!a.goals) {
+        for (int l = wave; l < cfg.n_lookahead; l += nwaves) {
+            const Intersect it = wave_intersect(px, py, cfg.lookahead[l], a.wx, a.wy, a.n, (double)ni + ns.t, true);
+            if (lane == 0) {
+                cen_ok[l] = it.found ? 1 : 0;
+                if (it.found) {
+                    const int r = it.i < 0 ? it.i + a.n : it.i;
+                    cen_x[l] = a.wx[r]; cen_y[l] = a.wy[r]; cen_psi[l] = a.wpsi[r];   // waypoints[i2, [0,1,3]]
+                }
+            }
+        }
+    }
+
+    // ---- 3. occupancy tile around the ego -> LDS ------------------------------------------------------
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    int tile_gx0 = 0, tile_gy0 = 0;   // cell coordinates of tile word 0 / row 0 (gx0 is a multiple of 32)
+    if (collide_on) {
+        const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
+        const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
+        // clamp so the int conversion is defined even for far-away / NaN poses
+        const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+        const int half = a.tile_rows / 2;             // tile_words * 32 >= 2 * half + 32 covers the alignment slack
+        tile_gx0 = ((egx - half) >> 5) << 5;          // arithmetic shift: floor to a multiple of 32
+        tile_gy0 = egy - half;
+        const int nwords = a.tile_rows * a.tile_words;
+        for (int q = tid; q < nwords; q += blockDim.x) {
+            const int r = q / a.tile_words, j = q - r * a.tile_words;
+            const int gy = tile_gy0 + r, gw = (tile_gx0 >> 5) + j;
+            uint32_t v = 0xffffffffu;   // outside the map: occupied
+            if (gy >= 0 && gy < a.grid.h && gw >= 0 && gw < a.grid.wwords) v = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
+            tile[q] = v;
+        }
+    }
+    __syncthreads();
+
+    double sn_t, cs_t;
+    sincos(theta, &sn_t, &cs_t);
+    const double ct = cs_t, st = sn_t;
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+    const int sim_m = S - cfg.n_shift - cfg.n_cull;
+
+    double bc; int bi;
+    if (a.mode != LATTICE_EMIT) {
+        // ---- 4. candidates: fit, sample, check, cost -------------------------------------------------
+        const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
+        bc = __builtin_huge_val(); bi = 0x7fffffff;
+        for (int c = c0 + tid; c < c1; c += blockDim.x) {
+            double gx, gy, gth;
+            const bool gok = candidate_goal(a, cfg, e, c, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+            Clothoid cl;
+            cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
+            if (gok) cl = g1_fit(gx, gy, gth);
+            double cost = __builtin_huge_val();
+            double* trow = a.all_traj ? a.all_traj + ((size_t)e * C + c) * (size_t)S * 4 : nullptr;
+            if (cl.ok) {
+                const double ds = cl.L / (double)den;
+                const int nsub = clothoid_nsub(cl.k0, cl.dk, cl.L, ds);
+                double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
+                bool hit = false;
+                for (int i = 0; i < S; ++i) {
+                    const double s = (double)i * ds;
+                    const double th = s * (cl.k0 + 0.5 * s * cl.dk);
+                    const double ak = fabs(cl.k0 + cl.dk * s);
+                    if (ak > maxk) maxk = ak;
+                    sumk += ak;
+                    if (prev && i < sim_m) { const double d = th - prev[i + cfg.n_shift]; sim += d * d; }
+                    if (collide_on) {
+                        const double xm = px + (ct * x - st * y);
+                        const double ym = py + (st * x + ct * y);
+                        int cgx, cgy;
+                        bool occ = true;
+                        if (cell_of(a.grid, xm, ym, cgx, cgy)) {
+                            const int lx = cgx - tile_gx0, ly = cgy - tile_gy0;
+                            uint32_t wv_;
+                            if ((lx >= 0) & (ly >= 0) & (lx < a.tile_words * 32) & (ly < a.tile_rows))
+                                wv_ = tile[ly * a.tile_words + (lx >> 5)];
+                            else
+                                wv_ = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
+                            occ = (wv_ >> (cgx & 31)) & 1u;
+                        }
+                        hit |= occ;
+                    }
+                    if (trow) {
+                        reinterpret_cast<double2*>(trow)[2 * i] = make_double2(x, y);
+                        reinterpret_cast<double2*>(trow)[2 * i + 1] = make_double2(th, ak);
+                    }
+                    if (i + 1 < S) {
+                        double dx, dy;
+                        interval_increment(cl.k0, cl.dk, s, ds, nsub, dx, dy);
+                        x += dx; y += dy;
+                    }
+                }
+                cost = 0.0;                                   // eval(): cost = 0.; cost += w_i * f_i
+                cost += cfg.w_length * (1.0 / cl.L);
+                cost += cfg.w_max_kappa * maxk;
+                cost += cfg.w_mean_kappa * (sumk / (double)S);
+                cost += cfg.w_similarity * sim;
+                if (hit) cost = __builtin_huge_val();
+            } else if (trow) {
+                for (int i = 0; i < 2 * S; ++i) reinterpret_cast<double2*>(trow)[i] = make_double2(0.0, 0.0);
+            }
+            if (a.all_cost) a.all_cost[(size_t)e * C + c] = cost;
+            if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; }
+        }
+        // ---- 5. select(): argmin, first minimum wins ----------------------------------------------------
+        block_argmin(bc, bi, red_d, red_i);
+        if (tid == 0) {
+            if (a.best_idx) a.best_idx[e] = bi;
+            if (a.best_cost) a.best_cost[e] = bc;
+            if (a.near_idx) a.near_idx[e] = ni;
+        }
+        if (a.mode == LATTICE_EVAL) return;
+    } else {
+        bi = a.emit_idx[e];
+        bc = a.emit_cost ? a.emit_cost[e] : 0.0;
+        if (tid == 0 && a.near_idx) a.near_idx[e] = ni;
+    }
+
+    // ---- 6. re-emit the winner: every interval is independent -> one lane per interval -----------------
+    if (wave != 0) return;
+    Clothoid cl;
+    cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
+    if (bi >= 0 && bi < C) {
+        double gx, gy, gth;
+        if (candidate_goal(a, cfg, e, bi, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth))
+            cl = g1_fit(gx, gy, gth);
+    }
+    const double ds = cl.ok ? cl.L / (double)den : 0.0;
+    const int nsub = cl.ok ? clothoid_nsub(cl.k0, cl.dk, cl.L, ds) : 1;
+    for (int i = lane; i < S - 1; i += 64) {
+        double dx = 0.0, dy = 0.0;
+        if (cl.ok) interval_increment(cl.k0, cl.dk, (double)i * ds, ds, nsub, dx, dy);
+        inc_x[i] = dx; inc_y[i] = dy;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
+    __builtin_amdgcn_wave_barrier();
+    double* bt = a.best_traj ? a.best_traj + (size_t)e * S * 4 : nullptr;
+    for (int i = lane; i < S; i += 64) {
+        double x = 0.0, y = 0.0;
+        for (int j = 0; j < i; ++j) { x += inc_x[j]; y += inc_y[j]; }   // same order as the evaluation loop
+        tr_x[i] = x; tr_y[i] = y;
+        if (bt) {
+            const double s = (double)i * ds;
+            const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
+            const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
+            reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
+            reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 7. track the winner: PurePursuitPlanner.plan(0, 0, 0, L, best_traj) in the ego frame ----------
+    Track o;
+    o.steer = 0.0; o.speed = 0.0; o.la_idx = F1P_LA_NONE; o.status = F1P_ST_ALL_BLOCKED;
+    if (cl.ok && bc < __builtin_huge_val()) {
+        double td; int ti;
+        nearest_scan(0.0, 0.0, tr_x, tr_y, S, lane, 64, td, ti);
+        wave_argmin(td, ti);
+        const SegProj ts = seg_project(0.0, 0.0, tr_x[ti], tr_y[ti], tr_x[ti + 1], tr_y[ti + 1]);
+        o = wave_pursuit(0.0, 0.0, 0.0, cfg.track_lookahead, cfg.wheelbase, cfg.max_reacquire, tr_x, tr_y, nullptr,
+                         a.wv[ni], S, ti, ts.t, ts.d);
+    }
+    if (lane == 0) {
+        a.steer[e] = o.steer;
+        a.speed[e] = o.speed;
+        if (a.status) a.status[e] = o.status;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clothoid_g1(const double* __restrict__ goals, int n, double* __restrict__ k0,
+                                                     double* __restrict__ dk, double* __restrict__ len,
+                                                     int32_t* __restrict__ ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Clothoid cl = g1_fit(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]);
+    if (k0) k0[i] = cl.k0;
+    if (dk) dk[i] = cl.dk;
+    if (len) len[i] = cl.L;
+    if (ok) ok[i] = cl.ok ? 1 : 0;
+}
+
+int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                   int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
+                   double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
+                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj) {
+    if (E <= 0) return F1P_OK;
+    LatticeArgs a;
+    a.poses = d_poses; a.goals = d_goals; a.prev_theta = d_prev_theta;
+    a.E = E; a.mode = mode;
+    a.wx = ctx->d_wx; a.wy = ctx->d_wy; a.wv = ctx->d_wv; a.wpsi = ctx->d_wpsi; a.n = ctx->n_wp;
+    a.grid = grid_dev(ctx);
+    a.has_grid = ctx->has_grid ? 1 : 0;
+    a.emit_idx = d_emit_idx; a.emit_cost = d_emit_cost;
+    a.steer = d_steer; a.speed = d_speed; a.best_idx = d_best_idx; a.best_cost = d_best_cost;
+    a.status = d_status; a.near_idx = d_near_idx; a.best_traj = d_best_traj; a.all_cost = d_all_cost; a.all_traj = d_all_traj;
+    // tile size from the reach of the goal grid: max look-ahead + max |width| (+ margin), host goals: 4 m
+    a.tile_rows = 0; a.tile_words = 0;
+    if (cfg->check_collision && ctx->has_grid) {
+        double reach = 4.0;
+        if (!d_goals) {
+            double ml = 0, mw = 0;
+            for (int i = 0; i < cfg->n_lookahead; ++i) ml = cfg->lookahead[i] > ml ? cfg->lookahead[i] : ml;
+            for (int i = 0; i < cfg->n_width; ++i) { double w = cfg->width[i] < 0 ? -cfg->width[i] : cfg->width[i]; mw = w > mw ? w : mw; }
+            reach = ml + mw + 0.25;
+        }
+        int half = (int)(reach * ctx->inv_res) + 2;
+        if (half > 128) half = 128;
+        if (half < 16) half = 16;
+        a.tile_rows = 2 * half;
+        a.tile_words = (2 * half + 31) / 32 + 1;
+    }
+    const int S = cfg->n_stations;
+    size_t lds = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
+                 sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
+    lds = (lds + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(k_lattice, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    return check_hip(ctx, hipGetLastError(), "k_lattice launch");
+}
+
+int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok) {
+    if (n <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_clothoid_g1, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_goals, n, d_k0, d_dk, d_len, d_ok);
+    return check_hip(ctx, hipGetLastError(), "k_clothoid_g1 launch");
+}
+
+}  // namespace f1p

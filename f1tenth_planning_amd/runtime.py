@@ -1,0 +1,285 @@
+"""Host-side runtime above the C-ABI (include/f1p.h): one `Context` per GPU.
+
+Plumbing only -- numpy arrays in and out, ctypes calls into libf1p.so; no planning arithmetic happens in
+Python.  There is no CPU fallback: constructing a Context without the HIP library or without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import F1PLibraryError, KmpcCfg, LatticeCfg  # noqa: F401
+
+
+class F1PError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libf1p error {code}: {msg}")
+        self.code = code
+
+
+def _raise(code, msg):
+    if code == _abi.F1P_EINVAL:
+        raise ValueError(msg)
+    raise F1PError(code, msg)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class DeviceBuffer:
+    """A caller-visible HBM buffer (f1p_dev_alloc) for the *_dev entry points."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.f1p_dev_alloc(ctx.h, C.byref(p), C.c_size_t(self.nbytes)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.f1p_h2d(self.ctx.h, self.ptr, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)))
+        self.ctx.sync()   # the host array may die right after the call
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.f1p_d2h(self.ctx.h, C.c_void_p(out.ctypes.data), self.ptr, C.c_size_t(out.nbytes)))
+        self.ctx.sync()
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx.h is not None:
+            self.ctx.lib.f1p_dev_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+
+class Context:
+    """One f1p_ctx: one device, one HIP stream.  Not thread-safe; use one Context per thread / rank."""
+
+    def __init__(self, device=0):
+        self.lib = _abi.load_library()
+        h = C.c_void_p()
+        rc = self.lib.f1p_create(C.byref(h), int(device))
+        if rc != _abi.F1P_OK:
+            msg = self.lib.f1p_last_error(None).decode()
+            raise F1PError(rc, msg + " -- the HIP path is mandatory, there is no CPU fallback")
+        self.h = h
+        self.device = int(device)
+        self.n_waypoints = 0
+        self._wp_key = None
+        self.has_grid = False
+
+    # ---- housekeeping ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _abi.F1P_OK:
+            _raise(rc, self.lib.f1p_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            self.lib.f1p_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self.lib.f1p_sync(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256); arch = C.create_string_buffer(256); cu = C.c_int32()
+        self._check(self.lib.f1p_device_info(self.h, name, 256, C.byref(cu), arch, 256))
+        return dict(name=name.value.decode(), compute_units=cu.value, arch=arch.value.decode())
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
+
+    def timer_begin(self):
+        self._check(self.lib.f1p_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._check(self.lib.f1p_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- scene ---------------------------------------------------------------------------------------
+    def set_waypoints(self, waypoints, cols=None):
+        """waypoints [N, m>=3]; cols = (x, y, v, psi) column indices, psi = -1 for none.  Default: the
+        pure-pursuit layout [x, y, v, psi, ...] (pure_pursuit.py:49)."""
+        wp = np.asarray(waypoints)
+        if wp.ndim != 2 or wp.shape[1] < 3:
+            raise ValueError('Waypoints needs to be a (Nxm), m >= 3, numpy array!')   # pure_pursuit.py:101-102
+        wp = _f64(wp)
+        if cols is None:
+            cols = (0, 1, 2, 3 if wp.shape[1] >= 4 else -1)
+        self._check(self.lib.f1p_set_waypoints(self.h, _ptr(wp), wp.shape[0], wp.shape[1], *[int(c) for c in cols]))
+        self.n_waypoints = wp.shape[0]
+
+    def set_waypoints_cached(self, waypoints, cols=None):
+        """Upload only when the caller's array changed (the reference keeps a live reference to the caller's
+        array, pure_pursuit.py:103, so in-place edits must be seen)."""
+        wp = np.asarray(waypoints)
+        if wp.ndim != 2 or wp.shape[1] < 3:
+            raise ValueError('Waypoints needs to be a (Nxm), m >= 3, numpy array!')
+        import zlib
+        key = (wp.shape, wp.dtype.str, cols, zlib.crc32(np.ascontiguousarray(wp).view(np.uint8).reshape(-1)))
+        if key != self._wp_key:
+            self.set_waypoints(wp, cols)
+            self._wp_key = key
+
+    def set_grid(self, img, resolution, origin, occupied_below):
+        """img [h, w] u8, row 0 = top (ROS map_server); a cell is occupied iff value < occupied_below."""
+        if img is None:
+            self._check(self.lib.f1p_set_grid(self.h, None, 0, 0, 0.0, 0.0, 0.0, 0))
+            self.has_grid = False
+            return
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.ndim != 2:
+            raise ValueError("occupancy image must be 2-D u8")
+        self._check(self.lib.f1p_set_grid(self.h, _ptr(img), img.shape[1], img.shape[0], float(resolution),
+                                          float(origin[0]), float(origin[1]), int(occupied_below)))
+        self.has_grid = True
+
+    # ---- leaf kernels ----------------------------------------------------------------------------------
+    def nearest_point(self, pts):
+        pts = _f64(pts, (-1, 2)); E = pts.shape[0]
+        proj = np.empty((E, 2)); dist = np.empty(E); t = np.empty(E); idx = np.empty(E, np.int32)
+        self._check(self.lib.f1p_nearest_point_batch(self.h, _ptr(pts), E, _ptr(proj), _ptr(dist), _ptr(t), _ptr(idx)))
+        return proj, dist, t, idx
+
+    def intersect_point(self, pts, radius, start_t, wrap=False):
+        pts = _f64(pts, (-1, 2)); E = pts.shape[0]
+        st = _f64(np.broadcast_to(start_t, (E,)))
+        p = np.empty((E, 2)); i = np.empty(E, np.int32); t = np.empty(E); found = np.empty(E, np.int32)
+        self._check(self.lib.f1p_intersect_point_batch(self.h, _ptr(pts), _ptr(st), E, float(radius), 1 if wrap else 0,
+                                                       _ptr(p), _ptr(i), _ptr(t), _ptr(found)))
+        return p, i, t, found.astype(bool)
+
+    def clothoid_g1(self, goals):
+        g = _f64(goals, (-1, 3)); n = g.shape[0]
+        k0 = np.empty(n); dk = np.empty(n); L = np.empty(n); ok = np.empty(n, np.int32)
+        self._check(self.lib.f1p_clothoid_g1_batch(self.h, _ptr(g), n, _ptr(k0), _ptr(dk), _ptr(L), _ptr(ok)))
+        return k0, dk, L, ok.astype(bool)
+
+    # ---- pure pursuit ------------------------------------------------------------------------------------
+    def pure_pursuit(self, poses, lookahead, wheelbase=0.33, max_reacquire=20.0):
+        poses = _f64(poses, (-1, 3)); E = poses.shape[0]
+        out = dict(steer=np.empty(E), speed=np.empty(E), near_idx=np.empty(E, np.int32), la_idx=np.empty(E, np.int32),
+                   status=np.empty(E, np.int32))
+        self._check(self.lib.f1p_pure_pursuit_batch(self.h, _ptr(poses), E, float(lookahead), float(wheelbase),
+                                                    float(max_reacquire), _ptr(out["steer"]), _ptr(out["speed"]),
+                                                    _ptr(out["near_idx"]), _ptr(out["la_idx"]), _ptr(out["status"])))
+        return out
+
+    # ---- lattice -------------------------------------------------------------------------------------------
+    def lattice_plan(self, poses, cfg: LatticeCfg, goals=None, prev_theta=None, want_traj=True, want_all=False):
+        poses = _f64(poses, (-1, 4)); E = poses.shape[0]; Cn = cfg.n_cand; S = cfg.n_stations
+        g = None if goals is None else _f64(goals, (E, Cn, 3))
+        pt = None if prev_theta is None else _f64(prev_theta, (E, S))
+        out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
+                   status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
+        if want_traj:
+            out["best_traj"] = np.empty((E, S, 4))
+        if want_all:
+            out["all_cost"] = np.empty((E, Cn)); out["all_traj"] = np.empty((E, Cn, S, 4))
+        self._check(self.lib.f1p_lattice_plan_batch(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
+                                                    _ptr(out["steer"]), _ptr(out["speed"]), _ptr(out["best_idx"]),
+                                                    _ptr(out["best_cost"]), _ptr(out["status"]), _ptr(out["near_idx"]),
+                                                    _ptr(out.get("best_traj")), _ptr(out.get("all_cost")),
+                                                    _ptr(out.get("all_traj"))))
+        return out
+
+    def lattice_plan_dev(self, d_poses, E, cfg: LatticeCfg, d_steer, d_speed, d_best_idx, d_best_cost=None, d_status=None,
+                         d_near_idx=None, d_best_traj=None, d_goals=None, d_prev_theta=None, d_all_cost=None,
+                         d_all_traj=None):
+        """Asynchronous launch on HBM-resident buffers (DeviceBuffer or None)."""
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_lattice_plan_dev(self.h, p(d_poses), p(d_goals), p(d_prev_theta), int(E), C.byref(cfg),
+                                                  p(d_steer), p(d_speed), p(d_best_idx), p(d_best_cost), p(d_status),
+                                                  p(d_near_idx), p(d_best_traj), p(d_all_cost), p(d_all_traj)))
+
+    def lattice_emit_dev(self, d_poses, E, cfg: LatticeCfg, d_cand_idx, d_cand_cost, d_steer, d_speed, d_status=None,
+                         d_near_idx=None, d_best_traj=None, d_goals=None):
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_lattice_emit_dev(self.h, p(d_poses), p(d_goals), int(E), C.byref(cfg), p(d_cand_idx),
+                                                  p(d_cand_cost), p(d_steer), p(d_speed), p(d_status), p(d_near_idx),
+                                                  p(d_best_traj)))
+
+    # ---- kinematic MPC -------------------------------------------------------------------------------------
+    def kmpc_ref(self, states, horizon, dt=0.1, dl=0.03):
+        st = _f64(states, (-1, 4)); E = st.shape[0]
+        ref = np.empty((E, 4, horizon + 1))
+        self._check(self.lib.f1p_kmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
+        return ref
+
+    def kmpc_shoot(self, x0, ref, controls, cfg: KmpcCfg, want_seq=True):
+        x0 = _f64(x0, (-1, 4)); E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
+        ref = _f64(ref, (E, 4, T + 1))
+        controls = np.ascontiguousarray(controls, dtype=np.float32)
+        if controls.shape != (E, T, 2, R):
+            raise ValueError(f"controls must be f32 [E={E}, T={T}, 2, R={R}]")
+        out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E))
+        if want_seq:
+            out["best_seq"] = np.empty((E, T, 2))
+        self._check(self.lib.f1p_kmpc_shoot_batch(self.h, _ptr(x0), _ptr(ref), _ptr(controls), E, C.byref(cfg),
+                                                  _ptr(out["steer"]), _ptr(out["speed"]), _ptr(out["best_idx"]),
+                                                  _ptr(out["best_cost"]), _ptr(out.get("best_seq"))))
+        return out
+
+    def kmpc_shoot_dev(self, d_x0, d_ref, d_controls, E, cfg: KmpcCfg, d_steer, d_speed, d_best_idx, d_best_cost=None,
+                       d_best_seq=None):
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_kmpc_shoot_dev(self.h, p(d_x0), p(d_ref), p(d_controls), int(E), C.byref(cfg), p(d_steer),
+                                                p(d_speed), p(d_best_idx), p(d_best_cost), p(d_best_seq)))
+
+    def kmpc_sample_controls_dev(self, d_controls, E, cfg: KmpcCfg, seed, sigma_accel=1.5, sigma_steer=0.15):
+        self._check(self.lib.f1p_kmpc_sample_controls_dev(self.h, d_controls.ptr, int(E), C.byref(cfg),
+                                                          C.c_uint64(int(seed)), float(sigma_accel), float(sigma_steer)))
+
+    # ---- multi-GPU exchange step -----------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+        self._check(self.lib.f1p_comm_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_init(self, uid, nranks, rank):
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(uid)
+        self._check(self.lib.f1p_comm_init(self.h, buf, int(nranks), int(rank)))
+
+    def comm_argmin_dev(self, d_cost, d_idx, E):
+        self._check(self.lib.f1p_comm_argmin_dev(self.h, d_cost.ptr, d_idx.ptr, int(E)))
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide Context on LOCAL_RANK (or device 0) used by the drop-in planner classes."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

@@ -1,0 +1,132 @@
+"""Seeded synthetic scenes for benchmarks and parity tests.
+
+Nothing here reads the reference's data files: the GPU box has no /root/reference.  The shapes match the
+reference's assets -- a closed 1692-point raceline at ~0.2 m spacing with columns [x, y, v, psi, kappa]
+(examples/control/Spielberg_raceline.csv:1), a 2000 x 2000 u8 occupancy image at 0.058 m per cell in the
+ROS map_server layout (examples/control/Spielberg_map.yaml:1-6), a 1828-point centreline at ~0.035 m
+spacing with constant v = 3 (examples/control/levine_centerline.csv:1-3).
+"""
+import numpy as np
+
+
+def _closed_curve(rng, n_pts, spacing, k_lo=3, k_hi=8, amp=(0.04, 0.10)):
+    """Closed polar curve r(phi) = R0 (1 + sum_k a_k cos(k phi + b_k)) resampled to n_pts points with equal
+    arc length `spacing`, first row == last row."""
+    ks = np.arange(k_lo, k_hi + 1)
+    a = rng.uniform(amp[0], amp[1], len(ks)) * rng.choice([-1.0, 1.0], len(ks))
+    b = rng.uniform(0, 2 * np.pi, len(ks))
+    phi = np.linspace(0.0, 2 * np.pi, 400001)
+    shape = 1.0 + (a[:, None] * np.cos(ks[:, None] * phi[None, :] + b[:, None])).sum(0)
+    ux, uy = shape * np.cos(phi), shape * np.sin(phi)
+    unit_len = np.hypot(np.diff(ux), np.diff(uy)).sum()
+    R0 = (n_pts - 1) * spacing / unit_len
+    x, y = R0 * ux, R0 * uy
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+    st = np.linspace(0.0, s[-1], n_pts)
+    xs, ys = np.interp(st, s, x), np.interp(st, s, y)
+    xs[-1], ys[-1] = xs[0], ys[0]
+    return xs, ys
+
+
+def _heading_curvature(xs, ys):
+    # closed curve: central differences with wrap (last row duplicates the first)
+    x, y = xs[:-1], ys[:-1]
+    dx = np.roll(x, -1) - np.roll(x, 1)
+    dy = np.roll(y, -1) - np.roll(y, 1)
+    psi = np.arctan2(dy, dx)
+    ds = 0.5 * np.hypot(dx, dy)
+    dpsi = np.arctan2(np.sin(np.roll(psi, -1) - np.roll(psi, 1)), np.cos(np.roll(psi, -1) - np.roll(psi, 1)))
+    kappa = 0.5 * dpsi / ds
+    return np.append(psi, psi[0]), np.append(kappa, kappa[0])
+
+
+def make_raceline(seed=0, n_pts=1692, spacing=0.2):
+    """[n_pts, 5] fp64 rows [x, y, v, psi, kappa]; closed (row 0 == row -1)."""
+    rng = np.random.default_rng(seed)
+    xs, ys = _closed_curve(rng, n_pts, spacing)
+    psi, kappa = _heading_curvature(xs, ys)
+    v = rng.uniform(4.5, 8.0, n_pts - 1)
+    ker = np.ones(41) / 41.0
+    v = np.convolve(np.concatenate([v[-20:], v, v[:20]]), ker, mode="valid")
+    v = np.append(v, v[0])
+    return np.ascontiguousarray(np.column_stack([xs, ys, v, psi, kappa]))
+
+
+def make_centerline(seed=2, n_pts=1828, spacing=0.0347, v=3.0):
+    """Levine-like centreline, [n_pts, 7] rows [s, x, y, psi, kappa, vx, ax]; open seam (row 0 != row -1)."""
+    rng = np.random.default_rng(seed)
+    xs, ys = _closed_curve(rng, n_pts + 1, spacing, k_lo=2, k_hi=4, amp=(0.05, 0.15))
+    psi, kappa = _heading_curvature(xs, ys)
+    xs, ys, psi, kappa = xs[:-1], ys[:-1], psi[:-1], kappa[:-1]
+    s = np.arange(n_pts) * spacing
+    return np.ascontiguousarray(np.column_stack([s, xs, ys, psi, kappa, np.full(n_pts, v), np.zeros(n_pts)]))
+
+
+def make_grid(raceline_xy, size=(2000, 2000), resolution=0.058, half_width=1.1, wall_px=3):
+    """Occupancy image [h, w] u8 in the ROS map_server layout (row 0 = top): free corridor (255) of
+    +-half_width around the line, walls (0) of `wall_px` cells around it, unknown (205) elsewhere is also
+    below no threshold -> only the walls and the outside of the image block.  Returns (img, origin_xy)."""
+    h, w = size
+    xy = np.asarray(raceline_xy, dtype=np.float64)
+    cx, cy = 0.5 * (xy[:, 0].min() + xy[:, 0].max()), 0.5 * (xy[:, 1].min() + xy[:, 1].max())
+    ox, oy = cx - 0.5 * w * resolution, cy - 0.5 * h * resolution
+    # distance-to-line field by stamping discs along a densified line (chunked, vectorised)
+    free = np.zeros((h, w), dtype=bool)
+    near = np.zeros((h, w), dtype=bool)
+    seg = np.diff(xy, axis=0)
+    nsub = max(1, int(np.ceil(np.hypot(seg[:, 0], seg[:, 1]).max() / (0.5 * resolution))))
+    t = (np.arange(nsub) / nsub)[None, :, None]
+    dense = (xy[:-1, None, :] + t * seg[:, None, :]).reshape(-1, 2)
+    r_free = int(np.ceil(half_width / resolution))
+    r_wall = r_free + wall_px
+    gx = np.floor((dense[:, 0] - ox) / resolution).astype(np.int64)
+    gy = np.floor((dense[:, 1] - oy) / resolution).astype(np.int64)
+    cells = np.unique(np.stack([gy, gx], 1), axis=0)
+    yy, xx = np.mgrid[-r_wall:r_wall + 1, -r_wall:r_wall + 1]
+    d2 = (yy * yy + xx * xx) * resolution * resolution
+    m_free = d2 <= half_width ** 2
+    m_near = d2 <= (half_width + wall_px * resolution) ** 2
+    for mask, dst in ((m_free, free), (m_near, near)):
+        oy_, ox_ = np.nonzero(mask)
+        oy_ -= r_wall; ox_ -= r_wall
+        for k in range(len(oy_)):
+            ry, rx = cells[:, 0] + oy_[k], cells[:, 1] + ox_[k]
+            ok = (ry >= 0) & (ry < h) & (rx >= 0) & (rx < w)
+            dst[ry[ok], rx[ok]] = True
+    img_gy = np.full((h, w), 205, dtype=np.uint8)   # indexed [gy][gx]
+    img_gy[near] = 0
+    img_gy[free] = 255
+    return np.ascontiguousarray(img_gy[::-1]), (float(ox), float(oy))
+
+
+def make_egos(raceline, n, seed=1, pos_sigma=0.3, yaw_sigma=0.15):
+    """[n, 4] fp64 poses (x, y, theta, v): a raceline point + N(0, pos_sigma) noise, heading + N(0, yaw_sigma)."""
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, raceline.shape[0] - 1, n)
+    x = raceline[k, 0] + rng.normal(0, pos_sigma, n)
+    y = raceline[k, 1] + rng.normal(0, pos_sigma, n)
+    th = raceline[k, 3] + rng.normal(0, yaw_sigma, n)
+    v = rng.uniform(0.5, 6.0, n)
+    return np.ascontiguousarray(np.column_stack([x, y, th, v]))
+
+
+def make_controls(E, T, R, seed=3, sigma_a=1.5, sigma_d=0.15, max_accel=3.0, max_steer=0.4189):
+    """f32 [E, T, 2, R]: accel ~ clip(N(0, sigma_a)), steer ~ clip(N(0, sigma_d))."""
+    rng = np.random.default_rng(seed)
+    c = np.empty((E, T, 2, R), dtype=np.float32)
+    c[:, :, 0, :] = np.clip(rng.normal(0, sigma_a, (E, T, R)), -max_accel, max_accel)
+    c[:, :, 1, :] = np.clip(rng.normal(0, sigma_d, (E, T, R)), -max_steer, max_steer)
+    return c
+
+
+def bench_lattice_cfg(n_cand=256, n_stations=50):
+    """The BASELINE.json lattice workload: look-aheads linspace(0.6, 3.0, 16) x widths linspace(-1, 1, C/16),
+    S = 50 stations, equal weights on the four cost terms, collision check on."""
+    from ._abi import lattice_cfg
+    n_l = 16
+    n_w = n_cand // n_l
+    if n_l * n_w != n_cand:
+        raise ValueError("n_cand must be a multiple of 16")
+    return lattice_cfg(lookaheads=np.linspace(0.6, 3.0, n_l), widths=np.linspace(-1.0, 1.0, n_w),
+                       n_stations=n_stations, weights=(0.25, 0.25, 0.25, 0.25), n_shift=1, n_cull=1,
+                       check_collision=True)

@@ -316,8 +316,9 @@ typedef struct orc_grid {
 } orc_grid;
 
 ORC_API int orc_cell_occupied(const orc_grid* g, double x, double y) {
-    double fx = floor((x - g->ox) / g->res);
-    double fy = floor((y - g->oy) / g->res);
+    double inv_res = 1.0 / g->res; /* one division per map, then multiplies (DESIGN.md "Occupancy grid") */
+    double fx = floor((x - g->ox) * inv_res);
+    double fy = floor((y - g->oy) * inv_res);
     if (!(fx >= 0.0) || !(fy >= 0.0) || !(fx < (double)g->w) || !(fy < (double)g->h)) return 1; /* outside / NaN */
     int gx = (int)fx, gy = (int)fy;
     return g->img[(size_t)(g->h - 1 - gy) * g->w + gx] < g->occupied_below;
