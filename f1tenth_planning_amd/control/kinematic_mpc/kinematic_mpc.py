@@ -1,0 +1,182 @@
+"""KMPCPlanner on the MI355X path: kinematic-bicycle MPC solved by random shooting.
+
+Same class names (`mpc_config`, `State`, `KMPCPlanner`), constructor and `plan(states, waypoints=None)` signature
+as the reference (f1tenth_planning/control/kinematic_mpc/kinematic_mpc.py:40-160), so
+examples/control/kinematic_mpc.py drives it unchanged.  What differs is the solver: the reference linearises the
+model and solves a QP with cvxpy/OSQP (:283-450, third-party, out of scope); here R candidate control sequences are
+rolled out through the reference's own nonlinear step (update_state_kinematic :223-243) on the GPU
+(csrc/k_kmpc.hip), scored with the reference's objective (:324-334) and bounds (:391-401), and the best one is
+applied (:506-508).  The reference trajectory extraction (calc_ref_trajectory_kinematic :162-206) also runs on the
+GPU.
+"""
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ... import _abi
+from ...runtime import Context
+
+
+@dataclass
+class mpc_config:
+    NXK: int = 4  # length of kinematic state vector: z = [x, y, v, yaw]
+    NU: int = 2  # length of input vector: u = [acceleration, steering angle]
+    TK: int = 8  # finite time horizon length kinematic
+    Rk: list = field(default_factory=lambda: np.diag([0.01, 100.0]))   # input cost matrix [accel, steer]
+    Rdk: list = field(default_factory=lambda: np.diag([0.01, 100.0]))  # input difference cost matrix
+    Qk: list = field(default_factory=lambda: np.diag([13.5, 13.5, 5.5, 13.0]))   # state error cost [x, y, v, yaw]
+    Qfk: list = field(default_factory=lambda: np.diag([13.5, 13.5, 5.5, 13.0]))  # final state error cost
+    N_IND_SEARCH: int = 20  # Search index number
+    DTK: float = 0.1  # time step [s] kinematic
+    dlk: float = 0.03  # dist step [m] kinematic
+    LENGTH: float = 0.58  # Length of the vehicle [m]
+    WIDTH: float = 0.31  # Width of the vehicle [m]
+    WB: float = 0.33  # Wheelbase [m]
+    MIN_STEER: float = -0.4189  # minimum steering angle [rad]
+    MAX_STEER: float = 0.4189  # maximum steering angle [rad]
+    MAX_DSTEER: float = np.deg2rad(180.0)  # maximum steering speed [rad/s]
+    MAX_SPEED: float = 6.0  # maximum speed [m/s]
+    MIN_SPEED: float = 0.0  # minimum backward speed [m/s]
+    MAX_ACCEL: float = 3.0  # maximum acceleration [m/ss]
+    # shooting parameters (not in the reference: its solver is a QP)
+    N_ROLLOUTS: int = 512  # candidate control sequences per plan
+    SIGMA_ACCEL: float = 1.5  # std of the acceleration samples [m/ss]
+    SIGMA_STEER: float = 0.15  # std of the steering samples [rad]
+    SEED: int = 0
+
+
+@dataclass
+class State:
+    x: float = 0.0
+    y: float = 0.0
+    delta: float = 0.0
+    v: float = 0.0
+    yaw: float = 0.0
+    yawrate: float = 0.0
+    beta: float = 0.0
+
+
+def _cfg_struct(c: mpc_config, n_rollouts=None):
+    return _abi.kmpc_cfg(horizon=c.TK, n_rollouts=n_rollouts or c.N_ROLLOUTS, dt=c.DTK, wheelbase=c.WB, max_steer=c.MAX_STEER,
+                         max_dsteer=c.MAX_DSTEER, max_speed=c.MAX_SPEED, min_speed=c.MIN_SPEED, max_accel=c.MAX_ACCEL,
+                         q=np.diag(c.Qk), qf=np.diag(c.Qfk), r=np.diag(c.Rk), rd=np.diag(c.Rdk))
+
+
+class KMPCPlanner:
+    """
+    Kinematic MPC controller (random shooting on the GPU).  All poses are in the map frame.
+
+    Args:
+        waypoints: [x, y, yaw, v] as a list of four 1-D arrays or an array [4, N]
+            (examples/control/kinematic_mpc.py:44-45)
+        config (mpc_config)
+    """
+
+    def __init__(self, waypoints=None, config=mpc_config(),
+                 params=np.array([3.74, 0.15875, 0.17145, 0.074, 4.718, 5.4562, 0.04712, 1.0489]), debug=False, device=None):
+        self.waypoints = waypoints
+        self.config = config
+        self.vehicle_params = params
+        self.odelta_v = None
+        self.oa = None
+        self.odelta = None
+        self.init_flag = 0
+        self.debug = debug
+        self._device = device
+        self._ctx = None
+        self._calls = 0
+
+    def _context(self):
+        if self._ctx is None:
+            dev = self._device if self._device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+            self._ctx = Context(dev)
+        return self._ctx
+
+    def _bind(self, waypoints):
+        if waypoints is not None:
+            w = np.asarray(waypoints)
+            if len(w.shape) != 2 or w.shape[1] < 3:
+                raise ValueError("Waypoints needs to be a (Nxm), m >= 3, numpy array!")     # :131-132
+            self.waypoints = waypoints
+        elif self.waypoints is None:
+            raise ValueError("Please set waypoints to track during planner instantiation or when calling plan()")
+        path = self.waypoints
+        cx, cy, cyaw, sp = (np.asarray(path[k], dtype=np.float64) for k in range(4))             # :479-482
+        ctx = self._context()
+        ctx.set_waypoints_cached(np.column_stack([cx, cy, sp, cyaw]), cols=(0, 1, 2, 3))
+        return ctx
+
+    def _controls(self, E, cfg, warm):
+        """Candidate sequences [E, T, 2, R] f32: Gaussian perturbations around the warm start (previous solution shifted
+        by one step, :491-498); rollout 0 is the unperturbed warm start, rollout 1 is all-zero."""
+        c = self.config
+        T, R = cfg.horizon, cfg.n_rollouts
+        rng = np.random.default_rng([c.SEED, self._calls])
+        ctrl = np.empty((E, T, 2, R), dtype=np.float32)
+        ctrl[:, :, 0, :] = rng.normal(0.0, c.SIGMA_ACCEL, (E, T, R))
+        ctrl[:, :, 1, :] = rng.normal(0.0, c.SIGMA_STEER, (E, T, R))
+        ctrl[:, :, :, 0] = 0.0
+        if warm is not None:
+            ctrl += warm[:, :, :, None].astype(np.float32)
+        if R > 1:
+            ctrl[:, :, :, 1] = 0.0
+        ctrl[:, :, 0, :] = np.clip(ctrl[:, :, 0, :], -c.MAX_ACCEL, c.MAX_ACCEL)
+        ctrl[:, :, 1, :] = np.clip(ctrl[:, :, 1, :], -c.MAX_STEER, c.MAX_STEER)
+        return ctrl
+
+    def plan(self, states, waypoints=None):
+        """
+        states: [x, y, delta, v, yaw, yawrate, beta] (the 7-state of f110_gym, :139-147).
+        Returns (steering_angle, speed).
+        """
+        ctx = self._bind(waypoints)
+        vehicle_state = State(x=states[0], y=states[1], delta=states[2], v=states[3], yaw=states[4], yawrate=states[5],
+                              beta=states[6])
+        x0 = np.array([[vehicle_state.x, vehicle_state.y, vehicle_state.v, vehicle_state.yaw]], dtype=np.float64)   # :487
+        out = self._shoot(ctx, x0)
+        self.oa = out["best_seq"][0, :, 0]
+        self.odelta_v = out["best_seq"][0, :, 1]
+        return float(out["steer"][0]), float(out["speed"][0])
+
+    def _shoot(self, ctx, x0):
+        c = self.config
+        cfg = _cfg_struct(c)
+        ref = ctx.kmpc_ref(x0, c.TK, c.DTK, c.dlk)
+        warm = None
+        if self.oa is not None and x0.shape[0] == 1:
+            warm = np.zeros((1, c.TK, 2))
+            warm[0, :-1, 0] = self.oa[1:]; warm[0, -1, 0] = self.oa[-1]
+            warm[0, :-1, 1] = self.odelta_v[1:]; warm[0, -1, 1] = self.odelta_v[-1]
+        ctrl = self._controls(x0.shape[0], cfg, warm)
+        self._calls += 1
+        return ctx.kmpc_shoot(x0, ref, ctrl, cfg)
+
+    def plan_batch(self, x0, waypoints=None, controls=None):
+        """x0 [E, 4] = (x, y, v, yaw) -> dict(steer, speed, best_idx, best_cost, best_seq).  `controls`
+        (f32 [E, T, 2, R]) overrides the internal sampler."""
+        ctx = self._bind(waypoints)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, 4)
+        if controls is None:
+            return self._shoot(ctx, x0)
+        c = self.config
+        cfg = _cfg_struct(c, n_rollouts=controls.shape[3])
+        ref = ctx.kmpc_ref(x0, c.TK, c.DTK, c.dlk)
+        return ctx.kmpc_shoot(x0, ref, controls, cfg)
+
+    # the reference's helper methods, on the GPU ---------------------------------------------------------------------
+    def predict_motion_kinematic(self, x0, oa, od, xref=None):
+        """Open-loop rollout [4, T+1] of update_state_kinematic for the controls (oa, od) (:208-221)."""
+        c = self.config
+        cfg = _cfg_struct(c)
+        cfg.horizon = len(oa)
+        return self._context().kmpc_predict(np.asarray(x0, dtype=np.float64)[None, :], np.asarray(oa, dtype=np.float64)[None, :],
+                                            np.asarray(od, dtype=np.float64)[None, :], cfg)[0]
+
+    def calc_ref_trajectory_kinematic(self, state, cx, cy, cyaw, sp):
+        """Reference trajectory [4, T+1] (rows x, y, v, yaw) along the course from the nearest point (:162-206).  Unlike the
+        reference, the caller's `cyaw` array is not modified (the +-2 pi fix-up of :198-203 is applied to the gathered values)."""
+        ctx = self._context()
+        ctx.set_waypoints_cached(np.column_stack([cx, cy, sp, cyaw]), cols=(0, 1, 2, 3))
+        c = self.config
+        return ctx.kmpc_ref(np.array([[state.x, state.y, state.v, state.yaw]], dtype=np.float64), c.TK, c.DTK, c.dlk)[0]

@@ -490,6 +490,24 @@ int f1p_kmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, cons
     return s.finish();
 }
 
+int f1p_kmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od, int32_t E,
+                           const f1p_kmpc_cfg* cfg, double* path) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!x0 || !oa || !od || !path)) return set_error(ctx, F1P_EINVAL, "x0, oa, od and path are required");
+    const size_t T = cfg->horizon, e = E;
+    Stage s(ctx);
+    s.need(8 * 4 * e); s.need(8 * e * T); s.need(8 * e * T); s.need(8 * e * 4 * (T + 1));
+    if ((rc = s.begin())) return rc;
+    const double *d_x0, *d_oa, *d_od;
+    if ((rc = s.in(x0, 4 * e, &d_x0))) return rc;
+    if ((rc = s.in(oa, e * T, &d_oa))) return rc;
+    if ((rc = s.in(od, e * T, &d_od))) return rc;
+    double* d_path = s.out(path, e * 4 * (T + 1));
+    if ((rc = launch_kmpc_predict(ctx, d_x0, d_oa, d_od, E, cfg, d_path))) return rc;
+    return s.finish();
+}
+
 int f1p_kmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl, double* ref) {
     F1P_ENTER(ctx);
     if (E < 0 || (E > 0 && (!states || !ref))) return set_error(ctx, F1P_EINVAL, "bad states / ref / E");

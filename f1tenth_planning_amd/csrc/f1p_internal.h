@@ -75,6 +75,8 @@ int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0,
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                       double* d_best_cost, double* d_best_seq);
+int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, const double* d_od, int E,
+                        const f1p_kmpc_cfg* cfg, double* d_path);
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);
 int launch_kmpc_sample(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, uint64_t seed, double sigma_a,
                        double sigma_d);

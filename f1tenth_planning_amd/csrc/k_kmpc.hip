@@ -99,6 +99,23 @@ __global__ __launch_bounds__(256) void k_kmpc_shoot(const double* __restrict__ x
     }
 }
 
+// predict_motion_kinematic :208-221: one thread per ego, T sequential steps, path [E][4][T+1]
+__global__ __launch_bounds__(256) void k_kmpc_predict(const double* __restrict__ x0, const double* __restrict__ oa,
+                                                      const double* __restrict__ od, int E, f1p_kmpc_cfg cfg,
+                                                      double* __restrict__ path) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int T = cfg.horizon;
+    KmpcStep s;
+    s.x = x0[4 * e]; s.y = x0[4 * e + 1]; s.v = x0[4 * e + 2]; s.yaw = x0[4 * e + 3];
+    double* p = path + (size_t)e * 4 * (T + 1);
+    p[0] = s.x; p[T + 1] = s.y; p[2 * (T + 1)] = s.v; p[3 * (T + 1)] = s.yaw;
+    for (int t = 0; t < T; ++t) {
+        kmpc_step(s, oa[(size_t)e * T + t], od[(size_t)e * T + t], cfg);
+        p[t + 1] = s.x; p[(T + 1) + t + 1] = s.y; p[2 * (T + 1) + t + 1] = s.v; p[3 * (T + 1) + t + 1] = s.yaw;
+    }
+}
+
 // calc_ref_trajectory_kinematic :162-206.  states [E][4] = (x, y, v, yaw); waypoints of the ctx are
 // (cx, cy, sp, cyaw) = (wx, wy, wv, wpsi).  ref [E][4][T+1].
 __global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
@@ -174,6 +191,13 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
     hipLaunchKernelGGL(k_kmpc_shoot, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
                        *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot launch");
+}
+
+int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, const double* d_od, int E,
+                        const f1p_kmpc_cfg* cfg, double* d_path) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_kmpc_predict, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_x0, d_oa, d_od, E, *cfg, d_path);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_predict launch");
 }
 
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref) {

@@ -235,6 +235,14 @@ class Context:
         self._check(self.lib.f1p_kmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
         return ref
 
+    def kmpc_predict(self, x0, oa, od, cfg: KmpcCfg):
+        """predict_motion_kinematic (kinematic_mpc.py:208-221) for E egos -> path [E, 4, T+1]"""
+        x0 = _f64(x0, (-1, 4)); E = x0.shape[0]; T = cfg.horizon
+        oa = _f64(oa, (E, T)); od = _f64(od, (E, T))
+        path = np.empty((E, 4, T + 1))
+        self._check(self.lib.f1p_kmpc_predict_batch(self.h, _ptr(x0), _ptr(oa), _ptr(od), E, C.byref(cfg), _ptr(path)))
+        return path
+
     def kmpc_shoot(self, x0, ref, controls, cfg: KmpcCfg, want_seq=True):
         x0 = _f64(x0, (-1, 4)); E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
         ref = _f64(ref, (E, 4, T + 1))

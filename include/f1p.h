@@ -230,6 +230,11 @@ int f1p_kmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, cons
 int f1p_kmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,
                        const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                        double* d_best_cost, double* d_best_seq);
+/* predict_motion_kinematic (:208-221) for E egos: open-loop rollout of update_state_kinematic (:223-243).
+ * x0 [E][4], oa [E][T], od [E][T] (fp64, used as given: only the steer clamp inside the step applies)
+ * -> path [E][4][T+1], rows x, y, v, yaw; column 0 is x0. */
+int f1p_kmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od, int32_t E,
+                           const f1p_kmpc_cfg* cfg, double* path);
 /* calc_ref_trajectory_kinematic (:162-206) for E egos against the ctx waypoints (cols x, y, v, psi):
  * states [E][4] = (x, y, v, yaw) -> ref [E][4][T+1].  The reference's in-place fix-up of cyaw (:198-203) is
  * applied to a per-ego view, never to the stored waypoints. */

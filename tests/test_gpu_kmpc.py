@@ -1,0 +1,170 @@
+"""K4 parity on the MI355X: kinematic-bicycle random-shooting MPC and the reference-trajectory extraction
+through the C-ABI against the CPU oracle and the golden vectors captured from the reference.
+Bar: best rollout index bit-exact; ref trajectory (pure gathers) bit-exact; steer/speed/cost 1e-9."""
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from f1tenth_planning_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_ref_trajectory_golden(ctx, golden, tracks):
+    g = golden("g5_g6_kmpc.npz")
+    lev = tracks["levine"]
+    ctx.set_waypoints(lev, cols=(1, 2, 5, 3))            # cx, cy, sp, cyaw  (examples/control/kinematic_mpc.py:42-45)
+    for T in (8, 30):
+        ref = ctx.kmpc_ref(g[f"ref{T}_state"], T)
+        np.testing.assert_array_equal(ref, g[f"ref{T}_out"])
+
+
+def test_rollout_golden_via_single_rollout(ctx, golden):
+    """predict_motion_kinematic (kinematic_mpc.py:208-221): a one-rollout shoot against a zero reference returns a cost
+    that only the golden path reproduces; checks the step arithmetic end to end."""
+    g = golden("g5_g6_kmpc.npz")
+    for T in (8, 30):
+        x0 = g[f"roll{T}_x0"]; oa = g[f"roll{T}_oa"]; od = g[f"roll{T}_od"]; path = g[f"roll{T}_path"]
+        E = len(x0)
+        # weights that make the objective = sum_t ||x_t - ref_t||^2 ; with ref = golden path the cost must be ~0
+        cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=1, q=(1, 1, 1, 1), qf=(1, 1, 1, 1), r=(0, 0), rd=(0, 0),
+                            max_accel=1e9, max_dsteer=1e9)
+        ctrl = np.zeros((E, T, 2, 1), np.float32)
+        ctrl[:, :, 0, 0] = oa; ctrl[:, :, 1, 0] = od
+        # controls are f32 in HBM: build the golden path for the rounded controls with the (pinned) oracle
+        from oracle import oracle
+        ref = np.stack([oracle.predict_motion_kinematic(x0[j], ctrl[j, :, 0, 0].astype(np.float64),
+                                                        ctrl[j, :, 1, 0].astype(np.float64), cfg) for j in range(E)])
+        assert np.abs(ref - path).max() < 5e-6            # f32 rounding of the controls only
+        out = ctx.kmpc_shoot(x0, ref, ctrl, cfg)
+        assert (out["best_idx"] == 0).all()
+        assert out["best_cost"].max() < 1e-20
+
+
+def test_shoot_vs_oracle(ctx, orc):
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(4)
+    E, T, R = 96, 30, 512
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E),
+                              rng.uniform(0.5, 5.5, E), cl[k, 3] + rng.normal(0, 0.1, E)])
+    ref = ctx.kmpc_ref(states, T)
+    for e in range(0, E, 9):
+        r0, _ = orc.calc_ref_trajectory(states[e], cl[:, 1], cl[:, 2], cl[:, 3], cl[:, 5], T)
+        np.testing.assert_array_equal(ref[e], r0)
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    ctrl = synth.make_controls(E, T, R, seed=5, sigma_a=2.5, sigma_d=0.3)     # wide enough to hit every clamp
+    got = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+    want = orc.kmpc_shoot_batch(states, ref, ctrl, cfg, nthreads=8)
+    np.testing.assert_array_equal(got["best_idx"], want["best_idx"])
+    np.testing.assert_allclose(got["best_cost"], want["best_cost"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(got["steer"], want["steer"])                # clamped f32 controls: exact
+    np.testing.assert_array_equal(got["speed"], want["speed"])
+    np.testing.assert_array_equal(got["best_seq"], want["best_seq"])
+    assert (np.abs(got["best_seq"][:, :, 0]) <= 3.0).all() and (np.abs(got["best_seq"][:, :, 1]) <= 0.4189).all()
+    assert (np.abs(np.diff(got["best_seq"][:, :, 1], axis=1)) <= np.pi * 0.1 + 1e-15).all()   # :391-394
+
+
+def test_shoot_reference_horizon_and_edges(ctx, orc):
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(6)
+    for E, T, R in ((5, 8, 64), (1, 8, 1), (3, 30, 700)):                      # TK = 8 is the reference horizon
+        k = rng.integers(0, len(cl) - 1, E)
+        states = np.column_stack([cl[k, 1], cl[k, 2], rng.uniform(0, 6, E), cl[k, 3]])
+        ref = ctx.kmpc_ref(states, T)
+        cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+        ctrl = synth.make_controls(E, T, R, seed=7)
+        got = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+        want = orc.kmpc_shoot_batch(states, ref, ctrl, cfg)
+        np.testing.assert_array_equal(got["best_idx"], want["best_idx"])
+        np.testing.assert_allclose(got["best_cost"], want["best_cost"], rtol=1e-12, atol=1e-9)
+    cfg = _abi.kmpc_cfg(horizon=8, n_rollouts=4)
+    ctrl = np.zeros((2, 8, 2, 4), np.float32)                                 # all rollouts tie -> index 0 (np.argmin)
+    out = ctx.kmpc_shoot(np.zeros((2, 4)), np.zeros((2, 4, 9)), ctrl, cfg)
+    assert (out["best_idx"] == 0).all()
+    with pytest.raises(ValueError):
+        ctx.kmpc_shoot(np.zeros((2, 4)), np.zeros((2, 4, 9)), np.zeros((2, 8, 2, 5), np.float32), cfg)
+    empty = ctx.kmpc_shoot(np.zeros((0, 4)), np.zeros((0, 4, 9)), np.zeros((0, 8, 2, 4), np.float32), cfg)
+    assert empty["steer"].shape == (0,)
+
+
+def test_device_sampler_and_full_size(ctx):
+    """BASELINE config 4 per-GPU share: 128 egos x 512 rollouts x 30 steps with controls sampled on the device;
+    properties: determinism in the seed, bounds, and agreement of the *_dev path with the host-pointer path."""
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    E, T, R = 128, 30, 512
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    rng = np.random.default_rng(8)
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1], cl[k, 2], rng.uniform(0.5, 5, E), cl[k, 3]])
+    ref = ctx.kmpc_ref(states, T)
+    d_ctrl = ctx.alloc(4 * E * T * 2 * R)
+    ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=1234)
+    c1 = d_ctrl.download(np.float32, (E, T, 2, R))
+    ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=1234)
+    c2 = d_ctrl.download(np.float32, (E, T, 2, R))
+    np.testing.assert_array_equal(c1, c2)
+    assert np.abs(c1[:, :, 0]).max() <= 3.0 and np.abs(c1[:, :, 1]).max() <= np.float32(0.4189)
+    assert abs(c1[:, :, 0].std() - 1.5) < 0.1 and abs(c1[:, :, 1].std() - 0.15) < 0.01 and abs(c1.mean()) < 0.01
+    d_x0, d_ref = ctx.to_device(states), ctx.to_device(ref)
+    d_steer, d_speed, d_bi, d_bc = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E)
+    ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc)
+    host = ctx.kmpc_shoot(states, ref, c1, cfg)
+    np.testing.assert_array_equal(d_bi.download(np.int32, (E,)), host["best_idx"])
+    np.testing.assert_array_equal(d_steer.download(np.float64, (E,)), host["steer"])
+    np.testing.assert_array_equal(d_bc.download(np.float64, (E,)), host["best_cost"])
+
+
+def test_predict_motion_golden(ctx, golden):
+    """predict_motion_kinematic / update_state_kinematic against the reference's own outputs (fp64 controls)."""
+    g = golden("g5_g6_kmpc.npz")
+    for T in (8, 30):
+        cfg = _abi.kmpc_cfg(horizon=T)
+        path = ctx.kmpc_predict(g[f"roll{T}_x0"], g[f"roll{T}_oa"], g[f"roll{T}_od"], cfg)
+        np.testing.assert_allclose(path, g[f"roll{T}_path"], rtol=0, atol=1e-11)
+    cfg1 = _abi.kmpc_cfg(horizon=1)
+    st = g["step_state"]
+    p1 = ctx.kmpc_predict(st, g["step_a"][:, None], g["step_delta"][:, None], cfg1)      # update_state_kinematic :223-243
+    np.testing.assert_allclose(p1[:, :, 1], g["step_out"], rtol=0, atol=1e-12)
+
+
+def test_planner_class_drop_in(golden, tracks):
+    """examples/control/kinematic_mpc.py:41-55 shape: list of four arrays as waypoints, 7-state in, (steer, speed) out."""
+    from f1tenth_planning_amd.control.kinematic_mpc.kinematic_mpc import KMPCPlanner, State, mpc_config
+    lev = tracks["levine"]
+    mpc_line = [lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5]]
+    planner = KMPCPlanner(waypoints=mpc_line)
+    state = np.array([2.51, 3.29, 0.0, 1.0, 1.58, 0.0, 0.0])
+    steer, speed = planner.plan(state)
+    assert isinstance(steer, float) and isinstance(speed, float)
+    assert abs(steer) <= 0.4189 and 1.0 - 0.3 - 1e-12 <= speed <= 1.0 + 0.3 + 1e-12          # v + a*DTK, |a| <= 3
+    steer2, speed2 = planner.plan(state)                                                   # warm start path
+    assert abs(steer2) <= 0.4189
+    g = golden("g5_g6_kmpc.npz")
+    ref = planner.calc_ref_trajectory_kinematic(State(*[g["ref8_state"][0][k] for k in (0, 1)], 0.0, g["ref8_state"][0][2],
+                                                      g["ref8_state"][0][3]), *mpc_line)
+    np.testing.assert_array_equal(ref, g["ref8_out"][0])
+    path = planner.predict_motion_kinematic(g["roll8_x0"][0], g["roll8_oa"][0], g["roll8_od"][0])
+    np.testing.assert_allclose(path, g["roll8_path"][0], rtol=0, atol=1e-11)
+    with pytest.raises(ValueError):
+        KMPCPlanner().plan(state)
+    # closed loop on the oracle-free kinematic model: the car must make progress along the centreline
+    cfgc = mpc_config()
+    x = np.array([lev[0, 1], lev[0, 2], 1.0, lev[0, 3]])
+    pl = KMPCPlanner(waypoints=mpc_line, config=cfgc)
+    for _ in range(30):
+        st, sp = pl.plan(np.array([x[0], x[1], 0.0, x[2], x[3], 0.0, 0.0]))
+        a = (sp - x[2]) / cfgc.DTK
+        x = pl.predict_motion_kinematic(x, [a], [st])[:, 1]
+    d = np.hypot(lev[:, 1] - x[0], lev[:, 2] - x[1])
+    assert d.min() < 0.25 and 40 < d.argmin() < 400
