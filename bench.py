@@ -32,7 +32,10 @@ from f1tenth_planning_amd import _abi, synth  # noqa: E402
 from f1tenth_planning_amd.runtime import Context  # noqa: E402  (loads libf1p.so before torch is imported)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64
+# fp64 vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s of FMA)
+FP64_VALU_PEAK_TLANES = 39.3
+# VALU wave-instructions per candidate of k_lattice, from the latest committed PMC profile (SQ_INSTS_VALU / candidates)
+VALU_INSTR_PER_CANDIDATE = {"value": 28770.0, "source": "profiles/r01_k_lattice_baseline_summary.md (SQ_INSTS_VALU 4.713e8 / 16384 waves)"}
 
 
 def algorithmic_bytes_lattice(E, C, S, n_wp, grid_w, grid_h, device_goals=True):
@@ -57,6 +60,7 @@ def main():
     ap.add_argument("--stations", type=int, default=50)
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-iters", type=int, default=30, help="host-boundary plan() calls for p50/p95 (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +112,18 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
 
+    # p50 / p95 latency of one plan() at the ctypes boundary: host poses in, host results out (H2D + kernel + D2H + sync)
+    lat = None
+    if args.latency_iters > 0:
+        ctx.lattice_plan(poses, cfg, want_traj=True)
+        ts = []
+        for _ in range(args.latency_iters):
+            t1 = time.perf_counter()
+            ctx.lattice_plan(poses, cfg, want_traj=True)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        lat = {"p50_ms": float(np.percentile(ts, 50)), "p95_ms": float(np.percentile(ts, 95)), "n": len(ts),
+               "includes": "H2D poses + kernel + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive)"}
+
     # parity gate that travels with every measurement: a seeded subset against the oracle (rank 0)
     steer = d_steer.download(np.float64, (E,))
     bidx = d_bidx.download(np.int32, (E,))
@@ -120,10 +136,7 @@ def main():
         kernel_ms = kernel_ms_total / args.steps
         abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0])
         achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9
-        # fp64 op-equivalents per candidate-step, counted from the kernel source (DESIGN.md "K3 work"):
-        #   station body ~40 + 4 sincos(~50 each) per interval, G1 fit ~4 Newton evaluations x 16 sincos per candidate
-        flop_per_step = 40 + 4 * 50 + (4 * 16 * 60) / S
-        valu_tflops = flop_per_step * E * C * S / (kernel_ms * 1e-3) / 1e12
+        valu_tlanes = VALU_INSTR_PER_CANDIDATE["value"] * E * C / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "candidate-trajectory-steps/sec per GPU; p50 plan() latency @4096 egos",
             "value": value, "unit": "candidate-trajectory-steps/s", "n_gpus": world, "steps": args.steps,
@@ -134,15 +147,16 @@ def main():
                        "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16),
                        "parallelism": f"egos sharded over {world} GPU(s), no collective"},
             "per_gpu_value": value / world,
-            "p50_plan_latency_ms": elapsed / args.steps * 1e3,
+            "plan_latency_host_boundary": lat,
+            "pcie_inclusive_value": (float(E) * C * S / (lat["p50_ms"] * 1e-3)) if lat else None,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_lattice",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_candidate_step": abytes / (E * C * S),
                          "note": "fused kernel is fp64-VALU/transcendental bound by construction; HBM fraction is tiny",
-                         "valu_fp64": {"achieved_tflops_equiv": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
-                                       "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
-                                       "op_equivalents_per_step": flop_per_step}},
+                         "valu_fp64": {"achieved": valu_tlanes, "peak": FP64_VALU_PEAK_TLANES, "unit": "T lane-instr/s",
+                                       "frac": valu_tlanes / FP64_VALU_PEAK_TLANES,
+                                       "valu_instr_per_candidate": VALU_INSTR_PER_CANDIDATE}},
             "blocked_egos": int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
         if not args.no_cpu_baseline:
