@@ -21,7 +21,7 @@ __device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, c
     if (delta >= c.max_steer) delta = c.max_steer;             // :226-229
     else if (delta <= -c.max_steer) delta = -c.max_steer;
     double sn, cs;
-    sincos(s.yaw, &sn, &cs);
+    sincos_fast(s.yaw, &sn, &cs);
     const double x = s.x + s.v * cs * c.dt;                    // :231
     const double y = s.y + s.v * sn * c.dt;                    // :232
     const double yaw = s.yaw + (s.v / c.wheelbase) * tan(delta) * c.dt;   // :233-235

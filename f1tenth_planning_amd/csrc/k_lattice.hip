@@ -18,6 +18,15 @@
 // ~0.14 B per candidate-step and is reported as such.
 #include "f1p_internal.h"
 
+// tuning knobs (A/B-tested on the MI355X, see profiles/): unroll of the 16-node quadrature loop and the
+// occupancy the register allocator is asked for (waves per SIMD)
+#ifndef F1P_K3_UNROLL
+#define F1P_K3_UNROLL 1
+#endif
+#ifndef F1P_K3_WAVES
+#define F1P_K3_WAVES 2
+#endif
+
 namespace f1p {
 
 // Gauss-Legendre nodes / weights on [0, 1]
@@ -50,12 +59,12 @@ __device__ __forceinline__ Moments fresnel_moments(double a, double b, double c)
     const double h = 1.0 / (double)panels;
     for (int p = 0; p < panels; ++p) {
         const double t0 = (double)p * h;
-#pragma unroll
+#pragma unroll F1P_K3_UNROLL
         for (int j = 0; j < 16; ++j) {
             const double tau = __builtin_fma(h, c_gl16_x[j], t0);
             const double ph = __builtin_fma(__builtin_fma(a, tau, b), tau, c);
             double sn, cs;
-            sincos(ph, &sn, &cs);
+            sincos_fast(ph, &sn, &cs);
             const double w = h * c_gl16_w[j];
             const double wc = w * cs;
             m.c0 += wc;
@@ -121,16 +130,16 @@ __device__ __forceinline__ void interval_increment(double k0, double dk, double 
         const double s0 = __builtin_fma((double)q, hs, s);
         double sn, cs, ix, iy;
         double u = __builtin_fma(hs, GL4_X0, s0);
-        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
         ix = GL4_W0 * cs; iy = GL4_W0 * sn;
         u = __builtin_fma(hs, GL4_X1, s0);
-        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
         ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
         u = __builtin_fma(hs, GL4_X2, s0);
-        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
         ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
         u = __builtin_fma(hs, GL4_X3, s0);
-        sincos(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
+        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
         ix = __builtin_fma(GL4_W0, cs, ix); iy = __builtin_fma(GL4_W0, sn, iy);
         ax = __builtin_fma(hs, ix, ax);
         ay = __builtin_fma(hs, iy, ay);
@@ -187,7 +196,7 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
+__global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
     double* red_d = reinterpret_cast<double*>(lds_raw);          // [4]
