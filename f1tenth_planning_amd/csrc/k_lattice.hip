@@ -24,7 +24,7 @@
 #define F1P_K3_UNROLL 1
 #endif
 #ifndef F1P_K3_WAVES
-#define F1P_K3_WAVES 2
+#define F1P_K3_WAVES 3
 #endif
 
 namespace f1p {
@@ -40,20 +40,32 @@ __constant__ double c_gl16_w[16] = {
     0.07479799440828838,  0.08457825969750131,  0.0913017075224618,   0.09472530522753429,
     0.09472530522753429,  0.0913017075224618,   0.08457825969750131,  0.07479799440828838,
     0.062314485627767015, 0.047579255841246296, 0.031126761969323853, 0.013576229705877019};
-#define GL4_X0 0.06943184420297371
-#define GL4_X1 0.33000947820757187
-#define GL4_X2 0.6699905217924281
-#define GL4_X3 0.9305681557970262
-#define GL4_W0 0.17392742256872684
-#define GL4_W1 0.3260725774312731
+// Series tables of the midpoint-frame interval integral (see interval_setup):
+// K_P[n][m] = (-1)^(n+m) 2 / ((2n)! (2m)! (2n+4m+1)),  K_Q[n][m] = (-1)^(n+m) 2 / ((2n)! (2m+1)! (2n+4m+3))
+__constant__ double c_k_p[6][4] = {
+    {2.0, -0.2, 0.009259259259259259, -0.00021367521367521368},
+    {-0.3333333333333333, 0.07142857142857142, -0.003787878787878788, 9.259259259259259e-05},
+    {0.016666666666666666, -0.004629629629629629, 0.0002670940170940171, -6.808278867102396e-06},
+    {-0.0003968253968253968, 0.00012626262626262626, -7.71604938271605e-06, 2.0305393112410655e-07},
+    {5.5114638447971785e-06, -1.907814407814408e-06, 1.2157640834111422e-07, -3.2806332409507015e-09},
+    {-5.010421677088344e-08, 1.8371546149323926e-08, -1.2086543519292057e-09, 3.328178650239842e-11}};
+__constant__ double c_k_q[6][4] = {
+    {0.6666666666666666, -0.047619047619047616, 0.0015151515151515152, -2.6455026455026456e-05},
+    {-0.2, 0.018518518518518517, -0.000641025641025641, 1.1671335200746965e-05},
+    {0.011904761904761904, -0.0012626262626262627, 4.6296296296296294e-05, -8.702311333890282e-07},
+    {-0.00030864197530864197, 3.561253561253561e-05, -1.3616557734204792e-06, 2.6245065927605612e-08},
+    {4.509379509379509e-06, -5.511463844797178e-07, 2.1755778334725704e-08, -4.2790868360226536e-10},
+    {-4.2395875729209064e-08, 5.4033959262717436e-09, -2.1870888273004676e-10, 4.374177654600935e-12}};
 
-struct Moments { double c0, s0, c1, c2; };
+// Moments of the G1 residual g(A) = int_0^1 sin(phi) dtau, phi = A tau^2 + (delta - A) tau + phi0, and of its
+// A-derivatives (d phi / dA = u = tau^2 - tau):  c0 = int cos, s0 = int sin = g, cu = int u cos = g',
+// su = int u sin = -d c0/dA, cuu = int u^2 cos = -d^2 c0/dA^2, suu = int u^2 sin = -g''.
+struct FitMoments { double c0, s0, cu, su, cuu, suu; };
 
-// c_k = int_0^1 tau^k cos(a tau^2 + b tau + c) dtau, s_0 likewise with sin.  16-point Gauss-Legendre per
-// panel is exact to 1e-14 while the phase excursion |a| + |b| per panel is <= 8 rad.
-__device__ __forceinline__ Moments fresnel_moments(double a, double b, double c) {
-    Moments m;
-    m.c0 = 0.0; m.s0 = 0.0; m.c1 = 0.0; m.c2 = 0.0;
+// 16-point Gauss-Legendre per panel: exact to 1e-14 while the phase excursion |a| + |b| per panel is <= 8 rad
+__device__ __forceinline__ FitMoments fit_moments(double a, double b, double c) {
+    FitMoments m;
+    m.c0 = 0.0; m.s0 = 0.0; m.cu = 0.0; m.su = 0.0; m.cuu = 0.0; m.suu = 0.0;
     int panels = (int)__builtin_ceil((fabs(a) + fabs(b)) * 0.125);
     panels = panels < 1 ? 1 : (panels > 1024 ? 1024 : panels);
     const double h = 1.0 / (double)panels;
@@ -66,11 +78,15 @@ __device__ __forceinline__ Moments fresnel_moments(double a, double b, double c)
             double sn, cs;
             sincos_fast(ph, &sn, &cs);
             const double w = h * c_gl16_w[j];
-            const double wc = w * cs;
+            const double u = __builtin_fma(tau, tau, -tau);
+            const double wc = w * cs, ws = w * sn;
+            const double wuc = wc * u, wus = ws * u;
             m.c0 += wc;
-            m.s0 = __builtin_fma(w, sn, m.s0);
-            m.c1 = __builtin_fma(wc, tau, m.c1);
-            m.c2 = __builtin_fma(wc * tau, tau, m.c2);
+            m.s0 += ws;
+            m.cu += wuc;
+            m.su += wus;
+            m.cuu = __builtin_fma(wuc, u, m.cuu);
+            m.suu = __builtin_fma(wus, u, m.suu);
         }
     }
     return m;
@@ -78,7 +94,10 @@ __device__ __forceinline__ Moments fresnel_moments(double a, double b, double c)
 
 struct Clothoid { double k0, dk, L; bool ok; };
 
-// G1 Hermite interpolation (0,0,0) -> (x1, y1, th1): Newton on A for int_0^1 sin(A t^2 + (delta-A) t + phi0) dt = 0
+// G1 Hermite interpolation (0,0,0) -> (x1, y1, th1) (Bertolazzi & Frego): solve g(A) = 0 from their polynomial
+// initial guess.  Halley steps (cubic) instead of Newton: the guess is within ~0.02 of the root, so two
+// quadrature passes normally suffice -- when the second step is tiny its cubic remainder is below 1e-14 and c0
+// at the root follows from its Taylor expansion (su, cuu are the A-derivatives of c0) without a third pass.
 __device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     Clothoid cl;
     cl.k0 = 0.0; cl.dk = 0.0; cl.L = 0.0; cl.ok = false;
@@ -93,23 +112,30 @@ __device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     double A = (phi0 + phi1) * (2.989696028701907 + xy * (0.716228953608281 + xy * -0.458969738821509) +
                                 (-0.502821153340377 + xy * 0.261062141752652) * (X2 + Y2) +
                                 -0.045854475238709 * (X2 * X2 + Y2 * Y2));
-    Moments m;
+    double c0 = 0.0;
     bool ok = false;
     for (int it = 0; it < 20; ++it) {
-        m = fresnel_moments(A, delta - A, phi0);
-        const double g = m.s0;
-        const double dg = m.c2 - m.c1;
-        if (fabs(g) <= 1e-13) { ok = true; break; }
-        if (dg == 0.0 || !isfinite(dg)) break;
-        A -= g / dg;
+        const FitMoments m = fit_moments(A, delta - A, phi0);
+        const double g = m.s0, g1 = m.cu, g2 = -m.suu;
+        if (fabs(g) <= 1e-13) { ok = true; c0 = m.c0; break; }
+        if (g1 == 0.0 || !isfinite(g1)) break;
+        const double den = 2.0 * g1 * g1 - g * g2;
+        double step = -2.0 * g * g1 / den;                        // Halley
+        if (!isfinite(step) || !(fabs(den) > 1e-300)) step = -g / g1;   // Newton fallback
+        A += step;
         if (!isfinite(A)) break;
+        if (fabs(step) <= 1e-4 && fabs(g1) >= 0.02) {             // cubic remainder < 1e-14: finish without another pass
+            c0 = m.c0 - step * m.su - 0.5 * step * step * m.cuu;
+            ok = true;
+            break;
+        }
     }
     if (!ok) {
-        m = fresnel_moments(A, delta - A, phi0);
-        if (fabs(m.s0) <= 1e-10) ok = true;
+        const FitMoments m = fit_moments(A, delta - A, phi0);
+        if (fabs(m.s0) <= 1e-10) { ok = true; c0 = m.c0; }
     }
     if (!ok) return cl;
-    const double L = r / m.c0;
+    const double L = r / c0;
     if (!(L > 0.0) || !isfinite(L)) return cl;
     cl.L = L;
     cl.k0 = (delta - A) / L;
@@ -118,40 +144,60 @@ __device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     return cl;
 }
 
-// (dx, dy) = int_s^{s+ds} (cos, sin)(theta(u)) du with theta(u) = u (k0 + u dk / 2).
-// 4-point Gauss-Legendre per sub-interval; `nsub` keeps the heading change per sub-interval below 0.35 rad
-// (error < 1e-13 ds).  Depends only on (k0, dk, s, ds, nsub): the winner re-emission reproduces the
-// evaluation loop bit for bit.
-__device__ __forceinline__ void interval_increment(double k0, double dk, double s, double ds, int nsub, double& dx,
-                                                   double& dy) {
-    const double hs = ds / (double)nsub;
-    double ax = 0.0, ay = 0.0;
-    for (int q = 0; q < nsub; ++q) {
-        const double s0 = __builtin_fma((double)q, hs, s);
-        double sn, cs, ix, iy;
-        double u = __builtin_fma(hs, GL4_X0, s0);
-        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
-        ix = GL4_W0 * cs; iy = GL4_W0 * sn;
-        u = __builtin_fma(hs, GL4_X1, s0);
-        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
-        ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
-        u = __builtin_fma(hs, GL4_X2, s0);
-        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
-        ix = __builtin_fma(GL4_W1, cs, ix); iy = __builtin_fma(GL4_W1, sn, iy);
-        u = __builtin_fma(hs, GL4_X3, s0);
-        sincos_fast(u * __builtin_fma(0.5 * dk, u, k0), &sn, &cs);
-        ix = __builtin_fma(GL4_W0, cs, ix); iy = __builtin_fma(GL4_W0, sn, iy);
-        ax = __builtin_fma(hs, ix, ax);
-        ay = __builtin_fma(hs, iy, ay);
+// ---------------------------------------------------------------------------------------------------
+// Station-to-station integral  (dx, dy) = int_s^{s+ds} (cos, sin)(theta(u)) du,  theta(u) = u (k0 + u dk / 2).
+// Each interval is cut into nsub pieces of length hs; in the frame of a piece's midpoint (heading theta_m,
+// curvature kappa_m) the phase is a t + b t^2 on t in [-1, 1] with a = kappa_m hs/2 and b = dk hs^2/8, and
+//     int_{-1}^{1} exp(j (a t + b t^2)) dt = P(a^2) + j Q(a^2)
+// (the odd parts cancel).  b is the same for every piece of a candidate, so the Taylor coefficients of P and Q
+// in a^2 are computed ONCE per candidate (interval_setup); a piece then costs one sincos of theta_m and two
+// degree-5 Horner polynomials instead of four sincos of a 4-point quadrature.  nsub keeps |a| <= 0.25 and
+// |b| <= 0.02, where the truncated series (6 terms in a^2, 4 in b^2) are exact to < 1e-15.
+// The result depends only on (clothoid, s): the winner re-emission reproduces the evaluation loop bit for bit.
+// ---------------------------------------------------------------------------------------------------
+struct IntervalCoef { double p[6], q[6]; double hs; int nsub; };
+
+__device__ __forceinline__ IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
+    IntervalCoef ic;
+    const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
+    const double n1 = __builtin_ceil(kmax * ds * 2.0);                    // |a| = |kappa_m| hs / 2 <= 0.25
+    const double n2 = __builtin_ceil(ds * __builtin_sqrt(fabs(dk) * 6.25));   // |b| = |dk| hs^2 / 8 <= 0.02
+    double nn = fmax(1.0, fmax(n1, n2));
+    nn = nn <= 4096.0 ? nn : 4096.0;                                      // also catches NaN
+    ic.nsub = (int)nn;
+    ic.hs = ds / nn;
+    const double h = 0.5 * ic.hs;
+    const double b = 0.5 * dk * h * h;
+    const double b2 = b * b;
+    const double hb = h * b;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        ic.p[n] = h * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_p[n][3], c_k_p[n][2]), c_k_p[n][1]), c_k_p[n][0]);
+        ic.q[n] = hb * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_q[n][3], c_k_q[n][2]), c_k_q[n][1]), c_k_q[n][0]);
     }
-    dx = ax; dy = ay;
+    return ic;
 }
 
-__device__ __forceinline__ int clothoid_nsub(double k0, double dk, double L, double ds) {
-    const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
-    const double turn = kmax * ds;
-    int nsub = (int)__builtin_ceil(turn * (1.0 / 0.35));
-    return nsub < 1 ? 1 : (nsub > 4096 ? 4096 : nsub);
+__device__ __forceinline__ void interval_increment(double k0, double dk, double s, const IntervalCoef& ic, double& dx,
+                                                   double& dy) {
+    double ax = 0.0, ay = 0.0;
+    const double h = 0.5 * ic.hs;
+    for (int q = 0; q < ic.nsub; ++q) {
+        const double sm = __builtin_fma((double)q + 0.5, ic.hs, s);       // midpoint of the piece
+        const double a = __builtin_fma(dk, sm, k0) * h;
+        const double z = a * a;
+        double P = __builtin_fma(z, ic.p[5], ic.p[4]);
+        double Q = __builtin_fma(z, ic.q[5], ic.q[4]);
+        P = __builtin_fma(z, P, ic.p[3]); Q = __builtin_fma(z, Q, ic.q[3]);
+        P = __builtin_fma(z, P, ic.p[2]); Q = __builtin_fma(z, Q, ic.q[2]);
+        P = __builtin_fma(z, P, ic.p[1]); Q = __builtin_fma(z, Q, ic.q[1]);
+        P = __builtin_fma(z, P, ic.p[0]); Q = __builtin_fma(z, Q, ic.q[0]);
+        double sn, cs;
+        sincos_fast(sm * __builtin_fma(0.5 * dk, sm, k0), &sn, &cs);
+        ax += __builtin_fma(cs, P, -(sn * Q));
+        ay += __builtin_fma(sn, P, cs * Q);
+    }
+    dx = ax; dy = ay;
 }
 
 struct LatticeArgs {
@@ -282,7 +328,7 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
             double* trow = a.all_traj ? a.all_traj + ((size_t)e * C + c) * (size_t)S * 4 : nullptr;
             if (cl.ok) {
                 const double ds = cl.L / (double)den;
-                const int nsub = clothoid_nsub(cl.k0, cl.dk, cl.L, ds);
+                const IntervalCoef ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
                 double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
                 bool hit = false;
                 for (int i = 0; i < S; ++i) {
@@ -314,7 +360,7 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                     }
                     if (i + 1 < S) {
                         double dx, dy;
-                        interval_increment(cl.k0, cl.dk, s, ds, nsub, dx, dy);
+                        interval_increment(cl.k0, cl.dk, s, ic, dx, dy);
                         x += dx; y += dy;
                     }
                 }
@@ -354,10 +400,11 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
             cl = g1_fit(gx, gy, gth);
     }
     const double ds = cl.ok ? cl.L / (double)den : 0.0;
-    const int nsub = cl.ok ? clothoid_nsub(cl.k0, cl.dk, cl.L, ds) : 1;
+    IntervalCoef ic;
+    if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
     for (int i = lane; i < S - 1; i += 64) {
         double dx = 0.0, dy = 0.0;
-        if (cl.ok) interval_increment(cl.k0, cl.dk, (double)i * ds, ds, nsub, dx, dy);
+        if (cl.ok) interval_increment(cl.k0, cl.dk, (double)i * ds, ic, dx, dy);
         inc_x[i] = dx; inc_y[i] = dy;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
