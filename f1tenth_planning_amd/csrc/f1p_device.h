@@ -217,7 +217,10 @@ __device__ __forceinline__ Intersect wave_intersect(double px, double py, double
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void get_actuation(double pose_theta, double lx, double ly, double lspeed, double px, double py,
                                               double lookahead, double wheelbase, double& speed, double& steer) {
-    const double wy = dot2(sin(-pose_theta), cos(-pose_theta), lx - px, ly - py);  // :155
+    // sin(-0.0) = -0.0 and cos(-0.0) = 1.0 exactly: the lattice tracker always runs from the ego-frame origin
+    const double sn = pose_theta == 0.0 ? -pose_theta : sin(-pose_theta);
+    const double cs = pose_theta == 0.0 ? 1.0 : cos(-pose_theta);
+    const double wy = dot2(sn, cs, lx - px, ly - py);                              // :155
     speed = lspeed;                                                                // :156
     if (fabs(wy) < 1e-6) { steer = 0.0; return; }                                  // :157
     const double radius = 1 / (2.0 * wy / (lookahead * lookahead));                // :159

@@ -23,6 +23,11 @@
 #ifndef F1P_K3_UNROLL
 #define F1P_K3_UNROLL 1
 #endif
+// ablation switches for profiling only (results are wrong when set): 1 = no station integrals, 2 = no occupancy test,
+// 4 = no G1 fit (straight-line clothoid), 8 = no winner re-emission / tracking
+#ifndef F1P_K3_ABLATE
+#define F1P_K3_ABLATE 0
+#endif
 #ifndef F1P_K3_WAVES
 #define F1P_K3_WAVES 3
 #endif
@@ -92,6 +97,17 @@ __device__ __forceinline__ FitMoments fit_moments(double a, double b, double c) 
     return m;
 }
 
+// remainder(x, 2 pi) for the moderate angles of this path: n = rint(x / 2pi) and ONE fma give the exactly representable
+// IEEE remainder x - n * fl(2 pi); a mis-rounded n at the +-pi seam is corrected, huge / non-finite x take the library path.
+__device__ __forceinline__ double remainder_2pi(double x) {
+    if (!(fabs(x) <= 1.0e6)) return remainder(x, 2.0 * F1P_PI);
+    const double n = __builtin_rint(x * 0.15915494309189534561);
+    double r = __builtin_fma(-n, 2.0 * F1P_PI, x);
+    if (r > F1P_PI) r -= 2.0 * F1P_PI;
+    else if (r < -F1P_PI) r += 2.0 * F1P_PI;
+    return r;
+}
+
 struct Clothoid { double k0, dk, L; bool ok; };
 
 // G1 Hermite interpolation (0,0,0) -> (x1, y1, th1) (Bertolazzi & Frego): solve g(A) = 0 from their polynomial
@@ -104,8 +120,8 @@ __device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     const double r = hypot(x1, y1);
     if (!(r > 1e-12) || !isfinite(r) || !isfinite(th1)) return cl;
     const double phi = atan2(y1, x1);
-    const double phi0 = remainder(0.0 - phi, 2.0 * F1P_PI);
-    const double phi1 = remainder(th1 - phi, 2.0 * F1P_PI);
+    const double phi0 = remainder_2pi(0.0 - phi);
+    const double phi1 = remainder_2pi(th1 - phi);
     const double delta = phi1 - phi0;
     const double X = phi0 / F1P_PI, Y = phi1 / F1P_PI;
     const double xy = X * Y, X2 = X * X, Y2 = Y * Y;
@@ -233,12 +249,14 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
     if (!cen_ok[l]) { gx = 0.0; gy = 0.0; gth = 0.0; return false; }
     const double psi = cen_psi[l];
     const double w = cfg.width[k];
-    const double mx = cen_x[l] + w * (-sin(psi));
-    const double my = cen_y[l] + w * cos(psi);
+    double sp, cp;
+    sincos_fast(psi, &sp, &cp);
+    const double mx = cen_x[l] + w * (-sp);
+    const double my = cen_y[l] + w * cp;
     const double dx = mx - px, dy = my - py;
     gx = ct * dx + st * dy;
     gy = -st * dx + ct * dy;
-    gth = remainder(psi - theta, 2.0 * F1P_PI);
+    gth = remainder_2pi(psi - theta);
     return true;
 }
 
@@ -254,7 +272,8 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     double* tr_y = tr_x + S;                                     // [S]
     double* inc_x = tr_y + S;                                    // [S]
     double* inc_y = inc_x + S;                                   // [S]
-    int* red_i = reinterpret_cast<int*>(inc_y + S);              // [4]
+    double* win = inc_y + S;                                     // [4] winner clothoid (k0, dk, L, ok)
+    int* red_i = reinterpret_cast<int*>(win + 4);                // [4]
     int* cen_ok = red_i + 4;                                     // [64]
     uint32_t* tile = reinterpret_cast<uint32_t*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [tile_rows][tile_words]
 
@@ -309,6 +328,11 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     double sn_t, cs_t;
     sincos(theta, &sn_t, &cs_t);
     const double ct = cs_t, st = sn_t;
+    // station (x, y) in the ego frame -> fractional cell coordinates relative to the LDS tile, two fma per axis:
+    //   cell_x = ((px + ct x - st y) - ox) / res  folded into  tx0 + txx x + txy y   (likewise y)
+    const double txx = ct * a.grid.inv_res, txy = -st * a.grid.inv_res, tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
+    const double tyx = st * a.grid.inv_res, tyy = ct * a.grid.inv_res, ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+    const double tile_w = (double)(a.tile_words * 32), tile_h = (double)a.tile_rows;
     const int den = S - 1 > 1 ? S - 1 : 1;
     const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
     const int sim_m = S - cfg.n_shift - cfg.n_cull;
@@ -318,12 +342,17 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
         // ---- 4. candidates: fit, sample, check, cost -------------------------------------------------
         const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
         bc = __builtin_huge_val(); bi = 0x7fffffff;
+        double my_k0 = 0.0, my_dk = 0.0, my_L = 0.0;      // clothoid of this thread's best candidate
+        bool my_ok = false;
         for (int c = c0 + tid; c < c1; c += blockDim.x) {
             double gx, gy, gth;
             const bool gok = candidate_goal(a, cfg, e, c, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
             Clothoid cl;
             cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
-            if (gok) cl = g1_fit(gx, gy, gth);
+            if (gok) {
+                if (F1P_K3_ABLATE & 4) { cl.ok = true; cl.k0 = 0.01 * gth; cl.dk = 0.01 * gy; cl.L = fabs(gx) + 1.0; }
+                else cl = g1_fit(gx, gy, gth);
+            }
             double cost = __builtin_huge_val();
             double* trow = a.all_traj ? a.all_traj + ((size_t)e * C + c) * (size_t)S * 4 : nullptr;
             if (cl.ok) {
@@ -338,19 +367,19 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                     if (ak > maxk) maxk = ak;
                     sumk += ak;
                     if (prev && i < sim_m) { const double d = th - prev[i + cfg.n_shift]; sim += d * d; }
-                    if (collide_on) {
-                        const double xm = px + (ct * x - st * y);
-                        const double ym = py + (st * x + ct * y);
-                        int cgx, cgy;
-                        bool occ = true;
-                        if (cell_of(a.grid, xm, ym, cgx, cgy)) {
-                            const int lx = cgx - tile_gx0, ly = cgy - tile_gy0;
-                            uint32_t wv_;
-                            if ((lx >= 0) & (ly >= 0) & (lx < a.tile_words * 32) & (ly < a.tile_rows))
-                                wv_ = tile[ly * a.tile_words + (lx >> 5)];
-                            else
-                                wv_ = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
-                            occ = (wv_ >> (cgx & 31)) & 1u;
+                    if (collide_on && !(F1P_K3_ABLATE & 2)) {
+                        const double lxf = __builtin_floor(__builtin_fma(txx, x, __builtin_fma(txy, y, tx0)));
+                        const double lyf = __builtin_floor(__builtin_fma(tyx, x, __builtin_fma(tyy, y, ty0)));
+                        bool occ = true;                                  // NaN / off-map: occupied
+                        if ((lxf >= 0.0) & (lxf < tile_w) & (lyf >= 0.0) & (lyf < tile_h)) {
+                            const int lx = (int)lxf, ly = (int)lyf;       // inside the LDS tile (off-map words are all ones)
+                            occ = (tile[ly * a.tile_words + (lx >> 5)] >> (lx & 31)) & 1u;
+                        } else {
+                            const double gxf = lxf + (double)tile_gx0, gyf = lyf + (double)tile_gy0;
+                            if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
+                                const int cgx = (int)gxf, cgy = (int)gyf;
+                                occ = (a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)] >> (cgx & 31)) & 1u;
+                            }
                         }
                         hit |= occ;
                     }
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                         reinterpret_cast<double2*>(trow)[2 * i] = make_double2(x, y);
                         reinterpret_cast<double2*>(trow)[2 * i + 1] = make_double2(th, ak);
                     }
-                    if (i + 1 < S) {
+                    if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
                         double dx, dy;
                         interval_increment(cl.k0, cl.dk, s, ic, dx, dy);
                         x += dx; y += dy;
@@ -374,16 +403,21 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                 for (int i = 0; i < 2 * S; ++i) reinterpret_cast<double2*>(trow)[i] = make_double2(0.0, 0.0);
             }
             if (a.all_cost) a.all_cost[(size_t)e * C + c] = cost;
-            if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; }
+            if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; my_k0 = cl.k0; my_dk = cl.dk; my_L = cl.L; my_ok = cl.ok; }
         }
         // ---- 5. select(): argmin, first minimum wins ----------------------------------------------------
+        const int my_bi = bi;
         block_argmin(bc, bi, red_d, red_i);
+        if (my_bi == bi && bi != 0x7fffffff) {            // the owner of the winner hands its clothoid to wave 0
+            win[0] = my_k0; win[1] = my_dk; win[2] = my_L; win[3] = my_ok ? 1.0 : 0.0;
+        }
         if (tid == 0) {
             if (a.best_idx) a.best_idx[e] = bi;
             if (a.best_cost) a.best_cost[e] = bc;
             if (a.near_idx) a.near_idx[e] = ni;
         }
         if (a.mode == LATTICE_EVAL) return;
+        __syncthreads();
     } else {
         bi = a.emit_idx[e];
         bc = a.emit_cost ? a.emit_cost[e] : 0.0;
@@ -391,10 +425,12 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     }
 
     // ---- 6. re-emit the winner: every interval is independent -> one lane per interval -----------------
-    if (wave != 0) return;
+    if (wave != 0 || (F1P_K3_ABLATE & 8)) return;
     Clothoid cl;
     cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
-    if (bi >= 0 && bi < C) {
+    if (a.mode != LATTICE_EMIT) {
+        if (bi != 0x7fffffff) { cl.k0 = win[0]; cl.dk = win[1]; cl.L = win[2]; cl.ok = win[3] != 0.0; }
+    } else if (bi >= 0 && bi < C) {
         double gx, gy, gth;
         if (candidate_goal(a, cfg, e, bi, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth))
             cl = g1_fit(gx, gy, gth);
@@ -486,7 +522,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
         a.tile_words = (2 * half + 31) / 32 + 1;
     }
     const int S = cfg->n_stations;
-    size_t lds = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
+    size_t lds = sizeof(double) * (8 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
                  sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
     lds = (lds + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_lattice, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
