@@ -75,8 +75,13 @@ __device__ __forceinline__ double dot2(double a0, double a1, double b0, double b
 // |x| <= 1e5; larger or non-finite arguments take the device library's full-range path.
 // ~30 fp64 instructions instead of the ~100 of the full-range sincos: this is the hot instruction of K3.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_core(double x, double* sn, double* cs);
 __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
     if (!(fabs(x) <= 1.0e5)) { sincos(x, sn, cs); return; }
+    sincos_core(x, sn, cs);
+}
+// the reduction + kernels without the range guard: callers bound |x| themselves (garbage, never a trap, beyond 1e5)
+__device__ __forceinline__ void sincos_core(double x, double* sn, double* cs) {
     const double k = __builtin_rint(x * 0.63661977236758134308);          // x * 2/pi
     double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);          // pi/2 high part
     r = __builtin_fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 low part

@@ -81,7 +81,7 @@ __device__ __forceinline__ FitMoments fit_moments(double a, double b, double c) 
             const double tau = __builtin_fma(h, c_gl16_x[j], t0);
             const double ph = __builtin_fma(__builtin_fma(a, tau, b), tau, c);
             double sn, cs;
-            sincos_fast(ph, &sn, &cs);
+            sincos_core(ph, &sn, &cs);                     // |ph| <= |a| + |b| + |c|; a runaway Newton iterate fails the isfinite tests
             const double w = h * c_gl16_w[j];
             const double u = __builtin_fma(tau, tau, -tau);
             const double wc = w * cs, ws = w * sn;
@@ -114,7 +114,7 @@ struct Clothoid { double k0, dk, L; bool ok; };
 // initial guess.  Halley steps (cubic) instead of Newton: the guess is within ~0.02 of the root, so two
 // quadrature passes normally suffice -- when the second step is tiny its cubic remainder is below 1e-14 and c0
 // at the root follows from its Taylor expansion (su, cuu are the A-derivatives of c0) without a third pass.
-__device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
+__device__ __noinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     Clothoid cl;
     cl.k0 = 0.0; cl.dk = 0.0; cl.L = 0.0; cl.ok = false;
     const double r = hypot(x1, y1);
@@ -173,7 +173,7 @@ __device__ __forceinline__ Clothoid g1_fit(double x1, double y1, double th1) {
 // ---------------------------------------------------------------------------------------------------
 struct IntervalCoef { double p[6], q[6]; double hs; int nsub; };
 
-__device__ __forceinline__ IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
+__device__ __noinline__ IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
     IntervalCoef ic;
     const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
     const double n1 = __builtin_ceil(kmax * ds * 2.0);                    // |a| = |kappa_m| hs / 2 <= 0.25
@@ -209,7 +209,7 @@ __device__ __forceinline__ void interval_increment(double k0, double dk, double 
         P = __builtin_fma(z, P, ic.p[1]); Q = __builtin_fma(z, Q, ic.q[1]);
         P = __builtin_fma(z, P, ic.p[0]); Q = __builtin_fma(z, Q, ic.q[0]);
         double sn, cs;
-        sincos_fast(sm * __builtin_fma(0.5 * dk, sm, k0), &sn, &cs);
+        sincos_core(sm * __builtin_fma(0.5 * dk, sm, k0), &sn, &cs);   // |theta| is a few turns at most on a fitted clothoid
         ax += __builtin_fma(cs, P, -(sn * Q));
         ay += __builtin_fma(sn, P, cs * Q);
     }
