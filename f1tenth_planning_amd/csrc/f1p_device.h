@@ -80,23 +80,35 @@ __device__ __forceinline__ void sincos_fast(double x, double* sn, double* cs) {
     if (!(fabs(x) <= 1.0e5)) { sincos(x, sn, cs); return; }
     sincos_core(x, sn, cs);
 }
-// the reduction + kernels without the range guard: callers bound |x| themselves (garbage, never a trap, beyond 1e5)
+// the reduction + kernels without the range guard: callers bound |x| themselves (garbage, never a trap, beyond 1e5).
+// The coefficients live in constant memory on purpose: a uniform s_load puts each one in an SGPR pair that v_fma_f64
+// reads directly, whereas a literal has to be moved into a VGPR pair by a VALU instruction before every use
+// (measured: 19 v_mov_b64 per quadrature node) -- and VALU issue is what bounds K3.
+__constant__ double c_sc[15] = {
+    0.63661977236758134308,      // 2/pi
+    1.57079632679489655800e+00,  // pi/2 high
+    6.12323399573676603587e-17,  // pi/2 low
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,   // S1..S6
+    2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,    // C1..C6
+    -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+
 __device__ __forceinline__ void sincos_core(double x, double* sn, double* cs) {
-    const double k = __builtin_rint(x * 0.63661977236758134308);          // x * 2/pi
-    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);          // pi/2 high part
-    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 low part
+    const double k = __builtin_rint(x * c_sc[0]);
+    double r = __builtin_fma(-k, c_sc[1], x);
+    r = __builtin_fma(-k, c_sc[2], r);
     const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(z, c_sc[8], c_sc[7]);
+    ps = __builtin_fma(z, ps, c_sc[6]);
+    ps = __builtin_fma(z, ps, c_sc[5]);
+    ps = __builtin_fma(z, ps, c_sc[4]);
+    ps = __builtin_fma(z, ps, c_sc[3]);
     const double s = __builtin_fma(z * r, ps, r);                         // r + r^3 S(z)
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(z, c_sc[14], c_sc[13]);
+    pc = __builtin_fma(z, pc, c_sc[12]);
+    pc = __builtin_fma(z, pc, c_sc[11]);
+    pc = __builtin_fma(z, pc, c_sc[10]);
+    pc = __builtin_fma(z, pc, c_sc[9]);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double c = w + (((1.0 - w) - hz) + z * z * pc);                 // 1 - z/2 + z^2 C(z), compensated
