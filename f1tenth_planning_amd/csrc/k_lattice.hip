@@ -62,15 +62,17 @@ __constant__ double c_k_q[6][4] = {
     {4.509379509379509e-06, -5.511463844797178e-07, 2.1755778334725704e-08, -4.2790868360226536e-10},
     {-4.2395875729209064e-08, 5.4033959262717436e-09, -2.1870888273004676e-10, 4.374177654600935e-12}};
 
-// Moments of the G1 residual g(A) = int_0^1 sin(phi) dtau, phi = A tau^2 + (delta - A) tau + phi0, and of its
-// A-derivatives (d phi / dA = u = tau^2 - tau):  c0 = int cos, s0 = int sin = g, cu = int u cos = g',
-// su = int u sin = -d c0/dA, cuu = int u^2 cos = -d^2 c0/dA^2, suu = int u^2 sin = -g''.
-struct FitMoments { double c0, s0, cu, su, cuu, suu; };
+// Moments of the G1 residual g(A) = int_0^1 sin(phi) dtau, phi = A tau^2 + (delta - A) tau + phi0.  Since
+// d phi / dA = u = tau^2 - tau, every A-derivative of g and of c0 = int cos(phi) is a moment of u^k cos / sin:
+//   c[k] = int u^k cos(phi),  s[k] = int u^k sin(phi),  k = 0..5
+//   g = s0, dg = c1, d2g = -s2, d3g = -c3, d4g = s4, d5g = c5;   dc0 = -s1, d2c0 = -c2, d3c0 = s3, d4c0 = c4, d5c0 = -s5.
+struct FitMoments { double c[6], s[6]; };
 
 // 16-point Gauss-Legendre per panel: exact to 1e-14 while the phase excursion |a| + |b| per panel is <= 8 rad
 __device__ __forceinline__ FitMoments fit_moments(double a, double b, double c) {
     FitMoments m;
-    m.c0 = 0.0; m.s0 = 0.0; m.cu = 0.0; m.su = 0.0; m.cuu = 0.0; m.suu = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { m.c[k] = 0.0; m.s[k] = 0.0; }
     int panels = (int)__builtin_ceil((fabs(a) + fabs(b)) * 0.125);
     panels = panels < 1 ? 1 : (panels > 1024 ? 1024 : panels);
     const double h = 1.0 / (double)panels;
@@ -81,17 +83,16 @@ __device__ __forceinline__ FitMoments fit_moments(double a, double b, double c) 
             const double tau = __builtin_fma(h, c_gl16_x[j], t0);
             const double ph = __builtin_fma(__builtin_fma(a, tau, b), tau, c);
             double sn, cs;
-            sincos_core(ph, &sn, &cs);                     // |ph| <= |a| + |b| + |c|; a runaway Newton iterate fails the isfinite tests
+            sincos_core(ph, &sn, &cs);                     // |ph| <= |a| + |b| + |c|; a runaway iterate fails the isfinite tests
             const double w = h * c_gl16_w[j];
             const double u = __builtin_fma(tau, tau, -tau);
-            const double wc = w * cs, ws = w * sn;
-            const double wuc = wc * u, wus = ws * u;
-            m.c0 += wc;
-            m.s0 += ws;
-            m.cu += wuc;
-            m.su += wus;
-            m.cuu = __builtin_fma(wuc, u, m.cuu);
-            m.suu = __builtin_fma(wus, u, m.suu);
+            double wc = w * cs, ws = w * sn;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                m.c[k] += wc;
+                m.s[k] += ws;
+                if (k < 5) { wc *= u; ws *= u; }
+            }
         }
     }
     return m;
@@ -111,9 +112,10 @@ __device__ __forceinline__ double remainder_2pi(double x) {
 struct Clothoid { double k0, dk, L; bool ok; };
 
 // G1 Hermite interpolation (0,0,0) -> (x1, y1, th1) (Bertolazzi & Frego): solve g(A) = 0 from their polynomial
-// initial guess.  Halley steps (cubic) instead of Newton: the guess is within ~0.02 of the root, so two
-// quadrature passes normally suffice -- when the second step is tiny its cubic remainder is below 1e-14 and c0
-// at the root follows from its Taylor expansion (su, cuu are the A-derivatives of c0) without a third pass.
+// initial guess.  The guess is within ~0.03 of the root and the k-th A-derivative of g is bounded by
+// B(k+1, k+1) = (k!)^2 / (2k+1)!, so ONE quadrature pass that also accumulates the u^k moments yields a degree-5
+// Taylor model of g (and of c0) around the guess whose remainder at |d| <= 0.05 is below 2e-15: the root of the
+// model is the root.  A second pass only happens when the model's root is farther away (pathological goals).
 __device__ __noinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     Clothoid cl;
     cl.k0 = 0.0; cl.dk = 0.0; cl.L = 0.0; cl.ok = false;
@@ -132,23 +134,25 @@ __device__ __noinline__ Clothoid g1_fit(double x1, double y1, double th1) {
     bool ok = false;
     for (int it = 0; it < 20; ++it) {
         const FitMoments m = fit_moments(A, delta - A, phi0);
-        const double g = m.s0, g1 = m.cu, g2 = -m.suu;
-        if (fabs(g) <= 1e-13) { ok = true; c0 = m.c0; break; }
-        if (g1 == 0.0 || !isfinite(g1)) break;
-        const double den = 2.0 * g1 * g1 - g * g2;
-        double step = -2.0 * g * g1 / den;                        // Halley
-        if (!isfinite(step) || !(fabs(den) > 1e-300)) step = -g / g1;   // Newton fallback
-        A += step;
-        if (!isfinite(A)) break;
-        if (fabs(step) <= 1e-4 && fabs(g1) >= 0.02) {             // cubic remainder < 1e-14: finish without another pass
-            c0 = m.c0 - step * m.su - 0.5 * step * step * m.cuu;
+        // Taylor coefficients of g around A
+        const double g0 = m.s[0], g1 = m.c[1], g2 = -0.5 * m.s[2], g3 = m.c[3] * (-1.0 / 6.0), g4 = m.s[4] * (1.0 / 24.0),
+                     g5 = m.c[5] * (1.0 / 120.0);
+        if (g1 == 0.0 || !isfinite(g1) || !isfinite(g0)) break;
+        double d = -g0 / g1;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {   // Newton on the quintic model
+            const double pv = __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, g5, g4), g3), g2), g1), g0);
+            const double dv = __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, 5.0 * g5, 4.0 * g4), 3.0 * g3), 2.0 * g2), g1);
+            d -= pv / dv;
+        }
+        if (!isfinite(d)) break;
+        A += d;
+        if (fabs(d) <= 0.05) {          // inside the model's trust radius: c0 at the root from its own Taylor series
+            const double q5 = m.s[5] * (-1.0 / 120.0), q4 = m.c[4] * (1.0 / 24.0), q3 = m.s[3] * (1.0 / 6.0), q2 = -0.5 * m.c[2], q1 = -m.s[1];
+            c0 = __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, __builtin_fma(d, q5, q4), q3), q2), q1), m.c[0]);
             ok = true;
             break;
         }
-    }
-    if (!ok) {
-        const FitMoments m = fit_moments(A, delta - A, phi0);
-        if (fabs(m.s0) <= 1e-10) { ok = true; c0 = m.c0; }
     }
     if (!ok) return cl;
     const double L = r / c0;
@@ -216,6 +220,73 @@ __device__ __forceinline__ void interval_increment(double k0, double dk, double 
     dx = ax; dy = ay;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Station loop of one candidate: sample_traj rows + occupancy test + the running cost terms.
+// Out of line on purpose: inside the kernel body the ~35 workgroup-uniform values it needs compete with kernel
+// arguments and the sincos constants for ~100 SGPRs, get spilled to VGPR lanes and come back through ~30
+// v_readlane per station -- VALU instructions in a VALU-bound kernel.  Here they sit in LDS (EgoParams) and are
+// read with vector LDS loads, so the hot loop sees only VGPR operands plus the SGPR-resident sincos constants.
+// ---------------------------------------------------------------------------------------------------
+struct EgoParams {
+    double tx0, txx, txy, ty0, tyx, tyy;      // station (x, y) -> fractional cell relative to the LDS tile (two fma per axis)
+    double tile_w, tile_h, tile_gx0, tile_gy0, grid_w, grid_h;
+    const double* prev;                        // previous winner's heading column or null
+    const uint32_t* bits;                      // global bitmap (off-tile samples)
+    int tile_words, wwords, S, den, sim_m, n_shift, collide, pad;
+};
+struct StationResult { double maxk, sumk, sim; int hit; };
+
+#define F1P_LDS(T) __attribute__((address_space(3))) T
+
+__device__ __noinline__ StationResult station_loop(double k0, double dk, double L, const F1P_LDS(EgoParams)* ep,
+                                                   const F1P_LDS(uint32_t)* tile, double* trow) {
+    StationResult r;
+    const int S = ep->S, sim_m = ep->sim_m, n_shift = ep->n_shift, tile_words = ep->tile_words;
+    const bool collide = ep->collide != 0;
+    const double* prev = ep->prev;
+    const double tx0 = ep->tx0, txx = ep->txx, txy = ep->txy, ty0 = ep->ty0, tyx = ep->tyx, tyy = ep->tyy;
+    const double tile_w = ep->tile_w, tile_h = ep->tile_h;
+    const double ds = L / (double)ep->den;
+    const IntervalCoef ic = interval_setup(k0, dk, L, ds);
+    double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
+    bool hit = false;
+    for (int i = 0; i < S; ++i) {
+        const double s = (double)i * ds;
+        const double th = s * (k0 + 0.5 * s * dk);
+        const double ak = fabs(k0 + dk * s);
+        if (ak > maxk) maxk = ak;
+        sumk += ak;
+        if (prev && i < sim_m) { const double d = th - prev[i + n_shift]; sim += d * d; }
+        if (collide && !(F1P_K3_ABLATE & 2)) {
+            const double lxf = __builtin_floor(__builtin_fma(txx, x, __builtin_fma(txy, y, tx0)));
+            const double lyf = __builtin_floor(__builtin_fma(tyx, x, __builtin_fma(tyy, y, ty0)));
+            bool occ = true;                                  // NaN / off-map: occupied
+            if ((lxf >= 0.0) & (lxf < tile_w) & (lyf >= 0.0) & (lyf < tile_h)) {
+                const int lx = (int)lxf, ly = (int)lyf;       // inside the LDS tile (off-map words are all ones)
+                occ = (tile[ly * tile_words + (lx >> 5)] >> (lx & 31)) & 1u;
+            } else {
+                const double gxf = lxf + ep->tile_gx0, gyf = lyf + ep->tile_gy0;
+                if ((gxf >= 0.0) & (gxf < ep->grid_w) & (gyf >= 0.0) & (gyf < ep->grid_h)) {
+                    const int cgx = (int)gxf, cgy = (int)gyf;
+                    occ = (ep->bits[(size_t)cgy * ep->wwords + (cgx >> 5)] >> (cgx & 31)) & 1u;
+                }
+            }
+            hit |= occ;
+        }
+        if (trow) {
+            reinterpret_cast<double2*>(trow)[2 * i] = make_double2(x, y);
+            reinterpret_cast<double2*>(trow)[2 * i + 1] = make_double2(th, ak);
+        }
+        if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
+            double dx, dy;
+            interval_increment(k0, dk, s, ic, dx, dy);
+            x += dx; y += dy;
+        }
+    }
+    r.maxk = maxk; r.sumk = sumk; r.sim = sim; r.hit = hit ? 1 : 0;
+    return r;
+}
+
 struct LatticeArgs {
     const double* poses;       // [E][4]
     const double* goals;       // [E][C][3] or null
@@ -273,7 +344,8 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     double* inc_x = tr_y + S;                                    // [S]
     double* inc_y = inc_x + S;                                   // [S]
     double* win = inc_y + S;                                     // [4] winner clothoid (k0, dk, L, ok)
-    int* red_i = reinterpret_cast<int*>(win + 4);                // [4]
+    EgoParams* egp = reinterpret_cast<EgoParams*>(win + 4);      // workgroup-uniform parameters of station_loop
+    int* red_i = reinterpret_cast<int*>(egp + 1);                // [4]
     int* cen_ok = red_i + 4;                                     // [64]
     uint32_t* tile = reinterpret_cast<uint32_t*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [tile_rows][tile_words]
 
@@ -323,19 +395,27 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
             tile[q] = v;
         }
     }
-    __syncthreads();
 
     double sn_t, cs_t;
     sincos(theta, &sn_t, &cs_t);
     const double ct = cs_t, st = sn_t;
-    // station (x, y) in the ego frame -> fractional cell coordinates relative to the LDS tile, two fma per axis:
-    //   cell_x = ((px + ct x - st y) - ox) / res  folded into  tx0 + txx x + txy y   (likewise y)
-    const double txx = ct * a.grid.inv_res, txy = -st * a.grid.inv_res, tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
-    const double tyx = st * a.grid.inv_res, tyy = ct * a.grid.inv_res, ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
-    const double tile_w = (double)(a.tile_words * 32), tile_h = (double)a.tile_rows;
     const int den = S - 1 > 1 ? S - 1 : 1;
     const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
     const int sim_m = S - cfg.n_shift - cfg.n_cull;
+    if (tid == 0) {
+        // station (x, y) in the ego frame -> fractional cell coordinates relative to the LDS tile, two fma per axis:
+        //   cell_x = ((px + ct x - st y) - ox) / res  folded into  tx0 + txx x + txy y   (likewise y)
+        EgoParams q;
+        q.txx = ct * a.grid.inv_res; q.txy = -st * a.grid.inv_res; q.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
+        q.tyx = st * a.grid.inv_res; q.tyy = ct * a.grid.inv_res; q.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+        q.tile_w = (double)(a.tile_words * 32); q.tile_h = (double)a.tile_rows;
+        q.tile_gx0 = (double)tile_gx0; q.tile_gy0 = (double)tile_gy0; q.grid_w = (double)a.grid.w; q.grid_h = (double)a.grid.h;
+        q.prev = prev; q.bits = a.grid.bits;
+        q.tile_words = a.tile_words; q.wwords = a.grid.wwords; q.S = S; q.den = den; q.sim_m = sim_m; q.n_shift = cfg.n_shift;
+        q.collide = collide_on ? 1 : 0; q.pad = 0;
+        *egp = q;
+    }
+    __syncthreads();
 
     double bc; int bi;
     if (a.mode != LATTICE_EMIT) {
@@ -356,43 +436,10 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
             double cost = __builtin_huge_val();
             double* trow = a.all_traj ? a.all_traj + ((size_t)e * C + c) * (size_t)S * 4 : nullptr;
             if (cl.ok) {
-                const double ds = cl.L / (double)den;
-                const IntervalCoef ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
-                double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
-                bool hit = false;
-                for (int i = 0; i < S; ++i) {
-                    const double s = (double)i * ds;
-                    const double th = s * (cl.k0 + 0.5 * s * cl.dk);
-                    const double ak = fabs(cl.k0 + cl.dk * s);
-                    if (ak > maxk) maxk = ak;
-                    sumk += ak;
-                    if (prev && i < sim_m) { const double d = th - prev[i + cfg.n_shift]; sim += d * d; }
-                    if (collide_on && !(F1P_K3_ABLATE & 2)) {
-                        const double lxf = __builtin_floor(__builtin_fma(txx, x, __builtin_fma(txy, y, tx0)));
-                        const double lyf = __builtin_floor(__builtin_fma(tyx, x, __builtin_fma(tyy, y, ty0)));
-                        bool occ = true;                                  // NaN / off-map: occupied
-                        if ((lxf >= 0.0) & (lxf < tile_w) & (lyf >= 0.0) & (lyf < tile_h)) {
-                            const int lx = (int)lxf, ly = (int)lyf;       // inside the LDS tile (off-map words are all ones)
-                            occ = (tile[ly * a.tile_words + (lx >> 5)] >> (lx & 31)) & 1u;
-                        } else {
-                            const double gxf = lxf + (double)tile_gx0, gyf = lyf + (double)tile_gy0;
-                            if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
-                                const int cgx = (int)gxf, cgy = (int)gyf;
-                                occ = (a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)] >> (cgx & 31)) & 1u;
-                            }
-                        }
-                        hit |= occ;
-                    }
-                    if (trow) {
-                        reinterpret_cast<double2*>(trow)[2 * i] = make_double2(x, y);
-                        reinterpret_cast<double2*>(trow)[2 * i + 1] = make_double2(th, ak);
-                    }
-                    if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
-                        double dx, dy;
-                        interval_increment(cl.k0, cl.dk, s, ic, dx, dy);
-                        x += dx; y += dy;
-                    }
-                }
+                const StationResult sr = station_loop(cl.k0, cl.dk, cl.L, (const F1P_LDS(EgoParams)*)egp,
+                                                      (const F1P_LDS(uint32_t)*)tile, trow);
+                const double maxk = sr.maxk, sumk = sr.sumk, sim = sr.sim;
+                const bool hit = sr.hit != 0;
                 cost = 0.0;                                   // eval(): cost = 0.; cost += w_i * f_i
                 cost += cfg.w_length * (1.0 / cl.L);
                 cost += cfg.w_max_kappa * maxk;
@@ -522,7 +569,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
         a.tile_words = (2 * half + 31) / 32 + 1;
     }
     const int S = cfg->n_stations;
-    size_t lds = sizeof(double) * (8 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
+    size_t lds = sizeof(EgoParams) + sizeof(double) * (8 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
                  sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
     lds = (lds + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_lattice, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
