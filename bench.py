@@ -61,7 +61,13 @@ def main():
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=30, help="host-boundary plan() calls for p50/p95 (0 = skip)")
+    ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc"], default="lattice",
+                    help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
+    ap.add_argument("--rollouts", type=int, default=512)
+    ap.add_argument("--horizon", type=int, default=30)
     args = ap.parse_args()
+    if args.workload == "kmpc":
+        return main_kmpc(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,9 +89,13 @@ def main():
     d_steer, d_speed = ctx.alloc(8 * E), ctx.alloc(8 * E)
     d_bidx, d_bcost, d_status, d_near = ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E)
     d_traj = ctx.alloc(8 * E * S * 4)
+    materialised = args.workload == "lattice-materialised"
+    d_all_cost = ctx.alloc(8 * E * C) if materialised else None
+    d_all_traj = ctx.alloc(8 * E * C * S * 4) if materialised else None   # the reference's all_traj data flow (:194-201)
 
     def step():
-        ctx.lattice_plan_dev(d_poses, E, cfg, d_steer, d_speed, d_bidx, d_bcost, d_status, d_near, d_traj)
+        ctx.lattice_plan_dev(d_poses, E, cfg, d_steer, d_speed, d_bidx, d_bcost, d_status, d_near, d_traj,
+                             d_all_cost=d_all_cost, d_all_traj=d_all_traj)
 
     dist = None
     if world > 1:
@@ -114,7 +124,7 @@ def main():
 
     # p50 / p95 latency of one plan() at the ctypes boundary: host poses in, host results out (H2D + kernel + D2H + sync)
     lat = None
-    if args.latency_iters > 0:
+    if args.latency_iters > 0 and not materialised:
         ctx.lattice_plan(poses, cfg, want_traj=True)
         ts = []
         for _ in range(args.latency_iters):
@@ -135,6 +145,8 @@ def main():
         value = steps_total / elapsed
         kernel_ms = kernel_ms_total / args.steps
         abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0])
+        if materialised:
+            abytes += E * C * S * 32 + E * C * 8      # every candidate's rows (x, y, theta, |kappa|) + its cost, written once
         achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9
         valu_tlanes = VALU_INSTR_PER_CANDIDATE["value"] * E * C / (kernel_ms * 1e-3) / 1e12
         out = {
@@ -142,7 +154,7 @@ def main():
             "value": value, "unit": "candidate-trajectory-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batched lattice: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[2])",
+            "config": {"workload": f"batched lattice{' (all_traj materialised)' if materialised else ''}: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[2])",
                        "egos_per_gpu": E, "candidates": C, "stations": S, "raceline_points": int(rl.shape[0]),
                        "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16),
                        "parallelism": f"egos sharded over {world} GPU(s), no collective"},
@@ -179,6 +191,82 @@ def main():
                                    "sample": f"first {n_cpu} of the {E} egos x {C} candidates x {S} stations, oracle/f1p_oracle.c "
                                              f"(fp64 C, OpenMP over egos, {nthr} threads), {cpu_s:.1f} s"}
             out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": mism, "max_abs_dsteer": dsteer}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def main_kmpc(args):
+    """Secondary line: kinematic-MPC random shooting (BASELINE configs[4]: 1024 egos x 512 rollouts x 30 steps, 128 egos
+    per GPU on 8 GPUs; here `--egos` per GPU).  The controls stream from HBM (8 B per rollout-step): HBM roofline."""
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    E = args.egos if args.egos != 4096 else 1024
+    T, R = args.horizon, args.rollouts
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    cl = synth.make_centerline(seed=2)
+    rng = np.random.default_rng(10 + rank)
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.uniform(0.5, 5.5, E),
+                              cl[k, 3] + rng.normal(0, 0.1, E)])
+    ctx = Context(local_rank)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    ref = ctx.kmpc_ref(states, T)
+    d_x0, d_ref = ctx.to_device(states), ctx.to_device(ref)
+    d_ctrl = ctx.alloc(4 * E * T * 2 * R)
+    ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=2 + rank)
+    d_steer, d_speed, d_bi, d_bc = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E)
+
+    def step():
+        ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    if dist:
+        dist.barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_end() / args.steps
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        abytes = E * R * T * 8 + E * (T + 1) * 32 + E * 32 + E * 28
+        value = float(E) * R * T * args.steps * world / elapsed
+        out = {"metric": "rollout-steps/sec (kinematic-MPC random shooting)", "value": value, "unit": "rollout-steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 arithmetic on f32 controls",
+               "data": "synthetic",
+               "config": {"workload": f"kmpc shooting: {E} egos x {R} rollouts x {T} steps per GPU (BASELINE configs[4])"},
+               "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_kmpc_shoot",
+                            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                            "bytes_per_rollout_step": abytes / (E * R * T)}}
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            nthr = oracle.max_threads()
+            n_cpu = min(E, max(nthr, 256))
+            ctrl = d_ctrl.download(np.float32, (E, T, 2, R))[:n_cpu]
+            t1 = time.perf_counter()
+            want = oracle.kmpc_shoot_batch(states[:n_cpu], ref[:n_cpu], ctrl, cfg, nthreads=nthr)
+            cpu_s = time.perf_counter() - t1
+            got = d_bi.download(np.int32, (E,))[:n_cpu]
+            out["cpu_baseline"] = {"value": n_cpu * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
+                                   "sample": f"first {n_cpu} egos, oracle/f1p_oracle.c, {nthr} threads, {cpu_s:.2f} s"}
+            out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": int((want["best_idx"] != got).sum())}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

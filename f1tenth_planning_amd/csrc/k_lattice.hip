@@ -28,6 +28,13 @@
 #ifndef F1P_K3_ABLATE
 #define F1P_K3_ABLATE 0
 #endif
+// inlining policy of the two per-candidate helpers (A/B knobs)
+#ifndef F1P_SETUP_INLINE
+#define F1P_SETUP_INLINE __forceinline__
+#endif
+#ifndef F1P_STATION_INLINE
+#define F1P_STATION_INLINE __noinline__
+#endif
 #ifndef F1P_K3_WAVES
 #define F1P_K3_WAVES 3
 #endif
@@ -175,9 +182,19 @@ __device__ __noinline__ Clothoid g1_fit(double x1, double y1, double th1) {
 // |b| <= 0.02, where the truncated series (6 terms in a^2, 4 in b^2) are exact to < 1e-15.
 // The result depends only on (clothoid, s): the winner re-emission reproduces the evaluation loop bit for bit.
 // ---------------------------------------------------------------------------------------------------
-struct IntervalCoef { double p[6], q[6]; double hs; int nsub; };
+// Heading phasor of the pieces.  theta_m is quadratic in the piece index n, so exp(j theta_m(n)) obeys a second-order
+// recurrence: E_{n+1} = E_n R_n, R_{n+1} = R_n W with W = exp(j dk hs^2) constant -- two complex multiplies (8 fp64
+// instructions) instead of a sincos (~45).  Rounding drift is bounded by re-anchoring E and R with exact sincos every
+// F1P_K3_ANCHOR pieces (8: drift < 1e-14 rad); the anchors depend only on the piece index, so any piece's state can be
+// rebuilt from its anchor and the winner re-emission stays bit-identical to the evaluation loop.
+#ifndef F1P_K3_ANCHOR
+#define F1P_K3_ANCHOR 8
+#endif
+struct PieceState { double er, ei, rr, ri; };
 
-__device__ __noinline__ IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
+struct IntervalCoef { double p[6], q[6]; double hs, wr, wi; int nsub; };
+
+__device__ F1P_SETUP_INLINE IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
     IntervalCoef ic;
     const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
     const double n1 = __builtin_ceil(kmax * ds * 2.0);                    // |a| = |kappa_m| hs / 2 <= 0.25
@@ -195,15 +212,29 @@ __device__ __noinline__ IntervalCoef interval_setup(double k0, double dk, double
         ic.p[n] = h * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_p[n][3], c_k_p[n][2]), c_k_p[n][1]), c_k_p[n][0]);
         ic.q[n] = hb * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_q[n][3], c_k_q[n][2]), c_k_q[n][1]), c_k_q[n][0]);
     }
+    sincos_core(dk * ic.hs * ic.hs, &ic.wi, &ic.wr);                      // W = exp(j dk hs^2)
     return ic;
 }
 
-__device__ __forceinline__ void interval_increment(double k0, double dk, double s, const IntervalCoef& ic, double& dx,
-                                                   double& dy) {
+// exact phasors at the piece whose midpoint is sm: E = exp(j theta(sm)), R = exp(j hs kappa(sm + hs/2))
+__device__ __forceinline__ void piece_anchor(PieceState& st, double k0, double dk, double hs, double sm) {
+    sincos_core(sm * __builtin_fma(0.5 * dk, sm, k0), &st.ei, &st.er);
+    sincos_core(hs * __builtin_fma(dk, __builtin_fma(0.5, hs, sm), k0), &st.ri, &st.rr);
+}
+__device__ __forceinline__ void piece_advance(PieceState& st, double wr, double wi) {
+    const double er = __builtin_fma(st.er, st.rr, -(st.ei * st.ri)), ei = __builtin_fma(st.er, st.ri, st.ei * st.rr);
+    const double rr = __builtin_fma(st.rr, wr, -(st.ri * wi)), ri = __builtin_fma(st.rr, wi, st.ri * wr);
+    st.er = er; st.ei = ei; st.rr = rr; st.ri = ri;
+}
+
+// integral over station interval i (pieces n0 .. n0 + nsub - 1, n0 = i nsub); `st` is the phasor state entering piece n0
+__device__ __forceinline__ void interval_increment(double k0, double dk, double s, int n0, const IntervalCoef& ic, PieceState& st,
+                                                   double& dx, double& dy) {
     double ax = 0.0, ay = 0.0;
     const double h = 0.5 * ic.hs;
     for (int q = 0; q < ic.nsub; ++q) {
         const double sm = __builtin_fma((double)q + 0.5, ic.hs, s);       // midpoint of the piece
+        if (((n0 + q) & (F1P_K3_ANCHOR - 1)) == 0) piece_anchor(st, k0, dk, ic.hs, sm);
         const double a = __builtin_fma(dk, sm, k0) * h;
         const double z = a * a;
         double P = __builtin_fma(z, ic.p[5], ic.p[4]);
@@ -212,12 +243,26 @@ __device__ __forceinline__ void interval_increment(double k0, double dk, double 
         P = __builtin_fma(z, P, ic.p[2]); Q = __builtin_fma(z, Q, ic.q[2]);
         P = __builtin_fma(z, P, ic.p[1]); Q = __builtin_fma(z, Q, ic.q[1]);
         P = __builtin_fma(z, P, ic.p[0]); Q = __builtin_fma(z, Q, ic.q[0]);
-        double sn, cs;
-        sincos_core(sm * __builtin_fma(0.5 * dk, sm, k0), &sn, &cs);   // |theta| is a few turns at most on a fitted clothoid
-        ax += __builtin_fma(cs, P, -(sn * Q));
-        ay += __builtin_fma(sn, P, cs * Q);
+        ax += __builtin_fma(st.er, P, -(st.ei * Q));
+        ay += __builtin_fma(st.ei, P, st.er * Q);
+        piece_advance(st, ic.wr, ic.wi);
     }
     dx = ax; dy = ay;
+}
+
+// phasor state entering piece n0 = i nsub, rebuilt from its anchor exactly as the sequential loop produced it
+__device__ __forceinline__ PieceState piece_state_at(double k0, double dk, double ds, int i, const IntervalCoef& ic) {
+    PieceState st;
+    st.er = 1.0; st.ei = 0.0; st.rr = 1.0; st.ri = 0.0;
+    const int n0 = i * ic.nsub;
+    const int na = n0 & ~(F1P_K3_ANCHOR - 1);
+    if (na < n0) {
+        const int ia = na / ic.nsub, qa = na - ia * ic.nsub;
+        const double sm = __builtin_fma((double)qa + 0.5, ic.hs, (double)ia * ds);
+        piece_anchor(st, k0, dk, ic.hs, sm);
+        for (int n = na; n < n0; ++n) piece_advance(st, ic.wr, ic.wi);
+    }
+    return st;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -238,7 +283,7 @@ struct StationResult { double maxk, sumk, sim; int hit; };
 
 #define F1P_LDS(T) __attribute__((address_space(3))) T
 
-__device__ __noinline__ StationResult station_loop(double k0, double dk, double L, const F1P_LDS(EgoParams)* ep,
+__device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, double L, const F1P_LDS(EgoParams)* ep,
                                                    const F1P_LDS(uint32_t)* tile, double* trow) {
     StationResult r;
     const int S = ep->S, sim_m = ep->sim_m, n_shift = ep->n_shift, tile_words = ep->tile_words;
@@ -250,6 +295,8 @@ __device__ __noinline__ StationResult station_loop(double k0, double dk, double 
     const IntervalCoef ic = interval_setup(k0, dk, L, ds);
     double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
     bool hit = false;
+    PieceState st;
+    st.er = 1.0; st.ei = 0.0; st.rr = 1.0; st.ri = 0.0;   // piece 0 is an anchor: overwritten before use
     for (int i = 0; i < S; ++i) {
         const double s = (double)i * ds;
         const double th = s * (k0 + 0.5 * s * dk);
@@ -279,7 +326,7 @@ __device__ __noinline__ StationResult station_loop(double k0, double dk, double 
         }
         if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
             double dx, dy;
-            interval_increment(k0, dk, s, ic, dx, dy);
+            interval_increment(k0, dk, s, i * ic.nsub, ic, st, dx, dy);
             x += dx; y += dy;
         }
     }
@@ -487,7 +534,10 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
     for (int i = lane; i < S - 1; i += 64) {
         double dx = 0.0, dy = 0.0;
-        if (cl.ok) interval_increment(cl.k0, cl.dk, (double)i * ds, ic, dx, dy);
+        if (cl.ok) {
+            PieceState st = piece_state_at(cl.k0, cl.dk, ds, i, ic);
+            interval_increment(cl.k0, cl.dk, (double)i * ds, i * ic.nsub, ic, st, dx, dy);
+        }
         inc_x[i] = dx; inc_y[i] = dy;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
