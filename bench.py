@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # fp64 vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s of FMA)
 FP64_VALU_PEAK_TLANES = 39.3
 # VALU wave-instructions per candidate of k_lattice, from the latest committed PMC profile (SQ_INSTS_VALU / candidates)
-VALU_INSTR_PER_CANDIDATE = {"value": 28770.0, "source": "profiles/r01_k_lattice_baseline_summary.md (SQ_INSTS_VALU 4.713e8 / 16384 waves)"}
+VALU_INSTR_PER_CANDIDATE = {"value": 9576.0, "source": "profiles/r01_k_lattice_opt2_summary.md (SQ_INSTS_VALU 1.569e8 / 16384 waves)"}
 
 
 def algorithmic_bytes_lattice(E, C, S, n_wp, grid_w, grid_h, device_goals=True):

@@ -29,6 +29,9 @@
 #define F1P_K3_ABLATE 0
 #endif
 // inlining policy of the two per-candidate helpers (A/B knobs)
+#ifndef F1P_FIT_INLINE
+#define F1P_FIT_INLINE __noinline__
+#endif
 #ifndef F1P_SETUP_INLINE
 #define F1P_SETUP_INLINE __forceinline__
 #endif
@@ -36,7 +39,7 @@
 #define F1P_STATION_INLINE __noinline__
 #endif
 #ifndef F1P_K3_WAVES
-#define F1P_K3_WAVES 3
+#define F1P_K3_WAVES 4
 #endif
 
 namespace f1p {
@@ -123,7 +126,7 @@ struct Clothoid { double k0, dk, L; bool ok; };
 // B(k+1, k+1) = (k!)^2 / (2k+1)!, so ONE quadrature pass that also accumulates the u^k moments yields a degree-5
 // Taylor model of g (and of c0) around the guess whose remainder at |d| <= 0.05 is below 2e-15: the root of the
 // model is the root.  A second pass only happens when the model's root is farther away (pathological goals).
-__device__ __noinline__ Clothoid g1_fit(double x1, double y1, double th1) {
+__device__ F1P_FIT_INLINE Clothoid g1_fit(double x1, double y1, double th1) {
     Clothoid cl;
     cl.k0 = 0.0; cl.dk = 0.0; cl.L = 0.0; cl.ok = false;
     const double r = hypot(x1, y1);
