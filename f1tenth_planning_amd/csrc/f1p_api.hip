@@ -283,6 +283,11 @@ int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, 
     auto bad = [&](int c) { return c < 0 || c >= ncols; };
     if (bad(col_x) || bad(col_y) || bad(col_v) || (col_psi >= 0 && bad(col_psi))) return set_error(ctx, F1P_EINVAL, "column index out of range");
     std::vector<double> soa((size_t)4 * n, 0.0);
+    if (col_psi >= 0)
+        for (int i = 0; i < n; ++i) {
+            const double psi = wp[(size_t)i * ncols + col_psi];
+            if (!(psi >= -1.0e4 && psi <= 1.0e4)) return set_error(ctx, F1P_EINVAL, "waypoint heading must be finite and within +-1e4 rad");
+        }
     for (int i = 0; i < n; ++i) {
         soa[i] = wp[(size_t)i * ncols + col_x];
         soa[(size_t)n + i] = wp[(size_t)i * ncols + col_y];

@@ -36,7 +36,10 @@
 #define F1P_SETUP_INLINE __forceinline__
 #endif
 #ifndef F1P_STATION_INLINE
-#define F1P_STATION_INLINE __noinline__
+#define F1P_STATION_INLINE __forceinline__
+#endif
+#ifndef F1P_K3_LDS_OPERANDS
+#define F1P_K3_LDS_OPERANDS 1
 #endif
 #ifndef F1P_K3_WAVES
 #define F1P_K3_WAVES 4
@@ -181,8 +184,8 @@ __device__ F1P_FIT_INLINE Clothoid g1_fit(double x1, double y1, double th1) {
 //     int_{-1}^{1} exp(j (a t + b t^2)) dt = P(a^2) + j Q(a^2)
 // (the odd parts cancel).  b is the same for every piece of a candidate, so the Taylor coefficients of P and Q
 // in a^2 are computed ONCE per candidate (interval_setup); a piece then costs one sincos of theta_m and two
-// degree-5 Horner polynomials instead of four sincos of a 4-point quadrature.  nsub keeps |a| <= 0.25 and
-// |b| <= 0.02, where the truncated series (6 terms in a^2, 4 in b^2) are exact to < 1e-15.
+// degree-4 Horner polynomials instead of four sincos of a 4-point quadrature.  nsub keeps |a| <= 0.15 and
+// |b| <= 0.02, where the truncated series (5 terms in a^2, 4 in b^2) are exact to < 1e-15.
 // The result depends only on (clothoid, s): the winner re-emission reproduces the evaluation loop bit for bit.
 // ---------------------------------------------------------------------------------------------------
 // Heading phasor of the pieces.  theta_m is quadratic in the piece index n, so exp(j theta_m(n)) obeys a second-order
@@ -195,12 +198,12 @@ __device__ F1P_FIT_INLINE Clothoid g1_fit(double x1, double y1, double th1) {
 #endif
 struct PieceState { double er, ei, rr, ri; };
 
-struct IntervalCoef { double p[6], q[6]; double hs, wr, wi; int nsub; };
+struct IntervalCoef { double p[5], q[5]; double hs, wr, wi; int nsub; };
 
 __device__ F1P_SETUP_INLINE IntervalCoef interval_setup(double k0, double dk, double L, double ds) {
     IntervalCoef ic;
     const double kmax = fmax(fabs(k0), fabs(__builtin_fma(dk, L, k0)));   // |kappa| is extremal at an end
-    const double n1 = __builtin_ceil(kmax * ds * 2.0);                    // |a| = |kappa_m| hs / 2 <= 0.25
+    const double n1 = __builtin_ceil(kmax * ds * (1.0 / 0.3));            // |a| = |kappa_m| hs / 2 <= 0.15
     const double n2 = __builtin_ceil(ds * __builtin_sqrt(fabs(dk) * 6.25));   // |b| = |dk| hs^2 / 8 <= 0.02
     double nn = fmax(1.0, fmax(n1, n2));
     nn = nn <= 4096.0 ? nn : 4096.0;                                      // also catches NaN
@@ -211,7 +214,7 @@ __device__ F1P_SETUP_INLINE IntervalCoef interval_setup(double k0, double dk, do
     const double b2 = b * b;
     const double hb = h * b;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
+    for (int n = 0; n < 5; ++n) {
         ic.p[n] = h * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_p[n][3], c_k_p[n][2]), c_k_p[n][1]), c_k_p[n][0]);
         ic.q[n] = hb * __builtin_fma(b2, __builtin_fma(b2, __builtin_fma(b2, c_k_q[n][3], c_k_q[n][2]), c_k_q[n][1]), c_k_q[n][0]);
     }
@@ -240,9 +243,8 @@ __device__ __forceinline__ void interval_increment(double k0, double dk, double 
         if (((n0 + q) & (F1P_K3_ANCHOR - 1)) == 0) piece_anchor(st, k0, dk, ic.hs, sm);
         const double a = __builtin_fma(dk, sm, k0) * h;
         const double z = a * a;
-        double P = __builtin_fma(z, ic.p[5], ic.p[4]);
-        double Q = __builtin_fma(z, ic.q[5], ic.q[4]);
-        P = __builtin_fma(z, P, ic.p[3]); Q = __builtin_fma(z, Q, ic.q[3]);
+        double P = __builtin_fma(z, ic.p[4], ic.p[3]);
+        double Q = __builtin_fma(z, ic.q[4], ic.q[3]);
         P = __builtin_fma(z, P, ic.p[2]); Q = __builtin_fma(z, Q, ic.q[2]);
         P = __builtin_fma(z, P, ic.p[1]); Q = __builtin_fma(z, Q, ic.q[1]);
         P = __builtin_fma(z, P, ic.p[0]); Q = __builtin_fma(z, Q, ic.q[0]);
@@ -278,6 +280,7 @@ __device__ __forceinline__ PieceState piece_state_at(double k0, double dk, doubl
 struct EgoParams {
     double tx0, txx, txy, ty0, tyx, tyy;      // station (x, y) -> fractional cell relative to the LDS tile (two fma per axis)
     double tile_w, tile_h, tile_gx0, tile_gy0, grid_w, grid_h;
+    double px, py, theta, ct, st;              // ego pose and its rotation (candidate_goal reads them here, not from registers)
     const double* prev;                        // previous winner's heading column or null
     const uint32_t* bits;                      // global bitmap (off-tile samples)
     int tile_words, wwords, S, den, sim_m, n_shift, collide, pad;
@@ -292,8 +295,17 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
     const int S = ep->S, sim_m = ep->sim_m, n_shift = ep->n_shift, tile_words = ep->tile_words;
     const bool collide = ep->collide != 0;
     const double* prev = ep->prev;
+#if F1P_K3_LDS_OPERANDS
+    // the eight transform / tile constants are re-read from LDS at every station (volatile: not hoisted): eight ds_read_b64
+    // (LDS pipe, idle here) instead of 16 VGPRs held across the loop -- the difference decides whether the loop spills at
+    // 4 waves per SIMD
+    const volatile F1P_LDS(EgoParams)* epv = ep;
+#define F1P_EP(f) (epv->f)
+#else
     const double tx0 = ep->tx0, txx = ep->txx, txy = ep->txy, ty0 = ep->ty0, tyx = ep->tyx, tyy = ep->tyy;
     const double tile_w = ep->tile_w, tile_h = ep->tile_h;
+#define F1P_EP(f) (f)
+#endif
     const double ds = L / (double)ep->den;
     const IntervalCoef ic = interval_setup(k0, dk, L, ds);
     double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
@@ -308,10 +320,10 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
         sumk += ak;
         if (prev && i < sim_m) { const double d = th - prev[i + n_shift]; sim += d * d; }
         if (collide && !(F1P_K3_ABLATE & 2)) {
-            const double lxf = __builtin_floor(__builtin_fma(txx, x, __builtin_fma(txy, y, tx0)));
-            const double lyf = __builtin_floor(__builtin_fma(tyx, x, __builtin_fma(tyy, y, ty0)));
+            const double lxf = __builtin_floor(__builtin_fma(F1P_EP(txx), x, __builtin_fma(F1P_EP(txy), y, F1P_EP(tx0))));
+            const double lyf = __builtin_floor(__builtin_fma(F1P_EP(tyx), x, __builtin_fma(F1P_EP(tyy), y, F1P_EP(ty0))));
             bool occ = true;                                  // NaN / off-map: occupied
-            if ((lxf >= 0.0) & (lxf < tile_w) & (lyf >= 0.0) & (lyf < tile_h)) {
+            if ((lxf >= 0.0) & (lxf < F1P_EP(tile_w)) & (lyf >= 0.0) & (lyf < F1P_EP(tile_h))) {
                 const int lx = (int)lxf, ly = (int)lyf;       // inside the LDS tile (off-map words are all ones)
                 occ = (tile[ly * tile_words + (lx >> 5)] >> (lx & 31)) & 1u;
             } else {
@@ -358,7 +370,7 @@ struct LatticeArgs {
 
 // goal of candidate c in the ego frame; false when it has no goal (look-ahead circle missed the raceline)
 __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_lattice_cfg& cfg, int e, int c, int C,
-                                               double px, double py, double theta, double ct, double st,
+                                               const volatile EgoParams* ep,
                                                const double* cen_x, const double* cen_y, const double* cen_psi,
                                                const int* cen_ok, double& gx, double& gy, double& gth) {
     if (a.goals) {
@@ -371,13 +383,14 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
     const double psi = cen_psi[l];
     const double w = cfg.width[k];
     double sp, cp;
-    sincos_fast(psi, &sp, &cp);
+    sincos_core(psi, &sp, &cp);   // |psi| <= 1e4 is enforced when the waypoints are uploaded (f1p_set_waypoints)
     const double mx = cen_x[l] + w * (-sp);
     const double my = cen_y[l] + w * cp;
-    const double dx = mx - px, dy = my - py;
+    const double dx = mx - ep->px, dy = my - ep->py;
+    const double ct = ep->ct, st = ep->st;
     gx = ct * dx + st * dy;
     gy = -st * dx + ct * dy;
-    gth = remainder_2pi(psi - theta);
+    gth = remainder_2pi(psi - ep->theta);
     return true;
 }
 
@@ -395,7 +408,8 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     double* inc_y = inc_x + S;                                   // [S]
     double* win = inc_y + S;                                     // [4] winner clothoid (k0, dk, L, ok)
     EgoParams* egp = reinterpret_cast<EgoParams*>(win + 4);      // workgroup-uniform parameters of station_loop
-    int* red_i = reinterpret_cast<int*>(egp + 1);                // [4]
+    double* slot = reinterpret_cast<double*>(egp + 1);           // [256][4] clothoid of each thread's best candidate
+    int* red_i = reinterpret_cast<int*>(slot + 4 * 256);         // [4]
     int* cen_ok = red_i + 4;                                     // [64]
     uint32_t* tile = reinterpret_cast<uint32_t*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [tile_rows][tile_words]
 
@@ -460,6 +474,7 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
         q.tyx = st * a.grid.inv_res; q.tyy = ct * a.grid.inv_res; q.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
         q.tile_w = (double)(a.tile_words * 32); q.tile_h = (double)a.tile_rows;
         q.tile_gx0 = (double)tile_gx0; q.tile_gy0 = (double)tile_gy0; q.grid_w = (double)a.grid.w; q.grid_h = (double)a.grid.h;
+        q.px = px; q.py = py; q.theta = theta; q.ct = ct; q.st = st;
         q.prev = prev; q.bits = a.grid.bits;
         q.tile_words = a.tile_words; q.wwords = a.grid.wwords; q.S = S; q.den = den; q.sim_m = sim_m; q.n_shift = cfg.n_shift;
         q.collide = collide_on ? 1 : 0; q.pad = 0;
@@ -472,11 +487,9 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
         // ---- 4. candidates: fit, sample, check, cost -------------------------------------------------
         const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
         bc = __builtin_huge_val(); bi = 0x7fffffff;
-        double my_k0 = 0.0, my_dk = 0.0, my_L = 0.0;      // clothoid of this thread's best candidate
-        bool my_ok = false;
         for (int c = c0 + tid; c < c1; c += blockDim.x) {
             double gx, gy, gth;
-            const bool gok = candidate_goal(a, cfg, e, c, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+            const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
             Clothoid cl;
             cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
             if (gok) {
@@ -500,13 +513,16 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                 for (int i = 0; i < 2 * S; ++i) reinterpret_cast<double2*>(trow)[i] = make_double2(0.0, 0.0);
             }
             if (a.all_cost) a.all_cost[(size_t)e * C + c] = cost;
-            if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; my_k0 = cl.k0; my_dk = cl.dk; my_L = cl.L; my_ok = cl.ok; }
+            if (argmin_better(cost, c, bc, bi)) {             // this thread's best so far: park its clothoid in LDS, not in registers
+                bc = cost; bi = c;
+                slot[4 * tid] = cl.k0; slot[4 * tid + 1] = cl.dk; slot[4 * tid + 2] = cl.L; slot[4 * tid + 3] = cl.ok ? 1.0 : 0.0;
+            }
         }
         // ---- 5. select(): argmin, first minimum wins ----------------------------------------------------
         const int my_bi = bi;
         block_argmin(bc, bi, red_d, red_i);
         if (my_bi == bi && bi != 0x7fffffff) {            // the owner of the winner hands its clothoid to wave 0
-            win[0] = my_k0; win[1] = my_dk; win[2] = my_L; win[3] = my_ok ? 1.0 : 0.0;
+            win[0] = slot[4 * tid]; win[1] = slot[4 * tid + 1]; win[2] = slot[4 * tid + 2]; win[3] = slot[4 * tid + 3];
         }
         if (tid == 0) {
             if (a.best_idx) a.best_idx[e] = bi;
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
         if (bi != 0x7fffffff) { cl.k0 = win[0]; cl.dk = win[1]; cl.L = win[2]; cl.ok = win[3] != 0.0; }
     } else if (bi >= 0 && bi < C) {
         double gx, gy, gth;
-        if (candidate_goal(a, cfg, e, bi, C, px, py, theta, ct, st, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth))
+        if (candidate_goal(a, cfg, e, bi, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth))
             cl = g1_fit(gx, gy, gth);
     }
     const double ds = cl.ok ? cl.L / (double)den : 0.0;
@@ -622,7 +638,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
         a.tile_words = (2 * half + 31) / 32 + 1;
     }
     const int S = cfg->n_stations;
-    size_t lds = sizeof(EgoParams) + sizeof(double) * (8 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
+    size_t lds = sizeof(EgoParams) + sizeof(double) * (8 + 4 * 256 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
                  sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
     lds = (lds + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_lattice, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
