@@ -17,14 +17,25 @@ struct KmpcStep { double x, y, v, yaw; };
 
 // update_state_kinematic :223-243 (delta already clamped by the caller's projection; the clamp is repeated
 // here because the reference does it inside the step)
+// FAST: the range-reduced sincos core for cos/sin(yaw) and tan = sin/cos (valid while |yaw| <= 1e5, which the caller
+// checks once per ego: a rollout changes yaw by < 1 rad per step); otherwise the device library's full-range functions.
+template <bool FAST>
 __device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, const f1p_kmpc_cfg& c) {
     if (delta >= c.max_steer) delta = c.max_steer;             // :226-229
     else if (delta <= -c.max_steer) delta = -c.max_steer;
-    double sn, cs;
-    sincos_fast(s.yaw, &sn, &cs);
+    double sn, cs, tn;
+    if (FAST) {
+        double sd, cd;
+        sincos_core(s.yaw, &sn, &cs);
+        sincos_core(delta, &sd, &cd);
+        tn = sd / cd;
+    } else {
+        sincos(s.yaw, &sn, &cs);
+        tn = tan(delta);
+    }
     const double x = s.x + s.v * cs * c.dt;                    // :231
     const double y = s.y + s.v * sn * c.dt;                    // :232
-    const double yaw = s.yaw + (s.v / c.wheelbase) * tan(delta) * c.dt;   // :233-235
+    const double yaw = s.yaw + (s.v / c.wheelbase) * tn * c.dt;   // :233-235
     double v = s.v + a * c.dt;                                 // :236
     if (v > c.max_speed) v = c.max_speed;                      // :238-241
     else if (v < c.min_speed) v = c.min_speed;
@@ -32,6 +43,39 @@ __device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, c
 }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
+
+// all rollouts of this thread: running cost in the reference's accumulation order, first-minimum argmin
+template <bool FAST>
+__device__ __forceinline__ void kmpc_rollouts(const float* __restrict__ ce, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
+                                              double sy, double sv, double syaw, double dmax, int tid, double& bc, int& bi) {
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    for (int r = tid; r < R; r += blockDim.x) {
+        KmpcStep s;
+        s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
+        double cost = 0.0, pa = 0.0, pd = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double a = (double)ce[((size_t)t * 2 + 0) * R + r];
+            double d = (double)ce[((size_t)t * 2 + 1) * R + r];
+            a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
+            d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
+            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
+            const double e0 = s.x - sref[0 * (T + 1) + t], e1 = s.y - sref[1 * (T + 1) + t];
+            const double e2 = s.v - sref[2 * (T + 1) + t], e3 = s.yaw - sref[3 * (T + 1) + t];
+            cost += ((cfg.q[0] * e0 * e0 + cfg.q[1] * e1 * e1) + cfg.q[2] * e2 * e2) + cfg.q[3] * e3 * e3;   // :331
+            cost += cfg.r[0] * a * a + cfg.r[1] * d * d;                                                     // :328
+            if (t > 0) {
+                const double da = a - pa, dd = d - pd;
+                cost += cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                                           // :334
+            }
+            kmpc_step<FAST>(s, a, d, cfg);
+            pa = a; pd = d;
+        }
+        const double e0 = s.x - sref[0 * (T + 1) + T], e1 = s.y - sref[1 * (T + 1) + T];
+        const double e2 = s.v - sref[2 * (T + 1) + T], e3 = s.yaw - sref[3 * (T + 1) + T];
+        cost += ((cfg.qf[0] * e0 * e0 + cfg.qf[1] * e1 * e1) + cfg.qf[2] * e2 * e2) + cfg.qf[3] * e3 * e3;
+        if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_kmpc_shoot(const double* __restrict__ x0, const double* __restrict__ ref,
                                                     const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
@@ -52,32 +96,9 @@ __global__ __launch_bounds__(256) void k_kmpc_shoot(const double* __restrict__ x
     const double dmax = cfg.max_dsteer * cfg.dt;
 
     double bc = __builtin_huge_val(); int bi = 0x7fffffff;
-    for (int r = tid; r < R; r += blockDim.x) {
-        KmpcStep s;
-        s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
-        double cost = 0.0, pa = 0.0, pd = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double a = (double)ce[((size_t)t * 2 + 0) * R + r];
-            double d = (double)ce[((size_t)t * 2 + 1) * R + r];
-            a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
-            d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
-            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
-            const double e0 = s.x - sref[0 * (T + 1) + t], e1 = s.y - sref[1 * (T + 1) + t];
-            const double e2 = s.v - sref[2 * (T + 1) + t], e3 = s.yaw - sref[3 * (T + 1) + t];
-            cost += ((cfg.q[0] * e0 * e0 + cfg.q[1] * e1 * e1) + cfg.q[2] * e2 * e2) + cfg.q[3] * e3 * e3;   // :331
-            cost += cfg.r[0] * a * a + cfg.r[1] * d * d;                                                     // :328
-            if (t > 0) {
-                const double da = a - pa, dd = d - pd;
-                cost += cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                                           // :334
-            }
-            kmpc_step(s, a, d, cfg);
-            pa = a; pd = d;
-        }
-        const double e0 = s.x - sref[0 * (T + 1) + T], e1 = s.y - sref[1 * (T + 1) + T];
-        const double e2 = s.v - sref[2 * (T + 1) + T], e3 = s.yaw - sref[3 * (T + 1) + T];
-        cost += ((cfg.qf[0] * e0 * e0 + cfg.qf[1] * e1 * e1) + cfg.qf[2] * e2 * e2) + cfg.qf[3] * e3 * e3;
-        if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
-    }
+    const bool fast = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4;   // workgroup-uniform
+    if (fast) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
+    else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     block_argmin(bc, bi, red_d, red_i);
     if (tid == 0) {
         // the winner's applied sequence: clamp, then the sequential rate limit
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(256) void k_kmpc_predict(const double* __restrict__
     double* p = path + (size_t)e * 4 * (T + 1);
     p[0] = s.x; p[T + 1] = s.y; p[2 * (T + 1)] = s.v; p[3 * (T + 1)] = s.yaw;
     for (int t = 0; t < T; ++t) {
-        kmpc_step(s, oa[(size_t)e * T + t], od[(size_t)e * T + t], cfg);
+        kmpc_step<false>(s, oa[(size_t)e * T + t], od[(size_t)e * T + t], cfg);
         p[t + 1] = s.x; p[(T + 1) + t + 1] = s.y; p[2 * (T + 1) + t + 1] = s.v; p[3 * (T + 1) + t + 1] = s.yaw;
     }
 }
