@@ -122,11 +122,14 @@ PROTOTYPES = {
     "f1p_timer_begin": (C.c_int, [_P]),
     "f1p_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "f1p_set_waypoints": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I]),
+    "f1p_set_waypoints_ex": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "f1p_set_grid": (C.c_int, [_P, _P, _I, _I, _D, _D, _D, _I]),
     "f1p_nearest_point_batch": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),
     "f1p_intersect_point_batch": (C.c_int, [_P, _P, _P, _I, _D, _I, _P, _P, _P, _P]),
     "f1p_pure_pursuit_batch": (C.c_int, [_P, _P, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
     "f1p_pure_pursuit_dev": (C.c_int, [_P, _P, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
+    "f1p_stanley_batch": (C.c_int, [_P, _P, _I, _D, _D, _P, _P, _P]),
+    "f1p_lqr_batch": (C.c_int, [_P, _P, _P, _I, _D, _D, _P, _D, _I, _D, _P, _P, _P]),
     "f1p_lattice_plan_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 9),
     "f1p_lattice_plan_dev": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 9),
     "f1p_lattice_emit_dev": (C.c_int, [_P, _P, _P, _I, C.POINTER(LatticeCfg), _P, _P, _P, _P, _P, _P, _P]),

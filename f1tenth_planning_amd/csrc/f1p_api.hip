@@ -201,7 +201,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -276,13 +276,19 @@ int f1p_timer_end(f1p_ctx* ctx, float* elapsed_ms) {
 // ---------------------------------------------------------------------------------------------------
 int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
                       int32_t col_v, int32_t col_psi) {
+    return f1p_set_waypoints_ex(ctx, wp, n, ncols, col_x, col_y, col_v, col_psi, -1);
+}
+
+int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
+                         int32_t col_v, int32_t col_psi, int32_t col_kappa) {
     F1P_ENTER(ctx);
     if (!wp) return set_error(ctx, F1P_EINVAL, "waypoints pointer is NULL");
     if (n < 2) return set_error(ctx, F1P_EINVAL, "at least 2 waypoints are required");
     if (ncols < 3) return set_error(ctx, F1P_EINVAL, "Waypoints needs to be a (Nxm), m >= 3, numpy array!");   // pure_pursuit.py:101-102
     auto bad = [&](int c) { return c < 0 || c >= ncols; };
-    if (bad(col_x) || bad(col_y) || bad(col_v) || (col_psi >= 0 && bad(col_psi))) return set_error(ctx, F1P_EINVAL, "column index out of range");
-    std::vector<double> soa((size_t)4 * n, 0.0);
+    if (bad(col_x) || bad(col_y) || bad(col_v) || (col_psi >= 0 && bad(col_psi)) || (col_kappa >= 0 && bad(col_kappa)))
+        return set_error(ctx, F1P_EINVAL, "column index out of range");
+    std::vector<double> soa((size_t)5 * n, 0.0);
     if (col_psi >= 0)
         for (int i = 0; i < n; ++i) {
             const double psi = wp[(size_t)i * ncols + col_psi];
@@ -293,10 +299,11 @@ int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, 
         soa[(size_t)n + i] = wp[(size_t)i * ncols + col_y];
         soa[(size_t)2 * n + i] = wp[(size_t)i * ncols + col_v];
         soa[(size_t)3 * n + i] = col_psi >= 0 ? wp[(size_t)i * ncols + col_psi] : 0.0;
+        soa[(size_t)4 * n + i] = col_kappa >= 0 ? wp[(size_t)i * ncols + col_kappa] : 0.0;
     }
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n != ctx->n_wp) {
-        double** ps[] = {&ctx->d_wx, &ctx->d_wy, &ctx->d_wv, &ctx->d_wpsi};
+        double** ps[] = {&ctx->d_wx, &ctx->d_wy, &ctx->d_wv, &ctx->d_wpsi, &ctx->d_wkappa};
         for (double** p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
         ctx->n_wp = 0;
         for (double** p : ps) F1P_HIP(ctx, hipMalloc((void**)p, sizeof(double) * (size_t)n));
@@ -306,8 +313,10 @@ int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, 
     F1P_HIP(ctx, hipMemcpy(ctx->d_wy, soa.data() + n, b, hipMemcpyHostToDevice));
     F1P_HIP(ctx, hipMemcpy(ctx->d_wv, soa.data() + 2 * (size_t)n, b, hipMemcpyHostToDevice));
     F1P_HIP(ctx, hipMemcpy(ctx->d_wpsi, soa.data() + 3 * (size_t)n, b, hipMemcpyHostToDevice));
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wkappa, soa.data() + 4 * (size_t)n, b, hipMemcpyHostToDevice));
     ctx->n_wp = n;
     ctx->has_psi = col_psi >= 0;
+    ctx->has_kappa = col_kappa >= 0;
     return F1P_OK;
 }
 
@@ -398,6 +407,45 @@ int f1p_pure_pursuit_batch(f1p_ctx* ctx, const double* poses, int32_t E, double 
     double* d_steer = s.out(steer, E); double* d_speed = s.out(speed, E);
     int32_t* d_n = s.out(near_idx, E); int32_t* d_l = s.out(la_idx, E); int32_t* d_s = s.out(status, E);
     if ((rc = f1p_pure_pursuit_dev(ctx, d_poses, E, lookahead, wheelbase, max_reacquire, d_steer, d_speed, d_n, d_l, d_s))) return rc;
+    return s.finish();
+}
+
+// ---------------------------------------------------------------------------------------------------
+int f1p_stanley_batch(f1p_ctx* ctx, const double* states, int32_t E, double wheelbase, double k_path, double* steer,
+                      double* speed, int32_t* near_idx) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!states || !steer || !speed))) return set_error(ctx, F1P_EINVAL, "states, steer and speed are required");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "Please set waypoints to track during planner instantiation or when calling plan()");
+    if (!ctx->has_psi) return set_error(ctx, F1P_EINVAL, "Waypoints needs to be a (Nxm), m >= 4, numpy array!");   // stanley.py:131-132
+    Stage s(ctx);
+    s.need(8 * 4 * (size_t)E); s.need(8 * (size_t)E); s.need(8 * (size_t)E); s.need(4 * (size_t)E, near_idx);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_st;
+    if ((rc = s.in(states, (size_t)4 * E, &d_st))) return rc;
+    double* d_steer = s.out(steer, E); double* d_speed = s.out(speed, E); int32_t* d_n = s.out(near_idx, E);
+    if ((rc = launch_stanley(ctx, d_st, E, wheelbase, k_path, d_steer, d_speed, d_n))) return rc;
+    return s.finish();
+}
+
+int f1p_lqr_batch(f1p_ctx* ctx, const double* states, double* err, int32_t E, double wheelbase, double timestep,
+                  const double q[4], double r, int32_t max_iter, double eps, double* steer, double* speed,
+                  int32_t* near_idx) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!states || !err || !steer || !speed)) || !q) return set_error(ctx, F1P_EINVAL, "states, err, q, steer and speed are required");
+    if (!(timestep > 0.0) || !(wheelbase > 0.0) || max_iter < 0) return set_error(ctx, F1P_EINVAL, "timestep and wheelbase must be > 0, max_iter >= 0");
+    if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "Please set waypoints to track during planner instantiation or when calling plan()");
+    if (!ctx->has_psi || !ctx->has_kappa) return set_error(ctx, F1P_EINVAL, "Waypoints needs to be a (Nxm), m >= 5, numpy array!");   // lqr.py:195-196
+    Stage s(ctx);
+    s.need(8 * 4 * (size_t)E); s.need(8 * 2 * (size_t)E); s.need(8 * (size_t)E); s.need(8 * (size_t)E); s.need(4 * (size_t)E, near_idx);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_st;
+    if ((rc = s.in(states, (size_t)4 * E, &d_st))) return rc;
+    const double* d_err_in;
+    if ((rc = s.in((const double*)err, (size_t)2 * E, &d_err_in))) return rc;
+    double* d_err = const_cast<double*>(d_err_in);
+    if (E > 0) s.outs.push_back({(void*)err, (void*)d_err, sizeof(double) * 2 * (size_t)E});   // in/out
+    double* d_steer = s.out(steer, E); double* d_speed = s.out(speed, E); int32_t* d_n = s.out(near_idx, E);
+    if ((rc = launch_lqr(ctx, d_st, d_err, E, wheelbase, timestep, q, r, max_iter, eps, d_steer, d_speed, d_n))) return rc;
     return s.finish();
 }
 

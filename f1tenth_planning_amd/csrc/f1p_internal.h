@@ -18,7 +18,8 @@ struct f1p_ctx {
     // waypoints, struct-of-arrays fp64 (coalesced lane-consecutive loads in nearest_scan / wave_intersect)
     int n_wp = 0;
     bool has_psi = false;
-    double *d_wx = nullptr, *d_wy = nullptr, *d_wv = nullptr, *d_wpsi = nullptr;
+    double *d_wx = nullptr, *d_wy = nullptr, *d_wv = nullptr, *d_wpsi = nullptr, *d_wkappa = nullptr;
+    bool has_kappa = false;
 
     // occupancy grid, bit-packed and row-flipped
     bool has_grid = false;
@@ -80,6 +81,10 @@ int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, co
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);
 int launch_kmpc_sample(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, uint64_t seed, double sigma_a,
                        double sigma_d);
+int launch_stanley(f1p_ctx* ctx, const double* d_states, int E, double wheelbase, double k_path, double* d_steer,
+                   double* d_speed, int32_t* d_near);
+int launch_lqr(f1p_ctx* ctx, const double* d_states, double* d_err, int E, double wheelbase, double ts, const double* q,
+               double r, int max_iter, double eps, double* d_steer, double* d_speed, int32_t* d_near);
 int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E);
 
 }  // namespace f1p

@@ -134,8 +134,9 @@ class Context:
             raise ValueError('Waypoints needs to be a (Nxm), m >= 3, numpy array!')   # pure_pursuit.py:101-102
         wp = _f64(wp)
         if cols is None:
-            cols = (0, 1, 2, 3 if wp.shape[1] >= 4 else -1)
-        self._check(self.lib.f1p_set_waypoints(self.h, _ptr(wp), wp.shape[0], wp.shape[1], *[int(c) for c in cols]))
+            cols = (0, 1, 2, 3 if wp.shape[1] >= 4 else -1, 4 if wp.shape[1] >= 5 else -1)
+        cols = tuple(int(c) for c in cols) + (-1,) * (5 - len(cols))      # (x, y, v, psi, kappa)
+        self._check(self.lib.f1p_set_waypoints_ex(self.h, _ptr(wp), wp.shape[0], wp.shape[1], *cols))
         self.n_waypoints = wp.shape[0]
 
     def set_waypoints_cached(self, waypoints, cols=None):
@@ -192,6 +193,23 @@ class Context:
         self._check(self.lib.f1p_pure_pursuit_batch(self.h, _ptr(poses), E, float(lookahead), float(wheelbase),
                                                     float(max_reacquire), _ptr(out["steer"]), _ptr(out["speed"]),
                                                     _ptr(out["near_idx"]), _ptr(out["la_idx"]), _ptr(out["status"])))
+        return out
+
+    # ---- Stanley / LQR --------------------------------------------------------------------
+    def stanley(self, states, wheelbase=0.33, k_path=5.0):
+        st = _f64(states, (-1, 4)); E = st.shape[0]
+        out = dict(steer=np.empty(E), speed=np.empty(E), near_idx=np.empty(E, np.int32))
+        self._check(self.lib.f1p_stanley_batch(self.h, _ptr(st), E, float(wheelbase), float(k_path), _ptr(out["steer"]),
+                                               _ptr(out["speed"]), _ptr(out["near_idx"])))
+        return out
+
+    def lqr(self, states, err, wheelbase=0.33, timestep=0.01, q=(0.999, 0.0, 0.0066, 0.0), r=0.75, max_iter=50, eps=0.001):
+        """err [E, 2] = (e_cog, theta_e) of the previous call; the updated errors come back in out['err']"""
+        st = _f64(states, (-1, 4)); E = st.shape[0]
+        err = _f64(err, (E, 2)).copy(); qa = _f64(q, (4,))
+        out = dict(steer=np.empty(E), speed=np.empty(E), near_idx=np.empty(E, np.int32), err=err)
+        self._check(self.lib.f1p_lqr_batch(self.h, _ptr(st), _ptr(err), E, float(wheelbase), float(timestep), _ptr(qa), float(r),
+                                           int(max_iter), float(eps), _ptr(out["steer"]), _ptr(out["speed"]), _ptr(out["near_idx"])))
         return out
 
     # ---- lattice -------------------------------------------------------------------------------------------

@@ -142,6 +142,10 @@ int f1p_timer_end(f1p_ctx* ctx, float* elapsed_ms);
  * (examples/control/Spielberg_raceline.csv:1), i.e. cols 0,1,2,3. */
 int f1p_set_waypoints(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
                       int32_t col_v, int32_t col_psi);
+/* Same, with a curvature column (LQR feed-forward, control/lqr/lqr.py:93): rows [x, y, v, psi, kappa]
+ * (examples/control/Spielberg_raceline.csv:1).  col_kappa < 0: none. */
+int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncols, int32_t col_x, int32_t col_y,
+                         int32_t col_v, int32_t col_psi, int32_t col_kappa);
 /* img: row-major [h][w] u8, row 0 = TOP of the image (ROS map_server layout,
  * examples/control/Spielberg_map.yaml:1-6); cell (gx, gy) with gx = floor((x-ox)/res), gy = floor((y-oy)/res)
  * reads img[h-1-gy][gx]; a cell is occupied iff its value < occupied_below; outside the image is occupied. */
@@ -172,6 +176,20 @@ int f1p_pure_pursuit_batch(f1p_ctx* ctx, const double* poses, int32_t E, double 
 int f1p_pure_pursuit_dev(f1p_ctx* ctx, const double* d_poses, int32_t E, double lookahead, double wheelbase,
                          double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near_idx,
                          int32_t* d_la_idx, int32_t* d_status);
+
+/* ------------------------------------------------------------------------------------------------
+ * SURVEY.md 8f rank 1 -- the two other waypoint trackers, batched on the same nearest-segment kernel.
+ * StanleyPlanner.plan (control/stanley/stanley.py:114-139): states [E][4] = (x, y, theta, velocity) ->
+ *   steer [E] = atan2(k_path * ef, v) + theta_e, speed [E] = waypoints[target, 2], near_idx [E] (nullable).
+ * LQRPlanner.plan (control/lqr/lqr.py:156-210) with solve_lqr / update_matrix (utils/utils.py:167-239):
+ *   err [E][2] carries (e_cog, theta_e) of the previous call (the planner's attributes, lqr.py:57-58) and is
+ *   updated in place; q[4] = diag Q, r = R, max_iter / eps of the Riccati iteration; needs a curvature column.
+ * ---------------------------------------------------------------------------------------------- */
+int f1p_stanley_batch(f1p_ctx* ctx, const double* states, int32_t E, double wheelbase, double k_path, double* steer,
+                      double* speed, int32_t* near_idx);
+int f1p_lqr_batch(f1p_ctx* ctx, const double* states, double* err, int32_t E, double wheelbase, double timestep,
+                  const double q[4], double r, int32_t max_iter, double eps, double* steer, double* speed,
+                  int32_t* near_idx);
 
 /* ------------------------------------------------------------------------------------------------
  * LatticePlanner.plan (planning/lattice_planner/lattice_planner.py:174-214) for E egos, one fused launch:

@@ -612,3 +612,131 @@ ORC_API int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Stanley and LQR lateral controllers on top of nearest_point                  */
+/* ------------------------------------------------------------------------------------------------ */
+/* calc_theta_and_ef (control/stanley/stanley.py:57-88) == calc_control_points (control/lqr/lqr.py:60-103):
+ * front-axle point, nearest_point on the raceline, cross-track error ef, heading error theta_e. */
+static void orc_front_axle_errors(double x, double y, double theta, double wheelbase, const double* wx, const double* wy,
+                                  const double* wpsi, int n, double* theta_e, double* ef, int* target_index) {
+    double fx = x + wheelbase * cos(theta); /* stanley.py:66 */
+    double fy = y + wheelbase * sin(theta); /* :67 */
+    double proj[2];
+    orc_nearest_point(fx, fy, wx, wy, n, proj, NULL, NULL, target_index); /* :69 */
+    double vx = fx - proj[0], vy = fy - proj[1];                          /* :70 */
+    *ef = dot2(vx, vy, cos(theta - M_PI / 2.0), sin(theta - M_PI / 2.0)); /* :73-75 np.dot */
+    *theta_e = orc_pi_2_pi(wpsi[*target_index] - theta);                  /* :79-80 */
+}
+
+/* StanleyPlanner.plan (stanley.py:90-139): steer = atan2(k_path * ef, v) + theta_e, speed = waypoints[target, 2] */
+ORC_API void orc_stanley_batch(const double* states /*E x 4: x, y, theta, v*/, int E, double wheelbase, double k_path,
+                               const double* wx, const double* wy, const double* wv, const double* wpsi, int n,
+                               double* steer, double* speed, int32_t* near_idx) {
+    for (int e = 0; e < E; ++e) {
+        double theta_e, ef;
+        int ti;
+        orc_front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, n, &theta_e, &ef, &ti);
+        double cte_front = atan2(k_path * ef, states[4 * e + 3]); /* :110 */
+        steer[e] = cte_front + theta_e;                           /* :111 */
+        speed[e] = wv[ti];
+        if (near_idx) near_idx[e] = ti;
+    }
+}
+
+/* solve_lqr (utils/utils.py:167-205) for the 4-state / 1-input system of update_matrix (:207-239).  Row-major 4x4. */
+static void orc_mat4_mul(const double* a, const double* b, double* c) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j];
+            c[4 * i + j] = s;
+        }
+}
+ORC_API void orc_solve_lqr(const double* A, const double* B /*4*/, const double* Q /*4x4*/, double R, double tolerance,
+                           int max_num_iteration, double* K /*4*/) {
+    double AT[16], P[16], Pn[16], T1[16], T2[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) AT[4 * i + j] = A[4 * j + i];
+    memcpy(P, Q, sizeof(P)); /* :190 */
+    int it = 0;
+    double diff = INFINITY;
+    while (it < max_num_iteration && diff > tolerance) { /* :194 */
+        ++it;
+        /* P_next = AT P A - (AT P B + M) pinv(R + BT P B) (BT P A + MT) + Q, M = 0  (:196-197) */
+        orc_mat4_mul(AT, P, T1); /* AT P */
+        orc_mat4_mul(T1, A, T2); /* AT P A */
+        double atpb[4], btpa[4], btp[4];
+        for (int i = 0; i < 4; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += T1[4 * i + k] * B[k];
+            atpb[i] = s;
+        }
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += B[k] * P[4 * k + j];
+            btp[j] = s;
+        }
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += btp[k] * A[4 * k + j];
+            btpa[j] = s;
+        }
+        double btpb = 0.0;
+        for (int k = 0; k < 4; ++k) btpb += btp[k] * B[k];   /* (B^T P) B, the order numpy evaluates BT @ P @ B */
+        double den = R + btpb;
+        double inv = den != 0.0 ? 1.0 / den : 0.0; /* np.linalg.pinv of a 1x1 matrix */
+        double mx = -INFINITY;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                Pn[4 * i + j] = T2[4 * i + j] - atpb[i] * inv * btpa[j] + Q[4 * i + j];
+                double d = Pn[4 * i + j] - P[4 * i + j];
+                if (d > mx) mx = d;
+            }
+        diff = fabs(mx); /* :200 np.abs(np.max(P_next - P)) */
+        memcpy(P, Pn, sizeof(P));
+    }
+    /* K = pinv(BT P B + R) (BT P A + MT)  (:203) */
+    double btp[4], btpa[4];
+    for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += B[k] * P[4 * k + j];
+        btp[j] = s;
+    }
+    double btpb = 0.0;
+    for (int k = 0; k < 4; ++k) btpb += btp[k] * B[k];   /* (B^T P) B, the order numpy evaluates BT @ P @ B */
+    for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += btp[k] * A[4 * k + j];
+        btpa[j] = s;
+    }
+    double den = btpb + R;
+    double inv = den != 0.0 ? 1.0 / den : 0.0;
+    for (int j = 0; j < 4; ++j) K[j] = inv * btpa[j];
+}
+
+/* LQRPlanner.plan (lqr.py:156-210) for E egos; err [E][2] holds (e_cog, theta_e) of the previous call and is updated */
+ORC_API void orc_lqr_batch(const double* states /*E x 4*/, double* err /*E x 2*/, int E, double wheelbase, double ts,
+                           const double* q /*4*/, double r, int max_iter, double eps, const double* wx, const double* wy,
+                           const double* wv, const double* wpsi, const double* wkappa, int n, double* steer, double* speed,
+                           int32_t* near_idx) {
+    for (int e = 0; e < E; ++e) {
+        double theta_e, ef;
+        int ti;
+        double v = states[4 * e + 3];
+        double e_old = err[2 * e], th_old = err[2 * e + 1];                                                 /* :136-137 */
+        orc_front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, n, &theta_e, &ef, &ti);
+        double A[16] = {1.0, ts, 0, 0, 0, 0, v, 0, 0, 0, 1.0, ts, 0, 0, 0, 0};                              /* update_matrix :227-233 */
+        double B[4] = {0, 0, 0, v / wheelbase};                                                             /* :236-237 */
+        double Q[16] = {0};
+        for (int i = 0; i < 4; ++i) Q[5 * i] = q[i];
+        double K[4];
+        orc_solve_lqr(A, B, Q, r, eps, max_iter, K);
+        double st[4] = {ef, (ef - e_old) / ts, theta_e, (theta_e - th_old) / ts};                           /* :150-153 */
+        double fb = ((K[0] * st[0] + K[1] * st[1]) + K[2] * st[2]) + K[3] * st[3];                          /* :155 */
+        steer[e] = fb + wkappa[ti] * wheelbase;                                                             /* :158-161 */
+        speed[e] = wv[ti];
+        err[2 * e] = ef; err[2 * e + 1] = theta_e;                                                          /* :100-101 */
+        if (near_idx) near_idx[e] = ti;
+    }
+}

@@ -221,3 +221,28 @@ def kmpc_shoot_batch(x0, ref, controls, cfg: KmpcCfg, want_all=False, nthreads=1
                                _p(out["speed"]), _p(out["best_idx"]), _p(out["best_cost"]), _p(out["best_seq"]),
                                _p(out.get("all_cost")), C.c_int(nthreads))
     return out
+
+
+# ---- Stanley / LQR ------------------------------------------------------------------------
+def stanley_batch(states, waypoints, wheelbase=0.33, k_path=5.0, cols=(0, 1, 2, 3)):
+    """StanleyPlanner.plan (control/stanley/stanley.py:114-139) over states [E, 4] = (x, y, theta, v)"""
+    st = _f64(states).reshape(-1, 4); wp = _f64(waypoints)
+    wx, wy, wv, wpsi = (_f64(wp[:, c]) for c in cols)
+    E = st.shape[0]
+    steer = np.zeros(E); speed = np.zeros(E); ni = np.zeros(E, np.int32)
+    lib().orc_stanley_batch(_p(st), C.c_int(E), C.c_double(wheelbase), C.c_double(k_path), _p(wx), _p(wy), _p(wv), _p(wpsi),
+                            C.c_int(len(wx)), _p(steer), _p(speed), _p(ni))
+    return dict(steer=steer, speed=speed, near_idx=ni)
+
+
+def lqr_batch(states, err, waypoints, wheelbase=0.33, ts=0.01, q=(0.999, 0.0, 0.0066, 0.0), r=0.75, max_iter=50, eps=0.001,
+              cols=(0, 1, 2, 3, 4)):
+    """LQRPlanner.plan (control/lqr/lqr.py:156-210); err [E, 2] = previous (e_cog, theta_e), returned updated"""
+    st = _f64(states).reshape(-1, 4); wp = _f64(waypoints); err = _f64(err).reshape(-1, 2).copy()
+    wx, wy, wv, wpsi, wk = (_f64(wp[:, c]) for c in cols)
+    E = st.shape[0]; qa = _f64(q)
+    steer = np.zeros(E); speed = np.zeros(E); ni = np.zeros(E, np.int32)
+    lib().orc_lqr_batch(_p(st), _p(err), C.c_int(E), C.c_double(wheelbase), C.c_double(ts), _p(qa), C.c_double(r),
+                        C.c_int(max_iter), C.c_double(eps), _p(wx), _p(wy), _p(wv), _p(wpsi), _p(wk), C.c_int(len(wx)),
+                        _p(steer), _p(speed), _p(ni))
+    return dict(steer=steer, speed=speed, near_idx=ni, err=err)

@@ -134,3 +134,31 @@ def test_sample_traj_layout_golden(orc, golden):
     np.testing.assert_allclose(orc.sample_traj(1.0 / R, 0.0, L, 50), g["arc_traj"], rtol=0, atol=1e-13)
     np.testing.assert_allclose(orc.sample_traj(1.0 / R, 0.0, L, 1), g["arc_traj1"], rtol=0, atol=1e-13)
     np.testing.assert_allclose(orc.sample_traj(0.0, 0.0, float(g["line_L"]), 100), g["line_traj"], rtol=0, atol=1e-13)
+
+
+def test_stanley_golden(orc, golden, tracks):
+    g = golden("g10_g11_stanley_lqr.npz")
+    spl = tracks["spielberg"]
+    for kp, key in ((5.0, "st_out5"), (7.0, "st_out7")):
+        out = orc.stanley_batch(g["st_states"], spl, k_path=kp)
+        np.testing.assert_allclose(out["steer"], g[key][:, 0], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(out["speed"], g[key][:, 1])
+    assert abs(orc.stanley_batch(g["st_states"][:1], spl, k_path=7.0)["steer"][0] - (-0.006591288747744449)) < 1e-13
+    lev4 = np.ascontiguousarray(tracks["levine"][:, [1, 2, 5, 3]])
+    out = orc.stanley_batch(g["st2_states"], lev4, wheelbase=float(g["st2_wheelbase"]))
+    np.testing.assert_allclose(out["steer"], g["st2_out"][:, 0], rtol=0, atol=1e-12)
+
+
+def test_lqr_golden(orc, golden, tracks):
+    g = golden("g10_g11_stanley_lqr.npz")
+    spl = tracks["spielberg"]
+    for q in range(g["lq_states"].shape[0]):
+        ts, q1, q2, q3, q4, r, iters, eps = g["lq_params"][q]
+        err = np.zeros((1, 2))                                   # a fresh LQRPlanner starts from zero errors (lqr.py:57-58)
+        for t in range(g["lq_states"].shape[1]):
+            out = orc.lqr_batch(g["lq_states"][q, t][None], err, spl, ts=ts, q=(q1, q2, q3, q4), r=r, max_iter=int(iters), eps=eps)
+            err = out["err"]
+            assert abs(out["steer"][0] - g["lq_out"][q, t, 0]) <= 1e-9 * max(1.0, abs(g["lq_out"][q, t, 0])), (q, t)
+            assert out["speed"][0] == g["lq_out"][q, t, 1]
+            np.testing.assert_allclose(err[0], g["lq_err"][q, t], rtol=0, atol=1e-13)
+    assert abs(g["lq_out"][0, 0, 0] - (-0.00014536216016581283)) < 1e-15

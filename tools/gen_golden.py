@@ -315,6 +315,50 @@ def main():
                         err_no_costs=errs["no_costs"], err_no_sample=errs["no_sample"],
                         ties=ties, tie_select=tie_sel, arc_R=2.0, arc_L=1.0, arc_traj=arc, arc_traj1=arc1,
                         line_L=1.7, line_traj=line)
+    # ---- G10 StanleyPlanner.plan, G11 LQRPlanner.plan ------------------------------------
+    from f1tenth_planning.control.stanley.stanley import StanleyPlanner
+    from f1tenth_planning.control.lqr.lqr import LQRPlanner
+    n = 192
+    k = rng.integers(0, spl.shape[0] - 1, n)
+    st_states = np.column_stack([spl[k, 0] + rng.normal(0, 0.4, n), spl[k, 1] + rng.normal(0, 0.4, n),
+                                 spl[k, 3] + rng.normal(0, 0.3, n), rng.uniform(0.0, 8.0, n)])
+    st_states[0] = [0.0, -0.84, 3.40, 1.0]                  # SURVEY section 4 probe: k_path = 7 -> -0.006591288747744449
+    st_states[1, 2] += 2 * np.pi                            # pi_2_pi single wrap
+    st_states[2, 2] -= 2 * np.pi
+    st_states[3, 3] = 0.0                                   # atan2(k*ef, 0)
+    st_states[4:12, :2] += rng.uniform(-20, 20, (8, 2))     # far from the line
+    stan = StanleyPlanner(waypoints=spl)
+    st_out = {}
+    for kp in (5.0, 7.0):
+        st_out[kp] = np.array([[float(np.asarray(v).reshape(-1)[0]) for v in stan.plan(*st_states[j], k_path=kp)] for j in range(n)])
+    stan2 = StanleyPlanner(wheelbase=0.3, waypoints=np.ascontiguousarray(lev[:, [1, 2, 5, 3]]))
+    st2_states = np.column_stack([lev[k % lev.shape[0], 1] + rng.normal(0, 0.1, n), lev[k % lev.shape[0], 2] + rng.normal(0, 0.1, n),
+                                  lev[k % lev.shape[0], 3] + rng.normal(0, 0.2, n), rng.uniform(0.5, 5.0, n)])[:64]
+    st2_out = np.array([[float(np.asarray(v).reshape(-1)[0]) for v in stan2.plan(*st2_states[j])] for j in range(64)])
+    # LQR: per-planner state (previous errors) -> sequences of consecutive calls
+    n_seq, n_step = 12, 10
+    lq_states = np.zeros((n_seq, n_step, 4)); lq_out = np.zeros((n_seq, n_step, 2)); lq_err = np.zeros((n_seq, n_step, 2))
+    lq_params = []
+    for q in range(n_seq):
+        pl_ = LQRPlanner(waypoints=spl)
+        kk = int(rng.integers(0, spl.shape[0] - 40))
+        kw = dict(timestep=[0.01, 0.02][q % 2], matrix_q_1=[0.999, 0.7][q % 2], matrix_q_2=[0.0, 0.1][(q // 2) % 2],
+                  matrix_q_3=0.0066, matrix_q_4=[0.0, 0.02][(q // 4) % 2], matrix_r=[0.75, 0.3][q % 2],
+                  iterations=[50, 5][(q // 3) % 2], eps=[0.001, 1e-9][(q // 2) % 2])
+        lq_params.append([kw["timestep"], kw["matrix_q_1"], kw["matrix_q_2"], kw["matrix_q_3"], kw["matrix_q_4"], kw["matrix_r"],
+                          kw["iterations"], kw["eps"]])
+        for t_ in range(n_step):
+            b = spl[kk + 3 * t_]
+            stt = [b[0] + rng.normal(0, 0.2), b[1] + rng.normal(0, 0.2), b[3] + rng.normal(0, 0.15), rng.uniform(0.5, 8.0)]
+            if q == 0 and t_ == 0:
+                stt = [0.0, -0.84, 3.40, 1.0]               # SURVEY section 4 probe -> -0.00014536216016581283
+            lq_states[q, t_] = stt
+            o = pl_.plan(*stt, **kw)
+            lq_out[q, t_] = [float(o[0]), float(o[1])]
+            lq_err[q, t_] = [float(pl_.vehicle_control_e_cog), float(pl_.vehicle_control_theta_e)]
+    np.savez_compressed(os.path.join(OUT, "g10_g11_stanley_lqr.npz"), st_states=st_states, st_out5=st_out[5.0], st_out7=st_out[7.0],
+                        st2_states=st2_states, st2_out=st2_out, st2_wheelbase=0.3,
+                        lq_states=lq_states, lq_out=lq_out, lq_err=lq_err, lq_params=np.array(lq_params))
     print("golden vectors written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))
