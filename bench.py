@@ -86,7 +86,7 @@ def main():
     img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=res)
     poses = synth.make_egos(rl, E, seed=1 + rank)          # every rank plans its own egos
 
-    ctx = Context(local_rank)
+    ctx = Context(local_rank % max(1, _abi.load_library().f1p_device_count()))   # one rank per GPU on a full node
     ctx.set_waypoints(rl)
     ctx.set_grid(img, res, origin, 206)
     d_poses = ctx.to_device(poses)
@@ -217,7 +217,7 @@ def main_kmpc(args):
     k = rng.integers(0, len(cl) - 1, E)
     states = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.uniform(0.5, 5.5, E),
                               cl[k, 3] + rng.normal(0, 0.1, E)])
-    ctx = Context(local_rank)
+    ctx = Context(local_rank % max(1, _abi.load_library().f1p_device_count()))
     ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
     ref = ctx.kmpc_ref(states, T)
     d_x0, d_ref = ctx.to_device(states), ctx.to_device(ref)
