@@ -38,6 +38,16 @@
 #ifndef F1P_STATION_INLINE
 #define F1P_STATION_INLINE __forceinline__
 #endif
+// materialised mode (all_traj requested): stations staged per wave in LDS and flushed as contiguous chunks of
+// F1P_STAGE_T rows (32 B each) per candidate instead of one 32-B row per lane at a 32*S-byte stride
+#ifndef F1P_K3_WAVES_STAGE
+#define F1P_K3_WAVES_STAGE 4
+#endif
+#ifndef F1P_STAGE_T
+#define F1P_STAGE_T 4
+#endif
+#define F1P_STAGE_PITCH (2 * F1P_STAGE_T + 1)   // 16-byte units per candidate row, +1 against LDS bank conflicts
+typedef double f1p_d2 __attribute__((ext_vector_type(2)));   // native 16-byte vector: usable behind an LDS address space
 #ifndef F1P_K3_LDS_OPERANDS
 #define F1P_K3_LDS_OPERANDS 1
 #endif
@@ -353,8 +363,13 @@ struct StationResult { double maxk, sumk, sim; int hit; };
 
 #define F1P_LDS(T) __attribute__((address_space(3))) T
 
+// `stage` (materialised mode, else null): this wave's LDS staging tile [64][F1P_STAGE_PITCH] double2; `wave_out` = global
+// address of the rows of the wave's first candidate; `n_valid` = candidates of this wave that exist.  When staging, ALL 64
+// lanes must call this function together (invalid candidates pass a zero clothoid and produce zero rows).
+template <bool STAGING>
 __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, double L, const F1P_LDS(EgoParams)* ep,
-                                                   const F1P_LDS(uint32_t)* tile, double* trow) {
+                                                   const F1P_LDS(uint32_t)* tile, F1P_LDS(f1p_d2)* stage, double* wave_out,
+                                                   int n_valid) {
     StationResult r;
     const int S = ep->S, sim_m = ep->sim_m, n_shift = ep->n_shift, tile_words = ep->tile_words;
     const bool collide = ep->collide != 0;
@@ -399,9 +414,26 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
             }
             hit |= occ;
         }
-        if (trow) {
-            reinterpret_cast<double2*>(trow)[2 * i] = make_double2(x, y);
-            reinterpret_cast<double2*>(trow)[2 * i + 1] = make_double2(th, ak);
+        if (STAGING) {
+            const int lane = threadIdx.x & 63, r = i % F1P_STAGE_T;
+            f1p_d2 v0, v1;
+            v0.x = x; v0.y = y; v1.x = th; v1.y = ak;
+            stage[lane * F1P_STAGE_PITCH + 2 * r] = v0;
+            stage[lane * F1P_STAGE_PITCH + 2 * r + 1] = v1;
+            if (r == F1P_STAGE_T - 1 || i == S - 1) {       // flush rows i - r .. i of all 64 candidates, coalesced
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                constexpr int UNITS = 2 * F1P_STAGE_T;       // 16-B units per full chunk
+                constexpr int CPI = 64 / UNITS;              // candidates per store instruction
+                const int unit = lane % UNITS, sub = lane / UNITS, n_units = 2 * (r + 1);
+                f1p_d2* dst0 = reinterpret_cast<f1p_d2*>(wave_out) + (size_t)(i - r) * 2;
+#pragma unroll
+                for (int g = 0; g < 64 / CPI; ++g) {
+                    const int cand = g * CPI + sub;
+                    if (cand < n_valid && unit < n_units) dst0[(size_t)cand * S * 2 + unit] = stage[cand * F1P_STAGE_PITCH + unit];
+                }
+                __builtin_amdgcn_wave_barrier();             // LDS ops of one wave execute in order: the next rows cannot overtake
+            }
         }
         if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
             double dx, dy;
@@ -430,6 +462,7 @@ struct LatticeArgs {
     int32_t *status, *near_idx;
     double *best_traj, *all_cost, *all_traj;
     int tile_rows, tile_words;  // LDS occupancy tile: rows x (32-cell words)
+    int stage_offset;           // byte offset of the staging tiles in dynamic LDS (materialised mode)
 };
 
 // goal of candidate c in the ego frame; false when it has no goal (look-ahead circle missed the raceline)
@@ -458,7 +491,9 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
     return true;
 }
 
-__global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
+// STAGING = materialised mode (all_traj requested): a second instantiation, so the fused kernel keeps its register budget
+template <bool STAGING>
+__global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
     double* red_d = reinterpret_cast<double*>(lds_raw);          // [4]
@@ -476,6 +511,8 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
     int* red_i = reinterpret_cast<int*>(slot + 4 * 256);         // [4]
     int* cen_ok = red_i + 4;                                     // [64]
     uint32_t* tile = reinterpret_cast<uint32_t*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [tile_rows][tile_words]
+    // materialised mode only: per-wave staging tiles behind the occupancy tile (16-byte aligned by the launcher)
+    f1p_d2* stage_all = reinterpret_cast<f1p_d2*>(lds_raw + a.stage_offset);
 
     const int e = blockIdx.x;
     if (e >= a.E) return;
@@ -551,9 +588,12 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
         // ---- 4. candidates: fit, sample, check, cost -------------------------------------------------
         const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
         bc = __builtin_huge_val(); bi = 0x7fffffff;
-        for (int c = c0 + tid; c < c1; c += blockDim.x) {
-            double gx, gy, gth;
-            const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+        constexpr bool staging = STAGING;
+        for (int cb = c0; cb < c1; cb += blockDim.x) {        // workgroup-uniform trip count: whole waves stay together
+            const int c = cb + tid;
+            const bool active = c < c1;
+            double gx = 0.0, gy = 0.0, gth = 0.0;
+            const bool gok = active && candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
             Clothoid cl;
             cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
             if (gok) {
@@ -561,25 +601,32 @@ __global__ __launch_bounds__(256, F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1
                 else cl = g1_fit(gx, gy, gth);
             }
             double cost = __builtin_huge_val();
-            double* trow = a.all_traj ? a.all_traj + ((size_t)e * C + c) * (size_t)S * 4 : nullptr;
-            if (cl.ok) {
-                const StationResult sr = station_loop(cl.k0, cl.dk, cl.L, (const F1P_LDS(EgoParams)*)egp,
-                                                      (const F1P_LDS(uint32_t)*)tile, trow);
-                const double maxk = sr.maxk, sumk = sr.sumk, sim = sr.sim;
-                const bool hit = sr.hit != 0;
-                cost = 0.0;                                   // eval(): cost = 0.; cost += w_i * f_i
-                cost += cfg.w_length * (1.0 / cl.L);
-                cost += cfg.w_max_kappa * maxk;
-                cost += cfg.w_mean_kappa * (sumk / (double)S);
-                cost += cfg.w_similarity * sim;
-                if (hit) cost = __builtin_huge_val();
-            } else if (trow) {
-                for (int i = 0; i < 2 * S; ++i) reinterpret_cast<double2*>(trow)[i] = make_double2(0.0, 0.0);
+            if (cl.ok || staging) {                            // staging: every lane takes part in the coalesced flush
+                const int wave_c0 = cb + (wave << 6);
+                int n_valid = c1 - wave_c0;
+                n_valid = n_valid < 0 ? 0 : (n_valid > 64 ? 64 : n_valid);
+                F1P_LDS(f1p_d2)* stage = staging ? (F1P_LDS(f1p_d2)*)(stage_all + wave * 64 * F1P_STAGE_PITCH) : nullptr;
+                double* wave_out = staging ? a.all_traj + ((size_t)e * C + wave_c0) * (size_t)S * 4 : nullptr;
+                const double sk0 = cl.ok ? cl.k0 : 0.0, sdk = cl.ok ? cl.dk : 0.0, sL = cl.ok ? cl.L : 0.0;   // zero rows when infeasible
+                const StationResult sr = station_loop<STAGING>(sk0, sdk, sL, (const F1P_LDS(EgoParams)*)egp,
+                                                      (const F1P_LDS(uint32_t)*)tile, stage, wave_out, n_valid);
+                if (cl.ok) {
+                    const double maxk = sr.maxk, sumk = sr.sumk, sim = sr.sim;
+                    const bool hit = sr.hit != 0;
+                    cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
+                    cost += cfg.w_length * (1.0 / cl.L);
+                    cost += cfg.w_max_kappa * maxk;
+                    cost += cfg.w_mean_kappa * (sumk / (double)S);
+                    cost += cfg.w_similarity * sim;
+                    if (hit) cost = __builtin_huge_val();
+                }
             }
-            if (a.all_cost) a.all_cost[(size_t)e * C + c] = cost;
-            if (argmin_better(cost, c, bc, bi)) {             // this thread's best so far: park its clothoid in LDS, not in registers
-                bc = cost; bi = c;
-                slot[4 * tid] = cl.k0; slot[4 * tid + 1] = cl.dk; slot[4 * tid + 2] = cl.L; slot[4 * tid + 3] = cl.ok ? 1.0 : 0.0;
+            if (active) {
+                if (a.all_cost) a.all_cost[(size_t)e * C + c] = cost;
+                if (argmin_better(cost, c, bc, bi)) {         // this thread's best so far: park its clothoid in LDS, not in registers
+                    bc = cost; bi = c;
+                    slot[4 * tid] = cl.k0; slot[4 * tid + 1] = cl.dk; slot[4 * tid + 2] = cl.L; slot[4 * tid + 3] = cl.ok ? 1.0 : 0.0;
+                }
             }
         }
         // ---- 5. select(): argmin, first minimum wins ----------------------------------------------------
@@ -705,7 +752,10 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     size_t lds = sizeof(EgoParams) + sizeof(double) * (8 + 4 * 256 + 3 * F1P_MAX_LOOKAHEADS + 4 * (size_t)S) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
                  sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
     lds = (lds + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(k_lattice, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    a.stage_offset = (int)lds;
+    if (d_all_traj) lds += 16 * 4 * 64 * F1P_STAGE_PITCH;
+    if (d_all_traj) hipLaunchKernelGGL(k_lattice<true>, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    else hipLaunchKernelGGL(k_lattice<false>, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
     return check_hip(ctx, hipGetLastError(), "k_lattice launch");
 }
 
