@@ -41,7 +41,7 @@
 // materialised mode (all_traj requested): stations staged per wave in LDS and flushed as contiguous chunks of
 // F1P_STAGE_T rows (32 B each) per candidate instead of one 32-B row per lane at a 32*S-byte stride
 #ifndef F1P_K3_WAVES_STAGE
-#define F1P_K3_WAVES_STAGE 4
+#define F1P_K3_WAVES_STAGE 3
 #endif
 #ifndef F1P_STAGE_T
 #define F1P_STAGE_T 4
