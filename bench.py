@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--latency-iters", type=int, default=30, help="host-boundary plan() calls for p50/p95 (0 = skip)")
     ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc"], default="lattice",
                     help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
+    ap.add_argument("--generator", choices=["clothoid", "cubic"], default="clothoid",
+                    help="candidate generator: clothoid = the reference's (headline); cubic = cubic Hermite spline (secondary line)")
     ap.add_argument("--rollouts", type=int, default=512)
     ap.add_argument("--horizon", type=int, default=30)
     args = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     E, C, S = args.egos, args.cands, args.stations
-    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S, generator=args.generator)
     rl = synth.make_raceline(seed=0)
     res = 0.058
     img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=res)
@@ -160,7 +162,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batched lattice{' (all_traj materialised)' if materialised else ''}: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[2])",
                        "egos_per_gpu": E, "candidates": C, "stations": S, "raceline_points": int(rl.shape[0]),
-                       "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16),
+                       "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16), "generator": args.generator,
                        "parallelism": f"egos sharded over {world} GPU(s), no collective"},
             "per_gpu_value": value / world,
             "plan_latency_host_boundary": lat,

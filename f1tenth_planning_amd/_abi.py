@@ -17,6 +17,7 @@ MAX_LOOKAHEADS = 64
 MAX_WIDTHS = 64
 COMM_ID_BYTES = 128
 LA_IDX_NONE = -(2 ** 31)
+GEN_CLOTHOID, GEN_CUBIC = 0, 1
 
 
 class LatticeCfg(C.Structure):
@@ -24,7 +25,7 @@ class LatticeCfg(C.Structure):
     _fields_ = [
         ("n_stations", C.c_int32), ("n_lookahead", C.c_int32), ("n_width", C.c_int32),
         ("n_shift", C.c_int32), ("n_cull", C.c_int32), ("check_collision", C.c_int32),
-        ("cand_begin", C.c_int32), ("cand_count", C.c_int32),
+        ("cand_begin", C.c_int32), ("cand_count", C.c_int32), ("generator", C.c_int32), ("reserved0", C.c_int32),
         ("lookahead", C.c_double * MAX_LOOKAHEADS), ("width", C.c_double * MAX_WIDTHS),
         ("w_length", C.c_double), ("w_max_kappa", C.c_double), ("w_mean_kappa", C.c_double),
         ("w_similarity", C.c_double), ("track_lookahead", C.c_double), ("wheelbase", C.c_double),
@@ -48,7 +49,7 @@ class KmpcCfg(C.Structure):
 
 def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, weights=(1.0, 0.0, 0.0, 0.0),
                 n_shift=1, n_cull=1, check_collision=True, track_lookahead=0.8, wheelbase=0.33,
-                max_reacquire=20.0, cand_begin=0, cand_count=0):
+                max_reacquire=20.0, cand_begin=0, cand_count=0, generator="clothoid"):
     """Build a LatticeCfg.  Defaults are the reference's: look-aheads [0.4, 0.6, 0.8, 1.0] and
     widths linspace(-1, 1, 7) (lattice_planner.py:228-229), 100 stations (:197), tracker look-ahead 0.8
     (:211), tracker wheelbase 0.33 (:55), only the length cost runnable (:268-271)."""
@@ -70,6 +71,10 @@ def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, we
     cfg.check_collision = 1 if check_collision else 0
     cfg.cand_begin = int(cand_begin)
     cfg.cand_count = int(cand_count)
+    gens = {"clothoid": GEN_CLOTHOID, "cubic": GEN_CUBIC, GEN_CLOTHOID: GEN_CLOTHOID, GEN_CUBIC: GEN_CUBIC}
+    if generator not in gens:
+        raise ValueError("generator must be 'clothoid' or 'cubic'")
+    cfg.generator = gens[generator]
     for i, v in enumerate(lookaheads):
         cfg.lookahead[i] = v
     for i, v in enumerate(widths):

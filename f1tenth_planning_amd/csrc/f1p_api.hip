@@ -90,6 +90,7 @@ static int validate_lattice(f1p_ctx* ctx, const f1p_lattice_cfg* cfg, int E, boo
     const int C = cfg->n_lookahead * cfg->n_width;
     if (cfg->cand_begin < 0 || cfg->cand_count < 0 || cfg->cand_begin + cfg->cand_count > C || (cfg->cand_count == 0 && cfg->cand_begin != 0))
         return set_error(ctx, F1P_EINVAL, "candidate shard [cand_begin, cand_begin+cand_count) outside [0, C)");
+    if (cfg->generator != F1P_GEN_CLOTHOID && cfg->generator != F1P_GEN_CUBIC) return set_error(ctx, F1P_EINVAL, "unknown trajectory generator");
     if (ctx->n_wp < 2) return set_error(ctx, F1P_ESTATE, "waypoints not set: call f1p_set_waypoints first");
     if (device_goals && !ctx->has_psi) return set_error(ctx, F1P_ESTATE, "device goal sampling needs a heading column (col_psi >= 0)");
     return F1P_OK;

@@ -345,6 +345,38 @@ __device__ __forceinline__ PieceState piece_state_at(double k0, double dk, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Cubic-spline candidate generator (F1P_GEN_CUBIC): parametric cubic Hermite from pose (0,0,0) to the goal pose with
+// both tangents of magnitude m = chord length, stations at u_i = i/(S-1).  Same operation order as the oracle
+// (oracle/f1p_oracle.c orc_cubic_row), so everything except the library atan2 / sin / cos is bit-identical.
+// ---------------------------------------------------------------------------------------------------
+struct Cubic { double m, gx, gy, cx, cy; bool ok; };
+
+__device__ __forceinline__ Cubic cubic_setup(double gx, double gy, double gth) {
+    Cubic q;
+    q.m = __builtin_sqrt(gx * gx + gy * gy);
+    q.gx = gx; q.gy = gy;
+    q.cx = q.m * cos(gth); q.cy = q.m * sin(gth);
+    q.ok = (q.m > 1e-12) && isfinite(q.m) && isfinite(gth);
+    return q;
+}
+
+__device__ __forceinline__ void cubic_row(const Cubic& q, double u, double& x, double& y, double& th, double& ak) {
+    const double u2 = u * u, u3 = u2 * u;
+    const double h10 = (u3 - 2.0 * u2) + u, h01 = 3.0 * u2 - 2.0 * u3, h11 = u3 - u2;
+    const double d10 = (3.0 * u2 - 4.0 * u) + 1.0, d01 = 6.0 * u - 6.0 * u2, d11 = 3.0 * u2 - 2.0 * u;
+    const double e10 = 6.0 * u - 4.0, e01 = 6.0 - 12.0 * u, e11 = 6.0 * u - 2.0;
+    x = (h10 * q.m + h01 * q.gx) + h11 * q.cx;
+    y = h01 * q.gy + h11 * q.cy;
+    const double xd = (d10 * q.m + d01 * q.gx) + d11 * q.cx;
+    const double yd = d01 * q.gy + d11 * q.cy;
+    const double xdd = (e10 * q.m + e01 * q.gx) + e11 * q.cx;
+    const double ydd = e01 * q.gy + e11 * q.cy;
+    const double sp = xd * xd + yd * yd;
+    th = atan2(yd, xd);
+    ak = fabs(xd * ydd - yd * xdd) / (sp * __builtin_sqrt(sp));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Station loop of one candidate: sample_traj rows + occupancy test + the running cost terms.
 // Out of line on purpose: inside the kernel body the ~35 workgroup-uniform values it needs compete with kernel
 // arguments and the sincos constants for ~100 SGPRs, get spilled to VGPR lanes and come back through ~30
@@ -359,14 +391,15 @@ struct EgoParams {
     const uint32_t* bits;                      // global bitmap (off-tile samples)
     int tile_words, wwords, S, den, sim_m, n_shift, collide, pad;
 };
-struct StationResult { double maxk, sumk, sim; int hit; };
+struct StationResult { double maxk, sumk, sim, len; int hit; };
 
 #define F1P_LDS(T) __attribute__((address_space(3))) T
 
 // `stage` (materialised mode, else null): this wave's LDS staging tile [64][F1P_STAGE_PITCH] double2; `wave_out` = global
 // address of the rows of the wave's first candidate; `n_valid` = candidates of this wave that exist.  When staging, ALL 64
 // lanes must call this function together (invalid candidates pass a zero clothoid and produce zero rows).
-template <bool STAGING>
+// GEN = F1P_GEN_CLOTHOID: (k0, dk, L) is the fitted clothoid; GEN = F1P_GEN_CUBIC: (k0, dk, L) carries the goal pose (gx, gy, gth).
+template <bool STAGING, int GEN>
 __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, double L, const F1P_LDS(EgoParams)* ep,
                                                    const F1P_LDS(uint32_t)* tile, F1P_LDS(f1p_d2)* stage, double* wave_out,
                                                    int n_valid) {
@@ -385,16 +418,31 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
     const double tile_w = ep->tile_w, tile_h = ep->tile_h;
 #define F1P_EP(f) (f)
 #endif
-    const double ds = L / (double)ep->den;
-    const IntervalCoef ic = interval_setup(k0, dk, L, ds);
-    double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0;
+    double x = 0.0, y = 0.0, maxk = 0.0, sumk = 0.0, sim = 0.0, len = 0.0;
     bool hit = false;
+    // clothoid state
+    const double ds = GEN == F1P_GEN_CLOTHOID ? L / (double)ep->den : 0.0;
+    IntervalCoef ic;
     PieceState st;
     st.er = 1.0; st.ei = 0.0; st.rr = 1.0; st.ri = 0.0;   // piece 0 is an anchor: overwritten before use
+    if (GEN == F1P_GEN_CLOTHOID) ic = interval_setup(k0, dk, L, ds);
+    // cubic state
+    Cubic cq;
+    double xp = 0.0, yp = 0.0;
+    if (GEN == F1P_GEN_CUBIC) cq = cubic_setup(k0, dk, L);
+    const double inv_den = (double)ep->den;
     for (int i = 0; i < S; ++i) {
-        const double s = (double)i * ds;
-        const double th = s * (k0 + 0.5 * s * dk);
-        const double ak = fabs(k0 + dk * s);
+        double s = 0.0, th, ak;
+        if (GEN == F1P_GEN_CLOTHOID) {
+            s = (double)i * ds;
+            th = s * (k0 + 0.5 * s * dk);
+            ak = fabs(k0 + dk * s);
+        } else {
+            if (cq.ok) cubic_row(cq, (double)i / inv_den, x, y, th, ak);
+            else { x = 0.0; y = 0.0; th = 0.0; ak = 0.0; }   // infeasible candidate in the materialised mode: zero rows
+            if (i > 0) { const double ddx = x - xp, ddy = y - yp; len += __builtin_sqrt(ddx * ddx + ddy * ddy); }
+            xp = x; yp = y;
+        }
         if (ak > maxk) maxk = ak;
         sumk += ak;
         if (prev && i < sim_m) { const double d = th - prev[i + n_shift]; sim += d * d; }
@@ -435,13 +483,14 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
                 __builtin_amdgcn_wave_barrier();             // LDS ops of one wave execute in order: the next rows cannot overtake
             }
         }
-        if (i + 1 < S && !(F1P_K3_ABLATE & 1)) {
+        if (GEN == F1P_GEN_CLOTHOID && i + 1 < S && !(F1P_K3_ABLATE & 1)) {
             double dx, dy;
             interval_increment(k0, dk, s, i * ic.nsub, ic, st, dx, dy);
             x += dx; y += dy;
         }
     }
     r.maxk = maxk; r.sumk = sumk; r.sim = sim; r.hit = hit ? 1 : 0;
+    r.len = GEN == F1P_GEN_CLOTHOID ? L : len;
     return r;
 }
 
@@ -492,7 +541,7 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
 }
 
 // STAGING = materialised mode (all_traj requested): a second instantiation, so the fused kernel keeps its register budget
-template <bool STAGING>
+template <bool STAGING, int GEN>
 __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
@@ -594,10 +643,11 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
             const bool active = c < c1;
             double gx = 0.0, gy = 0.0, gth = 0.0;
             const bool gok = active && candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
-            Clothoid cl;
+            Clothoid cl;                                       // cubic generator: (k0, dk, L) carries the goal pose
             cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
             if (gok) {
-                if (F1P_K3_ABLATE & 4) { cl.ok = true; cl.k0 = 0.01 * gth; cl.dk = 0.01 * gy; cl.L = fabs(gx) + 1.0; }
+                if (GEN == F1P_GEN_CUBIC) { cl.k0 = gx; cl.dk = gy; cl.L = gth; cl.ok = cubic_setup(gx, gy, gth).ok; }
+                else if (F1P_K3_ABLATE & 4) { cl.ok = true; cl.k0 = 0.01 * gth; cl.dk = 0.01 * gy; cl.L = fabs(gx) + 1.0; }
                 else cl = g1_fit(gx, gy, gth);
             }
             double cost = __builtin_huge_val();
@@ -608,13 +658,13 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
                 F1P_LDS(f1p_d2)* stage = staging ? (F1P_LDS(f1p_d2)*)(stage_all + wave * 64 * F1P_STAGE_PITCH) : nullptr;
                 double* wave_out = staging ? a.all_traj + ((size_t)e * C + wave_c0) * (size_t)S * 4 : nullptr;
                 const double sk0 = cl.ok ? cl.k0 : 0.0, sdk = cl.ok ? cl.dk : 0.0, sL = cl.ok ? cl.L : 0.0;   // zero rows when infeasible
-                const StationResult sr = station_loop<STAGING>(sk0, sdk, sL, (const F1P_LDS(EgoParams)*)egp,
+                const StationResult sr = station_loop<STAGING, GEN>(sk0, sdk, sL, (const F1P_LDS(EgoParams)*)egp,
                                                       (const F1P_LDS(uint32_t)*)tile, stage, wave_out, n_valid);
                 if (cl.ok) {
                     const double maxk = sr.maxk, sumk = sr.sumk, sim = sr.sim;
                     const bool hit = sr.hit != 0;
                     cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
-                    cost += cfg.w_length * (1.0 / cl.L);
+                    cost += cfg.w_length * (1.0 / sr.len);
                     cost += cfg.w_max_kappa * maxk;
                     cost += cfg.w_mean_kappa * (sumk / (double)S);
                     cost += cfg.w_similarity * sim;
@@ -650,39 +700,54 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
 
     // ---- 6. re-emit the winner: every interval is independent -> one lane per interval -----------------
     if (wave != 0 || (F1P_K3_ABLATE & 8)) return;
-    Clothoid cl;
+    Clothoid cl;                                       // cubic generator: (k0, dk, L) carries the goal pose
     cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
     if (a.mode != LATTICE_EMIT) {
         if (bi != 0x7fffffff) { cl.k0 = win[0]; cl.dk = win[1]; cl.L = win[2]; cl.ok = win[3] != 0.0; }
     } else if (bi >= 0 && bi < C) {
         double gx, gy, gth;
-        if (candidate_goal(a, cfg, e, bi, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth))
-            cl = g1_fit(gx, gy, gth);
-    }
-    const double ds = cl.ok ? cl.L / (double)den : 0.0;
-    IntervalCoef ic;
-    if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
-    for (int i = lane; i < S - 1; i += 64) {
-        double dx = 0.0, dy = 0.0;
-        if (cl.ok) {
-            PieceState st = piece_state_at(cl.k0, cl.dk, ds, i, ic);
-            interval_increment(cl.k0, cl.dk, (double)i * ds, i * ic.nsub, ic, st, dx, dy);
+        if (candidate_goal(a, cfg, e, bi, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth)) {
+            if (GEN == F1P_GEN_CUBIC) { cl.k0 = gx; cl.dk = gy; cl.L = gth; cl.ok = cubic_setup(gx, gy, gth).ok; }
+            else cl = g1_fit(gx, gy, gth);
         }
-        inc_x[i] = dx; inc_y[i] = dy;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
-    __builtin_amdgcn_wave_barrier();
     double* bt = a.best_traj ? a.best_traj + (size_t)e * S * 4 : nullptr;
-    for (int i = lane; i < S; i += 64) {
-        double x = 0.0, y = 0.0;
-        for (int j = 0; j < i; ++j) { x += inc_x[j]; y += inc_y[j]; }   // same order as the evaluation loop
-        tr_x[i] = x; tr_y[i] = y;
-        if (bt) {
-            const double s = (double)i * ds;
-            const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
-            const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
-            reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
-            reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+    if (GEN == F1P_GEN_CUBIC) {
+        const Cubic cq = cubic_setup(cl.k0, cl.dk, cl.L);
+        for (int i = lane; i < S; i += 64) {             // closed form per station: nothing to accumulate
+            double x = 0.0, y = 0.0, th = 0.0, ak = 0.0;
+            if (cl.ok) cubic_row(cq, (double)i / (double)den, x, y, th, ak);
+            tr_x[i] = x; tr_y[i] = y;
+            if (bt) {
+                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
+                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+            }
+        }
+    } else {
+        const double ds = cl.ok ? cl.L / (double)den : 0.0;
+        IntervalCoef ic;
+        if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
+        for (int i = lane; i < S - 1; i += 64) {
+            double dx = 0.0, dy = 0.0;
+            if (cl.ok) {
+                PieceState st = piece_state_at(cl.k0, cl.dk, ds, i, ic);
+                interval_increment(cl.k0, cl.dk, (double)i * ds, i * ic.nsub, ic, st, dx, dy);
+            }
+            inc_x[i] = dx; inc_y[i] = dy;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < S; i += 64) {
+            double x = 0.0, y = 0.0;
+            for (int j = 0; j < i; ++j) { x += inc_x[j]; y += inc_y[j]; }   // same order as the evaluation loop
+            tr_x[i] = x; tr_y[i] = y;
+            if (bt) {
+                const double s = (double)i * ds;
+                const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
+                const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
+                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
+                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -754,8 +819,14 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     lds = (lds + 15) & ~(size_t)15;
     a.stage_offset = (int)lds;
     if (d_all_traj) lds += 16 * 4 * 64 * F1P_STAGE_PITCH;
-    if (d_all_traj) hipLaunchKernelGGL(k_lattice<true>, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
-    else hipLaunchKernelGGL(k_lattice<false>, dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    const bool cubic = cfg->generator == F1P_GEN_CUBIC;
+    if (d_all_traj) {
+        if (cubic) hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CUBIC>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+        else hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CLOTHOID>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    } else {
+        if (cubic) hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CUBIC>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+        else hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CLOTHOID>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+    }
     return check_hip(ctx, hipGetLastError(), "k_lattice launch");
 }
 

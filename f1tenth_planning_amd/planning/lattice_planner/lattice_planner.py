@@ -53,6 +53,7 @@ class LatticePlanner():
         self.device_weights = (1.0, 0.0, 0.0, 0.0)   # (1/length, max |kappa|, mean |kappa|, similarity)
         self.n_shift, self.n_cull = 1, 1
         self.check_collision = True
+        self.generator = "clothoid"          # "clothoid" (the reference's G1 clothoid, :196) or "cubic" (cubic Hermite spline)
         self.prev_traj = None
 
         self._device = device
@@ -80,7 +81,7 @@ class LatticePlanner():
 
     # ---- configuration of the built-in device path -------------------------------------------------------------
     def configure(self, lookahead_distances=None, widths=None, weights=None, num_stations=None, n_shift=None,
-                  n_cull=None, check_collision=None, track_lookahead=None):
+                  n_cull=None, check_collision=None, track_lookahead=None, generator=None):
         if lookahead_distances is not None:
             self.lookahead_distances = list(lookahead_distances)
         if widths is not None:
@@ -99,6 +100,10 @@ class LatticePlanner():
             self.check_collision = bool(check_collision)
         if track_lookahead is not None:
             self.track_lookahead = float(track_lookahead)
+        if generator is not None:
+            if generator not in ("clothoid", "cubic"):
+                raise ValueError("generator must be 'clothoid' or 'cubic'")
+            self.generator = generator
 
     def set_map(self, image, resolution, origin, occupied_thresh=0.65, negate=0):
         """Occupancy image in the ROS map_server layout (examples/control/Spielberg_map.yaml:1-6): u8 [h, w], row 0 at
@@ -179,7 +184,7 @@ class LatticePlanner():
                                 n_shift=self.n_shift, n_cull=self.n_cull,
                                 check_collision=self.check_collision and self._map is not None,
                                 track_lookahead=self.track_lookahead, wheelbase=self.tracker.wheelbase,
-                                max_reacquire=self.tracker.max_reacquire)
+                                max_reacquire=self.tracker.max_reacquire, generator=self.generator)
 
     def plan(self, pose_x, pose_y, pose_theta, velocity, waypoints=None, cost_weights=None):
         """

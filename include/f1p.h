@@ -46,6 +46,11 @@ extern "C" {
 #define F1P_ST_NO_LOOKAHEAD 2   /* no look-ahead point: (0.0, 0.0) + warning (pure_pursuit.py:112-114) */
 #define F1P_ST_ALL_BLOCKED 3    /* lattice: every candidate is in collision / infeasible               */
 
+/* candidate trajectory generators of the lattice planner */
+#define F1P_GEN_CLOTHOID 0      /* G1 Hermite clothoid, what the reference builds with pyclothoids (lattice_planner.py:196) */
+#define F1P_GEN_CUBIC 1         /* parametric cubic Hermite spline between the two poses (north_star "cubic-spline"):       */
+                                /*   tangent magnitude = chord length, stations at equal parameter steps u_i = i/(S-1)       */
+
 /* limits of the fixed-size config structs */
 #define F1P_MAX_LOOKAHEADS 64
 #define F1P_MAX_WIDTHS 64
@@ -67,6 +72,8 @@ typedef struct f1p_lattice_cfg {
     int32_t check_collision; /* 1: a station in an occupied / out-of-map cell makes the cost +inf           */
     int32_t cand_begin;      /* candidate shard [cand_begin, cand_begin + cand_count) evaluated by this     */
     int32_t cand_count;      /*   call; 0 count = all C (used when one ego's candidates span ranks)         */
+    int32_t generator;       /* F1P_GEN_CLOTHOID (the reference's G1 clothoid, :196) or F1P_GEN_CUBIC             */
+    int32_t reserved0;       /* keeps the doubles 8-byte aligned; must be 0                                  */
     double lookahead[F1P_MAX_LOOKAHEADS]; /* metres, circle radii for intersect_point                       */
     double width[F1P_MAX_WIDTHS];         /* metres, lateral offsets along the path normal                  */
     double w_length;         /* weight of 1/L                 (get_length_cost     :268-271)                */

@@ -365,6 +365,40 @@ static int orc_track_traj(const double* traj, int S, double lookahead, double wh
     return st;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* Cubic-spline candidate generator (north_star "clothoid/cubic-spline"; no reference code: BUILD-DEFINED)  */
+/* Parametric cubic Hermite from pose (0,0,0) to (gx, gy, gth), both tangents of magnitude m = chord length:  */
+/*   x(u) = h10 m + h01 gx + h11 m cos(gth),  y(u) = h01 gy + h11 m sin(gth),  u in [0, 1]                   */
+/* Rows like sample_traj: (x, y, theta = atan2(y', x'), |kappa| = |x'y'' - y'x''| / (x'^2 + y'^2)^1.5).       */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct orc_cubic { double m, gx, gy, cx, cy; int ok; } orc_cubic;
+
+ORC_API orc_cubic orc_cubic_setup(double gx, double gy, double gth) {
+    orc_cubic q;
+    q.m = sqrt(gx * gx + gy * gy);
+    q.gx = gx; q.gy = gy;
+    q.cx = q.m * cos(gth); q.cy = q.m * sin(gth);
+    q.ok = (q.m > 1e-12) && isfinite(q.m) && isfinite(gth);
+    return q;
+}
+
+ORC_API void orc_cubic_row(const orc_cubic* q, double u, double out[4]) {
+    double u2 = u * u, u3 = u2 * u;
+    double h10 = (u3 - 2.0 * u2) + u, h01 = 3.0 * u2 - 2.0 * u3, h11 = u3 - u2;
+    double d10 = (3.0 * u2 - 4.0 * u) + 1.0, d01 = 6.0 * u - 6.0 * u2, d11 = 3.0 * u2 - 2.0 * u;
+    double e10 = 6.0 * u - 4.0, e01 = 6.0 - 12.0 * u, e11 = 6.0 * u - 2.0;
+    double x = (h10 * q->m + h01 * q->gx) + h11 * q->cx;
+    double y = h01 * q->gy + h11 * q->cy;
+    double xd = (d10 * q->m + d01 * q->gx) + d11 * q->cx;
+    double yd = d01 * q->gy + d11 * q->cy;
+    double xdd = (e10 * q->m + e01 * q->gx) + e11 * q->cx;
+    double ydd = e01 * q->gy + e11 * q->cy;
+    double sp = xd * xd + yd * yd;
+    out[0] = x; out[1] = y;
+    out[2] = atan2(yd, xd);
+    out[3] = fabs(xd * ydd - yd * xdd) / (sp * sqrt(sp));
+}
+
 /* one candidate: fit, sample, cost.  Returns the cost (+inf when infeasible / in collision).
  * traj_out may be NULL. */
 static double orc_lattice_candidate(const double* goal, int goal_valid, double px, double py, double ct, double st,
@@ -373,11 +407,28 @@ static double orc_lattice_candidate(const double* goal, int goal_valid, double p
     int S = cfg->n_stations;
     double* tr = traj_out ? traj_out : scratch;
     double k0, dk, L;
-    if (!goal_valid || !orc_clothoid_g1(goal[0], goal[1], goal[2], &k0, &dk, &L)) {
-        for (int i = 0; i < 4 * S; ++i) tr[i] = 0.0;
-        return INFINITY;
+    if (cfg->generator == F1P_GEN_CUBIC) {
+        orc_cubic q = orc_cubic_setup(goal[0], goal[1], goal[2]);
+        if (!goal_valid || !q.ok) {
+            for (int i = 0; i < 4 * S; ++i) tr[i] = 0.0;
+            return INFINITY;
+        }
+        int den = S - 1 > 1 ? S - 1 : 1;
+        L = 0.0; /* polyline length of the sampled stations stands in for the arc length of the 1/L term */
+        for (int i = 0; i < S; ++i) {
+            orc_cubic_row(&q, (double)i / (double)den, &tr[4 * i]);
+            if (i > 0) {
+                double dx = tr[4 * i] - tr[4 * (i - 1)], dy = tr[4 * i + 1] - tr[4 * (i - 1) + 1];
+                L += sqrt(dx * dx + dy * dy);
+            }
+        }
+    } else {
+        if (!goal_valid || !orc_clothoid_g1(goal[0], goal[1], goal[2], &k0, &dk, &L)) {
+            for (int i = 0; i < 4 * S; ++i) tr[i] = 0.0;
+            return INFINITY;
+        }
+        orc_sample_traj(k0, dk, L, S, tr);
     }
-    orc_sample_traj(k0, dk, L, S, tr);
     double maxk = 0.0, sumk = 0.0, sim = 0.0;
     int collide = 0;
     for (int i = 0; i < S; ++i) {

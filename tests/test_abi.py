@@ -41,7 +41,7 @@ def test_struct_layout_matches_defaults():
     assert list(cfg.lookahead[:4]) == [0.4, 0.6, 0.8, 1.0] == list(ref.lookahead[:4])
     assert abs(cfg.width[0] + 1.0) < 1e-15 and cfg.width[6] == 1.0 and abs(cfg.width[3]) < 1e-15
     assert (cfg.track_lookahead, cfg.wheelbase, cfg.max_reacquire, cfg.w_length) == (0.8, 0.33, 20.0, 1.0)
-    assert C.sizeof(cfg) == 8 * 4 + 8 * 128 + 8 * 7
+    assert C.sizeof(cfg) == 10 * 4 + 8 * 128 + 8 * 7 and cfg.generator == 0
     k = _abi.KmpcCfg()
     lib.f1p_kmpc_cfg_default(C.byref(k))
     d = _abi.kmpc_cfg()

@@ -167,3 +167,34 @@ def test_lattice_full_size_properties(ctx, orc, scene):
     sub = np.arange(0, 4096, 16)
     want = orc.lattice_plan_batch(poses[sub], rl, cfg, grid=(img, 0.058, origin[0], origin[1], 206), nthreads=8)
     _compare({k: v[sub] for k, v in got.items()}, want)
+
+
+def test_cubic_generator_vs_oracle(ctx, orc, scene):
+    """north_star's second candidate generator: cubic Hermite splines.  Same operation order on both sides, so the rows are
+    identical up to the library atan2 / sin / cos (1e-12); selection indices and collision flags exact."""
+    rl, img, origin = scene
+    cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50, generator="cubic")
+    poses = synth.make_egos(rl, 160, seed=61)
+    poses[0, :2] += 400.0
+    prev = np.random.default_rng(2).normal(0, 0.1, (160, 50))
+    got = ctx.lattice_plan(poses, cfg, prev_theta=prev, want_all=True)
+    want = orc.lattice_plan_batch(poses, rl, cfg, grid=(img, 0.058, origin[0], origin[1], 206), prev_theta=prev, want_all=True, nthreads=8)
+    _compare(got, want, tol_traj=1e-12)
+    np.testing.assert_array_equal(np.isinf(got["all_cost"]), np.isinf(want["all_cost"]))
+    fin = np.isfinite(want["all_cost"])
+    np.testing.assert_allclose(got["all_cost"][fin], want["all_cost"][fin], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(got["all_traj"], want["all_traj"], rtol=0, atol=1e-12)
+    e = np.arange(len(poses))
+    np.testing.assert_array_equal(got["best_traj"], got["all_traj"][e, got["best_idx"]])
+    assert (got["best_traj"][1:, 0, :2] == 0).all()                          # every spline starts at the ego
+    clo = ctx.lattice_plan(poses, synth.bench_lattice_cfg(256, 50), prev_theta=prev)
+    assert np.abs(clo["best_traj"][1:, -1, :2] - got["best_traj"][1:, -1, :2]).max() < 2.1   # both end on the goal grid
+    # host goals + shards + emit path with the cubic generator
+    rng = np.random.default_rng(9)
+    goals = np.column_stack([rng.uniform(0.5, 3, 32), rng.uniform(-1, 1, 32), rng.uniform(-0.5, 0.5, 32)])
+    cfg2 = _abi.lattice_cfg(lookaheads=[1.0] * 4, widths=[0.0] * 8, n_stations=30, weights=(0.3, 0.3, 0.2, 0.2), generator="cubic")
+    g2 = ctx.lattice_plan(poses[1:9], cfg2, goals=np.broadcast_to(goals, (8, 32, 3)).copy())
+    w2 = orc.lattice_plan_batch(poses[1:9], rl, cfg2, grid=(img, 0.058, origin[0], origin[1], 206), goals=np.broadcast_to(goals, (8, 32, 3)).copy())
+    _compare(g2, w2, tol_traj=1e-12)
+    with pytest.raises(ValueError):
+        _abi.lattice_cfg(generator="bezier")
