@@ -122,6 +122,13 @@ class LatticePlanner():
         if self._ctx is not None:
             self._ctx.set_grid(*self._map)
 
+    def load_map(self, yaml_path):
+        """Read a ROS map_server YAML + image (examples/control/Spielberg_map.yaml) and install it as the occupancy grid."""
+        from ...io import load_map
+        m = load_map(yaml_path)
+        self.set_map(m["image"], m["resolution"], m["origin"], occupied_thresh=m["occupied_thresh"], negate=0)   # negate already applied
+        return m
+
     # ---- reference methods ------------------------------------------------------------------------------------------
     def sample(self, pose_x, pose_y, pose_theta, velocity, waypoints):
         """Goal grid [C, 3] from the registered sample function (:113-128)."""

@@ -103,3 +103,29 @@ def test_lattice_blocked_warning(scene):
         warnings.simplefilter("always")
         steer, speed, traj = lp.plan(500.0, 500.0, 0.0, 1.0)
         assert (steer, speed) == (0.0, 0.0) and any("blocked" in str(x.message) for x in w)
+
+
+def test_load_map_and_raceline_files(tmp_path, scene):
+    """On-disk formats end to end: a map_server YAML + PGM and a ';' CSV written to disk drive the planner like arrays do."""
+    from f1tenth_planning.planning.lattice_planner.lattice_planner import LatticePlanner
+    from f1tenth_planning_amd import io as fio
+    rl, img, origin = scene
+    with open(tmp_path / "track.pgm", "wb") as fh:
+        fh.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+    (tmp_path / "track.yaml").write_text(f"image: track.pgm\nresolution: 0.058\norigin: [{origin[0]!r}, {origin[1]!r}, 0.0]\nnegate: 0\n"
+                                         "occupied_thresh: 0.194\nfree_thresh: 0.1\n")
+    with open(tmp_path / "raceline.csv", "w") as fh:
+        fh.write("# x_m; y_m; vx_mps; psi_rad; kappa_radpm\n")
+        for r in rl:
+            fh.write(";".join(repr(float(v)) for v in r) + "\n")
+    wp = fio.load_raceline(str(tmp_path / "raceline.csv"))
+    np.testing.assert_array_equal(wp, rl)
+    a = LatticePlanner(waypoints=wp)
+    m = a.load_map(str(tmp_path / "track.yaml"))
+    assert m["occupied_below"] == 206                     # 255 * (1 - 0.194) = 205.53 -> values < 206 are occupied
+    b = LatticePlanner(waypoints=rl)
+    b.set_map(img, 0.058, origin, occupied_thresh=1.0 - 205.5 / 255.0)
+    pose = synth.make_egos(rl, 1, seed=71)[0]
+    ra, rb = a.plan(*pose), b.plan(*pose)
+    assert ra[0] == rb[0] and ra[1] == rb[1]
+    np.testing.assert_array_equal(ra[2], rb[2])
