@@ -47,6 +47,33 @@ class KmpcCfg(C.Structure):
     ]
 
 
+class StmpcCfg(C.Structure):
+    """struct f1p_stmpc_cfg (include/f1p.h)"""
+    _fields_ = [
+        ("horizon", C.c_int32), ("n_rollouts", C.c_int32),
+        ("dt", C.c_double), ("wheelbase", C.c_double), ("max_steer", C.c_double), ("max_steer_v", C.c_double),
+        ("max_speed", C.c_double), ("min_speed", C.c_double), ("max_accel", C.c_double),
+        ("q", C.c_double * 7), ("qf", C.c_double * 7), ("r", C.c_double * 2), ("rd", C.c_double * 2), ("params", C.c_double * 8),
+    ]
+
+
+def stmpc_cfg(horizon=40, n_rollouts=512, dt=0.025, wheelbase=0.33, max_steer=0.4189, max_steer_v=3.2, max_speed=6.0,
+              min_speed=0.0, max_accel=3.0, q=(32.0, 32.0, 0.0, 1.0, 0.5, 0.0, 0.0), qf=(32.0, 32.0, 0.0, 1.0, 0.5, 0.0, 0.0),
+              r=(0.5, 0.01), rd=(0.3, 0.01), params=(3.74, 0.15875, 0.17145, 0.074, 4.718, 5.4562, 0.04712, 1.0489)):
+    """Build a StmpcCfg with the defaults of dynamic_mpc.py's mpc_config (:40-86) and STMPCPlanner's vehicle parameters."""
+    cfg = StmpcCfg()
+    cfg.horizon, cfg.n_rollouts = int(horizon), int(n_rollouts)
+    cfg.dt, cfg.wheelbase, cfg.max_steer, cfg.max_steer_v = float(dt), float(wheelbase), float(max_steer), float(max_steer_v)
+    cfg.max_speed, cfg.min_speed, cfg.max_accel = float(max_speed), float(min_speed), float(max_accel)
+    for i in range(7):
+        cfg.q[i] = float(q[i]); cfg.qf[i] = float(qf[i])
+    for i in range(2):
+        cfg.r[i] = float(r[i]); cfg.rd[i] = float(rd[i])
+    for i in range(8):
+        cfg.params[i] = float(params[i])
+    return cfg
+
+
 def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, weights=(1.0, 0.0, 0.0, 0.0),
                 n_shift=1, n_cull=1, check_collision=True, track_lookahead=0.8, wheelbase=0.33,
                 max_reacquire=20.0, cand_begin=0, cand_count=0, generator="clothoid"):
@@ -144,6 +171,11 @@ PROTOTYPES = {
     "f1p_kmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(KmpcCfg), _P]),
     "f1p_kmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),
     "f1p_kmpc_sample_controls_dev": (C.c_int, [_P, _P, _I, C.POINTER(KmpcCfg), C.c_uint64, _D, _D]),
+    "f1p_stmpc_cfg_default": (None, [C.POINTER(StmpcCfg)]),
+    "f1p_stmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P]),
+    "f1p_stmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),
+    "f1p_stmpc_shoot_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P, _P, _P, _P, _P]),
+    "f1p_stmpc_shoot_dev": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P, _P, _P, _P, _P]),
     "f1p_comm_unique_id": (C.c_int, [_P, _P]),
     "f1p_comm_init": (C.c_int, [_P, _P, _I, _I]),
     "f1p_comm_destroy": (C.c_int, [_P]),

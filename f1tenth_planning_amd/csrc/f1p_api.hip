@@ -650,5 +650,95 @@ int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E)
     return F1P_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// dynamic single-track shooting
+// ---------------------------------------------------------------------------------------------------
+void f1p_stmpc_cfg_default(f1p_stmpc_cfg* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->horizon = 40; cfg->n_rollouts = 512;
+    cfg->dt = 0.025; cfg->wheelbase = 0.33; cfg->max_steer = 0.4189; cfg->max_steer_v = 3.2;
+    cfg->max_speed = 6.0; cfg->min_speed = 0.0; cfg->max_accel = 3.0;
+    const double q[7] = {32.0, 32.0, 0.0, 1.0, 0.5, 0.0, 0.0};
+    for (int i = 0; i < 7; ++i) { cfg->q[i] = q[i]; cfg->qf[i] = q[i]; }
+    cfg->r[0] = 0.5; cfg->r[1] = 0.01; cfg->rd[0] = 0.3; cfg->rd[1] = 0.01;
+    const double p[8] = {3.74, 0.15875, 0.17145, 0.074, 4.718, 5.4562, 0.04712, 1.0489};
+    for (int i = 0; i < 8; ++i) cfg->params[i] = p[i];
+}
+
+static int validate_stmpc(f1p_ctx* ctx, const f1p_stmpc_cfg* cfg, int E) {
+    if (!cfg) return set_error(ctx, F1P_EINVAL, "cfg is NULL");
+    if (E < 0) return set_error(ctx, F1P_EINVAL, "E must be >= 0");
+    if (cfg->horizon < 1 || cfg->horizon > 4096) return set_error(ctx, F1P_EINVAL, "horizon must be in [1, 4096]");
+    if (cfg->n_rollouts < 1) return set_error(ctx, F1P_EINVAL, "n_rollouts must be >= 1");
+    if (!(cfg->dt > 0) || !(cfg->wheelbase > 0)) return set_error(ctx, F1P_EINVAL, "dt and wheelbase must be > 0");
+    return F1P_OK;
+}
+
+int f1p_stmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od_v, int32_t E,
+                            const f1p_stmpc_cfg* cfg, double* path) {
+    F1P_ENTER(ctx);
+    int rc = validate_stmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!x0 || !oa || !od_v || !path)) return set_error(ctx, F1P_EINVAL, "x0, oa, od_v and path are required");
+    const size_t T = cfg->horizon, e = E;
+    Stage s(ctx);
+    s.need(8 * 7 * e); s.need(8 * e * T); s.need(8 * e * T); s.need(8 * e * 7 * (T + 1));
+    if ((rc = s.begin())) return rc;
+    const double *d_x0, *d_oa, *d_od;
+    if ((rc = s.in(x0, 7 * e, &d_x0))) return rc;
+    if ((rc = s.in(oa, e * T, &d_oa))) return rc;
+    if ((rc = s.in(od_v, e * T, &d_od))) return rc;
+    double* d_path = s.out(path, e * 7 * (T + 1));
+    if ((rc = launch_stmpc_predict(ctx, d_x0, d_oa, d_od, E, cfg, d_path))) return rc;
+    return s.finish();
+}
+
+int f1p_stmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl, double* ref) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!states || !ref))) return set_error(ctx, F1P_EINVAL, "bad states / ref / E");
+    if (horizon < 1 || !(dt > 0) || !(dl > 0)) return set_error(ctx, F1P_EINVAL, "horizon, dt and dl must be positive");
+    if (ctx->n_wp < 2 || !ctx->has_psi) return set_error(ctx, F1P_ESTATE, "waypoints with a heading column are required");
+    Stage s(ctx);
+    s.need(8 * 4 * (size_t)E); s.need(8 * (size_t)E * 7 * (horizon + 1));
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_s;
+    if ((rc = s.in(states, (size_t)4 * E, &d_s))) return rc;
+    double* d_ref = s.out(ref, (size_t)E * 7 * (horizon + 1));
+    if ((rc = launch_stmpc_ref(ctx, d_s, E, horizon, dt, dl, d_ref))) return rc;
+    return s.finish();
+}
+
+int f1p_stmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,
+                        const f1p_stmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                        double* d_best_cost, double* d_best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_stmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!d_x0 || !d_ref || !d_controls || !d_steer || !d_speed || !d_best_idx))
+        return set_error(ctx, F1P_EINVAL, "x0, ref, controls, steer, speed and best_idx are required");
+    return launch_stmpc_shoot(ctx, d_x0, d_ref, d_controls, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
+}
+
+int f1p_stmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, const float* controls, int32_t E,
+                          const f1p_stmpc_cfg* cfg, double* steer, double* speed, int32_t* best_idx, double* best_cost,
+                          double* best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_stmpc(ctx, cfg, E); if (rc) return rc;
+    if (E > 0 && (!x0 || !ref || !controls || !steer || !speed || !best_idx))
+        return set_error(ctx, F1P_EINVAL, "x0, ref, controls, steer, speed and best_idx are required");
+    const size_t T = cfg->horizon, R = cfg->n_rollouts, e = E;
+    Stage s(ctx);
+    s.need(8 * 7 * e); s.need(8 * e * 7 * (T + 1)); s.need(4 * e * T * 2 * R);
+    s.need(8 * e); s.need(8 * e); s.need(4 * e); s.need(8 * e, best_cost); s.need(8 * e * T * 2, best_seq);
+    if ((rc = s.begin())) return rc;
+    const double *d_x0, *d_ref; const float* d_c;
+    if ((rc = s.in(x0, 7 * e, &d_x0))) return rc;
+    if ((rc = s.in(ref, e * 7 * (T + 1), &d_ref))) return rc;
+    if ((rc = s.in(controls, e * T * 2 * R, &d_c))) return rc;
+    double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
+    double* d_bc = s.out(best_cost, e); double* d_bs = s.out(best_seq, e * T * 2);
+    if ((rc = launch_stmpc_shoot(ctx, d_x0, d_ref, d_c, E, cfg, d_steer, d_speed, d_bi, d_bc, d_bs))) return rc;
+    return s.finish();
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -85,6 +85,10 @@ int launch_stanley(f1p_ctx* ctx, const double* d_states, int E, double wheelbase
                    double* d_speed, int32_t* d_near);
 int launch_lqr(f1p_ctx* ctx, const double* d_states, double* d_err, int E, double wheelbase, double ts, const double* q,
                double r, int max_iter, double eps, double* d_steer, double* d_speed, int32_t* d_near);
+int launch_stmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, const double* d_od, int E, const f1p_stmpc_cfg* cfg, double* d_path);
+int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E, const f1p_stmpc_cfg* cfg,
+                       double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, double* d_best_seq);
+int launch_stmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);
 int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E);
 
 }  // namespace f1p

@@ -285,6 +285,35 @@ class Context:
         self._check(self.lib.f1p_kmpc_sample_controls_dev(self.h, d_controls.ptr, int(E), C.byref(cfg),
                                                           C.c_uint64(int(seed)), float(sigma_accel), float(sigma_steer)))
 
+    # ---- dynamic single-track shooting ------------------------------------------------------
+    def stmpc_predict(self, x0, oa, od_v, cfg):
+        """predict_motion (dynamic_mpc.py:280-300) for E egos -> path [E, 7, T+1]"""
+        x0 = _f64(x0, (-1, 7)); E = x0.shape[0]; T = cfg.horizon
+        oa = _f64(oa, (E, T)); od = _f64(od_v, (E, T))
+        path = np.empty((E, 7, T + 1))
+        self._check(self.lib.f1p_stmpc_predict_batch(self.h, _ptr(x0), _ptr(oa), _ptr(od), E, C.byref(cfg), _ptr(path)))
+        return path
+
+    def stmpc_ref(self, states, horizon, dt=0.025, dl=0.03):
+        st = _f64(states, (-1, 4)); E = st.shape[0]
+        ref = np.empty((E, 7, horizon + 1))
+        self._check(self.lib.f1p_stmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
+        return ref
+
+    def stmpc_shoot(self, x0, ref, controls, cfg, want_seq=True):
+        x0 = _f64(x0, (-1, 7)); E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
+        ref = _f64(ref, (E, 7, T + 1))
+        controls = np.ascontiguousarray(controls, dtype=np.float32)
+        if controls.shape != (E, T, 2, R):
+            raise ValueError(f"controls must be f32 [E={E}, T={T}, 2, R={R}]")
+        out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E))
+        if want_seq:
+            out["best_seq"] = np.empty((E, T, 2))
+        self._check(self.lib.f1p_stmpc_shoot_batch(self.h, _ptr(x0), _ptr(ref), _ptr(controls), E, C.byref(cfg), _ptr(out["steer"]),
+                                                   _ptr(out["speed"]), _ptr(out["best_idx"]), _ptr(out["best_cost"]),
+                                                   _ptr(out.get("best_seq"))))
+        return out
+
     # ---- multi-GPU exchange step -----------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()

@@ -106,6 +106,29 @@ typedef struct f1p_kmpc_cfg {
     double rd[2];            /* diag Rdk = [0.01, 100]                                                      */
 } f1p_kmpc_cfg;
 
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic single-track shooting configuration: the numeric content of `mpc_config` of
+ * control/dynamic_mpc/dynamic_mpc.py:40-86 that update_state (:317-404) and the objective (:616-622) use.
+ * State z = [x, y, delta, v, yaw, yaw rate, beta]; input u = [steering speed, accel].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct f1p_stmpc_cfg {
+    int32_t horizon;         /* T = 40                                                                      */
+    int32_t n_rollouts;      /* R candidate control sequences per ego                                       */
+    double dt;               /* DT = 0.025                                                                  */
+    double wheelbase;        /* WB = 0.33                                                                   */
+    double max_steer;        /* MAX_STEER = 0.4189                                                          */
+    double max_steer_v;      /* MAX_STEER_V = 3.2 rad/s (input bound AND the bound on its change, :685)     */
+    double max_speed;        /* MAX_SPEED = 6                                                               */
+    double min_speed;        /* MIN_SPEED = 0                                                               */
+    double max_accel;        /* MAX_ACCEL = 3                                                               */
+    double q[7];             /* diag Q  = [32, 32, 0, 1, 0.5, 0, 0]                                         */
+    double qf[7];            /* diag Qf = [32, 32, 0, 1, 0.5, 0, 0]                                         */
+    double r[2];             /* diag R  = [0.5, 0.01]  (steering speed, accel)                              */
+    double rd[2];            /* diag Rd = [0.3, 0.01]                                                       */
+    double params[8];        /* mass, l_f, l_r, h_CoG, c_f, c_r, Iz, mu  (STMPCPlanner.__init__ default)    */
+} f1p_stmpc_cfg;
+void f1p_stmpc_cfg_default(f1p_stmpc_cfg* cfg);
+
 /* fill the structs with the reference defaults (lattice: 4 look-aheads x 7 widths, S = 100) */
 void f1p_lattice_cfg_default(f1p_lattice_cfg* cfg);
 void f1p_kmpc_cfg_default(f1p_kmpc_cfg* cfg);
@@ -269,6 +292,23 @@ int f1p_kmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t ho
  * accel ~ clip(N(0, sigma_a), +-max_accel), steer ~ clip(N(0, sigma_d), +-max_steer) */
 int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const f1p_kmpc_cfg* cfg,
                                  uint64_t seed, double sigma_accel, double sigma_steer);
+
+/* ------------------------------------------------------------------------------------------------
+ * SURVEY.md 8f rank 2 -- the dynamic single-track model as a second model for shooting MPC
+ * (control/dynamic_mpc/dynamic_mpc.py): predict_motion / update_state (:280-404), calc_ref_trajectory (:195-233),
+ * objective :616-622, bounds :685-706, output map :1112-1117.
+ *   x0 [E][7]; oa / od_v [E][T] fp64; path [E][7][T+1]; states [E][4] = (x, y, v, yaw); ref [E][7][T+1];
+ *   controls [E][T][2][R] f32 = (steering speed, accel), rollout index fastest.
+ * ---------------------------------------------------------------------------------------------- */
+int f1p_stmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od_v, int32_t E,
+                            const f1p_stmpc_cfg* cfg, double* path);
+int f1p_stmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl, double* ref);
+int f1p_stmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, const float* controls, int32_t E,
+                          const f1p_stmpc_cfg* cfg, double* steer, double* speed, int32_t* best_idx, double* best_cost,
+                          double* best_seq);
+int f1p_stmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,
+                        const f1p_stmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                        double* d_best_cost, double* d_best_seq);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU: egos shard with no communication (one ctx per rank).  Only when ONE ego's candidate set is

@@ -791,3 +791,136 @@ ORC_API void orc_lqr_batch(const double* states /*E x 4*/, double* err /*E x 2*/
         if (near_idx) near_idx[e] = ti;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* dynamic single-track model of control/dynamic_mpc/dynamic_mpc.py              */
+/* state = [x, y, delta, v, yaw, yawrate, beta], input = [steering speed, accel]                      */
+/* ------------------------------------------------------------------------------------------------ */
+/* update_state :317-404 */
+ORC_API void orc_update_state_dynamic(double* s, double a, double delta_v, const f1p_stmpc_cfg* c) {
+    const double* p = c->params;
+    double mass = p[0], l_f = p[1], l_r = p[2], h_cog = p[3], c_f = p[4], c_r = p[5], iz = p[6], mu = p[7];
+    double g = 9.81;
+    if (delta_v >= c->max_steer_v) delta_v = c->max_steer_v;          /* :330-333 */
+    else if (delta_v <= -c->max_steer_v) delta_v = -c->max_steer_v;
+    if (a >= c->max_accel) a = c->max_accel;                          /* :336-339 */
+    else if (a <= -c->max_accel) a = -c->max_accel;
+    double K = (mu * mass) / ((l_f + l_r) * iz);                      /* :342-348 */
+    double T = (g * l_r) - (a * h_cog);
+    double V = (g * l_f) + (a * h_cog);
+    double F = l_f * c_f;
+    double R = l_r * c_r;
+    double M = (mu * c_f) / (l_f + l_r);
+    double N = (mu * c_r) / (l_f + l_r);
+    double A1 = K * F * T;                                            /* :350-355 */
+    double A2 = K * (R * V - F * T);
+    double A3 = K * (l_f * l_f * c_f * T + l_r * l_r * c_r * V);
+    double A4 = M * T;
+    double A5 = N * V + M * T;
+    double A6 = N * V * l_r - M * T * l_f;
+    double x = s[0], y = s[1], delta = s[2], v = s[3], yaw = s[4], yr = s[5], beta = s[6];
+    double x_new = x + v * cos(yaw + beta) * c->dt;                   /* :358 */
+    double y_new = y + v * sin(yaw + beta) * c->dt;                   /* :359 */
+    double delta_new = delta + delta_v * c->dt;                       /* :360 */
+    double v_new = v + a * c->dt;                                     /* :361 */
+    double yaw_new = yaw + v / c->wheelbase * tan(delta) * c->dt;     /* :362-365 */
+    double yr_new = yr + (A1 * delta + A2 * beta - A3 * (yr / v)) * c->dt;                                  /* :367-371 */
+    double beta_new = beta + (A4 * (delta / v) - A5 * (beta / v) + A6 * (yr / (v * v)) - yr) * c->dt;       /* :372-381 */
+    if (v_new > c->max_speed) v_new = c->max_speed;                   /* :393-396 */
+    else if (v_new < c->min_speed) v_new = c->min_speed;
+    if (delta_new >= c->max_steer) delta_new = c->max_steer;          /* :399-402 */
+    else if (delta_new <= -c->max_steer) delta_new = -c->max_steer;
+    s[0] = x_new; s[1] = y_new; s[2] = delta_new; s[3] = v_new; s[4] = yaw_new; s[5] = yr_new; s[6] = beta_new;
+}
+
+/* predict_motion :280-300: path [7][T+1] */
+ORC_API void orc_predict_motion_dynamic(const double* x0, const double* oa, const double* od_v, const f1p_stmpc_cfg* c, double* path) {
+    int T = c->horizon;
+    double s[7];
+    for (int k = 0; k < 7; ++k) { s[k] = x0[k]; path[k * (T + 1)] = x0[k]; }
+    for (int i = 1; i <= T; ++i) {
+        orc_update_state_dynamic(s, oa[i - 1], od_v[i - 1], c);
+        for (int k = 0; k < 7; ++k) path[k * (T + 1) + i] = s[k];
+    }
+}
+
+/* calc_ref_trajectory :195-233: ref [7][T+1], rows x, y, (delta = 0), v, yaw, (yawrate = 0), (beta = 0); the yaw fix-up
+ * threshold is 5 here (4.5 in the kinematic planner) */
+ORC_API void orc_calc_ref_trajectory_dynamic(double sx, double sy, double sv, double syaw, const double* cx, const double* cy,
+                                             double* cyaw_work, const double* sp, int n, int T, double dt, double dl, double* ref) {
+    int ind;
+    orc_nearest_point(sx, sy, cx, cy, n, NULL, NULL, NULL, &ind);
+    double dind = (fabs(sv) * dt) / dl;
+    for (int i = 0; i < n; ++i)
+        if (cyaw_work[i] - syaw > 5) cyaw_work[i] = fabs(cyaw_work[i] - (2 * M_PI));
+    for (int i = 0; i < n; ++i)
+        if (cyaw_work[i] - syaw < -5) cyaw_work[i] = fabs(cyaw_work[i] + (2 * M_PI));
+    for (int k = 0; k < 7 * (T + 1); ++k) ref[k] = 0.0;
+    double cum = 0.0;
+    for (int j = 0; j <= T; ++j) {
+        if (j > 0) cum += dind;
+        int il = ind + (int)cum;
+        if (il >= n) il -= n;
+        if (il < 0) il = 0;
+        if (il >= n) il = n - 1;   /* the reference would raise IndexError; clamp (same rule as the kernel) */
+        ref[0 * (T + 1) + j] = cx[il];
+        ref[1 * (T + 1) + j] = cy[il];
+        ref[3 * (T + 1) + j] = sp[il];
+        ref[4 * (T + 1) + j] = cyaw_work[il];
+    }
+}
+
+/* shooting objective for one rollout (BUILD-DEFINED driver; arithmetic of :616-622 on the nonlinear rollout) */
+ORC_API double orc_stmpc_rollout_cost(const double* x0, const double* ref /*[7][T+1]*/, const float* ctrl_dv, const float* ctrl_a,
+                                      size_t stride, const f1p_stmpc_cfg* c, double* seq_out) {
+    int T = c->horizon;
+    double s[7];
+    for (int k = 0; k < 7; ++k) s[k] = x0[k];
+    double cost = 0.0, pdv = 0.0, pa = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double dv = (double)ctrl_dv[(size_t)t * stride], a = (double)ctrl_a[(size_t)t * stride];
+        if (dv > c->max_steer_v) dv = c->max_steer_v; else if (dv < -c->max_steer_v) dv = -c->max_steer_v;   /* :701-703 */
+        if (a > c->max_accel) a = c->max_accel; else if (a < -c->max_accel) a = -c->max_accel;               /* :704-706 */
+        if (t > 0) { if (dv > pdv + c->max_steer_v) dv = pdv + c->max_steer_v; else if (dv < pdv - c->max_steer_v) dv = pdv - c->max_steer_v; } /* :685 */
+        double q = 0.0;
+        for (int k = 0; k < 7; ++k) { double e = s[k] - ref[k * (T + 1) + t]; q += c->q[k] * e * e; }
+        cost += q;
+        cost += c->r[0] * dv * dv + c->r[1] * a * a;
+        if (t > 0) { double d0 = dv - pdv, d1 = a - pa; cost += c->rd[0] * d0 * d0 + c->rd[1] * d1 * d1; }
+        if (seq_out) { seq_out[2 * t] = dv; seq_out[2 * t + 1] = a; }
+        orc_update_state_dynamic(s, a, dv, c);
+        pdv = dv; pa = a;
+    }
+    double q = 0.0;
+    for (int k = 0; k < 7; ++k) { double e = s[k] - ref[k * (T + 1) + T]; q += c->qf[k] * e * e; }
+    cost += q;
+    return cost;
+}
+
+/* x0 [E][7], ref [E][7][T+1], controls [E][T][2][R] f32 (steering speed, accel) */
+ORC_API void orc_stmpc_shoot_batch(const double* x0, const double* ref, const float* controls, int E, const f1p_stmpc_cfg* c,
+                                   double* steer, double* speed, int32_t* best_idx, double* best_cost, double* best_seq, int nthreads) {
+    int T = c->horizon, R = c->n_rollouts;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        const float* ce = &controls[(size_t)e * T * 2 * R];
+        const double* re = &ref[(size_t)e * 7 * (T + 1)];
+        double bc = 0.0;
+        int bi = -1;
+        for (int r = 0; r < R; ++r) {
+            double cost = orc_stmpc_rollout_cost(&x0[7 * e], re, ce + r, ce + R + r, (size_t)2 * R, c, NULL);
+            if (bi < 0 || cost < bc || (isnan(cost) && !isnan(bc))) { bc = cost; bi = r; }
+        }
+        double* seq = (double*)malloc(sizeof(double) * 2 * (size_t)T);
+        (void)orc_stmpc_rollout_cost(&x0[7 * e], re, ce + bi, ce + R + bi, (size_t)2 * R, c, seq);
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+        steer[e] = x0[7 * e + 2] + seq[0] * c->dt;   /* :1112 steer_output = delta + odelta_v[0] * DT */
+        speed[e] = x0[7 * e + 3] + seq[1] * c->dt;   /* :1117 speed_output = v + oa[0] * DT        */
+        if (best_seq) memcpy(&best_seq[(size_t)e * T * 2], seq, sizeof(double) * 2 * (size_t)T);
+        free(seq);
+    }
+}

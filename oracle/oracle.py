@@ -246,3 +246,38 @@ def lqr_batch(states, err, waypoints, wheelbase=0.33, ts=0.01, q=(0.999, 0.0, 0.
                         C.c_int(max_iter), C.c_double(eps), _p(wx), _p(wy), _p(wv), _p(wpsi), _p(wk), C.c_int(len(wx)),
                         _p(steer), _p(speed), _p(ni))
     return dict(steer=steer, speed=speed, near_idx=ni, err=err)
+
+
+# ---- dynamic single-track model -----------------------------------------------------------
+def update_state_dynamic(state, a, delta_v, cfg):
+    s = _f64(state).copy()
+    lib().orc_update_state_dynamic(_p(s), C.c_double(a), C.c_double(delta_v), C.byref(cfg))
+    return s
+
+
+def predict_motion_dynamic(x0, oa, od_v, cfg):
+    x0 = _f64(x0); oa = _f64(oa); od = _f64(od_v)
+    path = np.zeros((7, cfg.horizon + 1))
+    lib().orc_predict_motion_dynamic(_p(x0), _p(oa), _p(od), C.byref(cfg), _p(path))
+    return path
+
+
+def calc_ref_trajectory_dynamic(state, cx, cy, cyaw, sp, T, dt=0.025, dl=0.03):
+    """dynamic_mpc.py:195-233; state = (x, y, v, yaw) -> ref [7, T+1]"""
+    cx, cy, sp = _f64(cx), _f64(cy), _f64(sp)
+    cw = _f64(cyaw).copy()
+    ref = np.zeros((7, T + 1))
+    lib().orc_calc_ref_trajectory_dynamic(C.c_double(state[0]), C.c_double(state[1]), C.c_double(state[2]), C.c_double(state[3]),
+                                          _p(cx), _p(cy), _p(cw), _p(sp), C.c_int(len(cx)), C.c_int(T), C.c_double(dt),
+                                          C.c_double(dl), _p(ref))
+    return ref
+
+
+def stmpc_shoot_batch(x0, ref, controls, cfg, nthreads=1):
+    x0 = _f64(x0); ref = _f64(ref); controls = np.ascontiguousarray(controls, dtype=np.float32)
+    E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
+    assert controls.shape == (E, T, 2, R) and ref.shape == (E, 7, T + 1)
+    out = dict(steer=np.zeros(E), speed=np.zeros(E), best_idx=np.zeros(E, np.int32), best_cost=np.zeros(E), best_seq=np.zeros((E, T, 2)))
+    lib().orc_stmpc_shoot_batch(_p(x0), _p(ref), _p(controls), C.c_int(E), C.byref(cfg), _p(out["steer"]), _p(out["speed"]),
+                                _p(out["best_idx"]), _p(out["best_cost"]), _p(out["best_seq"]), C.c_int(nthreads))
+    return out

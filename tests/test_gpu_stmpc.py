@@ -1,0 +1,74 @@
+"""Dynamic single-track model on the MI355X: update_state / predict_motion / calc_ref_trajectory
+against golden vectors captured from the reference's dynamic_mpc.py, shooting against the CPU oracle.
+Bar: reference-trajectory gathers and best-rollout indices exact; rollouts 1e-10 relative (40 steps through sin/cos/tan)."""
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from f1tenth_planning_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_dynamic_model_golden(ctx, golden, tracks):
+    g = golden("g12_dynamic_model.npz")
+    cfg = _abi.stmpc_cfg()
+    path = ctx.stmpc_predict(g["dyn_roll_x0"], g["dyn_roll_oa"], g["dyn_roll_od"], cfg)
+    np.testing.assert_allclose(path, g["dyn_roll_path"], rtol=1e-11, atol=1e-10)
+    c1 = _abi.stmpc_cfg(horizon=1)
+    p1 = ctx.stmpc_predict(g["dyn_step_state"], g["dyn_step_a"][:, None], g["dyn_step_dv"][:, None], c1)   # update_state :317-404
+    np.testing.assert_allclose(p1[:, :, 1], g["dyn_step_out"], rtol=0, atol=1e-12)
+    ctx.set_waypoints(tracks["levine"], cols=(1, 2, 5, 3))
+    ref = ctx.stmpc_ref(g["dyn_ref_state"], cfg.horizon)
+    np.testing.assert_array_equal(ref, g["dyn_ref_out"])
+
+
+def test_stmpc_shoot_vs_oracle(ctx, orc):
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(14)
+    E, T, R = 64, 40, 512
+    k = rng.integers(0, len(cl) - 1, E)
+    x0 = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.normal(0, 0.1, E),
+                          rng.uniform(2.2, 5.5, E), cl[k, 3] + rng.normal(0, 0.1, E), rng.normal(0, 0.3, E), rng.normal(0, 0.05, E)])
+    ref = ctx.stmpc_ref(x0[:, [0, 1, 3, 4]], T)
+    for e in range(0, E, 13):
+        r0 = orc.calc_ref_trajectory_dynamic(x0[e, [0, 1, 3, 4]], cl[:, 1], cl[:, 2], cl[:, 3], cl[:, 5], T)
+        np.testing.assert_array_equal(ref[e], r0)
+    cfg = _abi.stmpc_cfg(horizon=T, n_rollouts=R)
+    ctrl = synth.make_controls(E, T, R, seed=15, sigma_a=2.0, sigma_d=2.5, max_accel=3.2, max_steer=4.0)   # [.., 0, :] = steering speed
+    got = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+    want = orc.stmpc_shoot_batch(x0, ref, ctrl, cfg, nthreads=8)
+    np.testing.assert_array_equal(got["best_idx"], want["best_idx"])
+    np.testing.assert_allclose(got["best_cost"], want["best_cost"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_array_equal(got["best_seq"], want["best_seq"])
+    np.testing.assert_array_equal(got["steer"], want["steer"])
+    np.testing.assert_array_equal(got["speed"], want["speed"])
+    assert (np.abs(got["best_seq"][:, :, 0]) <= 3.2).all() and (np.abs(got["best_seq"][:, :, 1]) <= 3.0).all()
+
+
+def test_planner_class_drop_in(golden, tracks):
+    from f1tenth_planning.control.dynamic_mpc.dynamic_mpc import STMPCPlanner, State, mpc_config
+    lev = tracks["levine"]
+    line = [lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5]]
+    pl = STMPCPlanner(waypoints=line)
+    g = golden("g12_dynamic_model.npz")
+    np.testing.assert_allclose(pl.predict_motion(g["dyn_roll_x0"][0], g["dyn_roll_oa"][0], g["dyn_roll_od"][0]), g["dyn_roll_path"][0],
+                               rtol=1e-11, atol=1e-10)
+    s = g["dyn_ref_state"][1]
+    np.testing.assert_array_equal(pl.calc_ref_trajectory(State(x=s[0], y=s[1], v=s[2], yaw=s[3]), *line), g["dyn_ref_out"][1])
+    slow = np.array([2.51, 3.29, 0.0, 1.0, 1.58, 0.0, 0.0])          # v <= V_KS: kinematic branch
+    fast = np.array([2.51, 3.29, 0.0, 3.0, 1.58, 0.0, 0.0])          # v > V_KS: dynamic branch
+    for st in (slow, fast):
+        steer, speed = pl.plan(st)
+        assert abs(steer) <= 0.4189 + 3.2 * 0.025 + 1e-12 and abs(speed - st[3]) <= 3.0 * 0.1 + 1e-12
+    assert mpc_config().V_KS == 2.0 and mpc_config().T == 40
+    with pytest.raises(ValueError):
+        STMPCPlanner().plan(fast)

@@ -162,3 +162,25 @@ def test_lqr_golden(orc, golden, tracks):
             assert out["speed"][0] == g["lq_out"][q, t, 1]
             np.testing.assert_allclose(err[0], g["lq_err"][q, t], rtol=0, atol=1e-13)
     assert abs(g["lq_out"][0, 0, 0] - (-0.00014536216016581283)) < 1e-15
+
+
+def test_dynamic_model_golden(orc, golden, tracks):
+    from f1tenth_planning_amd._abi import stmpc_cfg
+    g = golden("g12_dynamic_model.npz")
+    cfg = stmpc_cfg()
+    sc = g["dyn_cfg"]
+    assert (sc == np.array([cfg.horizon, cfg.dt, 0.03, cfg.wheelbase, cfg.max_steer, cfg.max_steer_v, cfg.max_speed, cfg.min_speed,
+                            cfg.max_accel, 2.0])).all()
+    assert (g["dyn_Q"] == np.array(cfg.q[:])).all() and (g["dyn_Qf"] == np.array(cfg.qf[:])).all()
+    assert (g["dyn_R"] == np.array(cfg.r[:])).all() and (g["dyn_Rd"] == np.array(cfg.rd[:])).all()
+    assert (g["dyn_params"] == np.array(cfg.params[:])).all()
+    for j in range(len(g["dyn_step_a"])):
+        s = orc.update_state_dynamic(g["dyn_step_state"][j], g["dyn_step_a"][j], g["dyn_step_dv"][j], cfg)
+        np.testing.assert_allclose(s, g["dyn_step_out"][j], rtol=0, atol=1e-12)
+    for j in range(len(g["dyn_roll_x0"])):
+        path = orc.predict_motion_dynamic(g["dyn_roll_x0"][j], g["dyn_roll_oa"][j], g["dyn_roll_od"][j], cfg)
+        np.testing.assert_allclose(path, g["dyn_roll_path"][j], rtol=1e-11, atol=1e-10)
+    lev = tracks["levine"]
+    for j in range(len(g["dyn_ref_state"])):
+        ref = orc.calc_ref_trajectory_dynamic(g["dyn_ref_state"][j], lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5], cfg.horizon)
+        np.testing.assert_array_equal(ref, g["dyn_ref_out"][j])

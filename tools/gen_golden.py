@@ -359,6 +359,48 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g10_g11_stanley_lqr.npz"), st_states=st_states, st_out5=st_out[5.0], st_out7=st_out[7.0],
                         st2_states=st2_states, st2_out=st2_out, st2_wheelbase=0.3,
                         lq_states=lq_states, lq_out=lq_out, lq_err=lq_err, lq_params=np.array(lq_params))
+    # ---- G12 dynamic single-track model of dynamic_mpc.py ---------------------------------
+    sys.modules.setdefault("cvxpy.atoms", types.ModuleType("cvxpy.atoms"))
+    aff = types.ModuleType("cvxpy.atoms.affine"); wr = types.ModuleType("cvxpy.atoms.affine.wraps")
+    wr.psd_wrap = lambda x: x
+    sys.modules["cvxpy.atoms.affine"] = aff; sys.modules["cvxpy.atoms.affine.wraps"] = wr
+    from f1tenth_planning.control.dynamic_mpc import dynamic_mpc as D
+    dp = D.STMPCPlanner.__new__(D.STMPCPlanner)          # bypass the cvxpy-using __init__
+    dp.config = D.mpc_config()
+    vp = np.array([3.74, 0.15875, 0.17145, 0.074, 4.718, 5.4562, 0.04712, 1.0489])
+    g = {}
+    n = 96
+    st7 = np.column_stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(2.0, 7.0, n),
+                           rng.uniform(-4, 4, n), rng.uniform(-2, 2, n), rng.uniform(-0.3, 0.3, n)])
+    aa = rng.uniform(-4, 4, n); dv = rng.uniform(-4, 4, n)
+    o7 = np.zeros((n, 7))
+    for j in range(n):
+        s_ = D.State(x=st7[j, 0], y=st7[j, 1], delta=st7[j, 2], v=st7[j, 3], yaw=st7[j, 4], yawrate=st7[j, 5], beta=st7[j, 6])
+        s_ = dp.update_state(s_, aa[j], dv[j], vp)
+        o7[j] = [s_.x, s_.y, s_.delta, s_.v, s_.yaw, s_.yawrate, s_.beta]
+    g["dyn_step_state"] = st7; g["dyn_step_a"] = aa; g["dyn_step_dv"] = dv; g["dyn_step_out"] = o7
+    m = 16
+    T = dp.config.T
+    x07 = st7[:m].copy(); oa7 = rng.normal(0, 1.5, (m, T)); od7 = rng.normal(0, 1.0, (m, T))
+    paths7 = np.zeros((m, 7, T + 1))
+    for j in range(m):
+        paths7[j] = dp.predict_motion(x07[j], oa7[j], od7[j], np.zeros((7, T + 1)), vp)
+    g["dyn_roll_x0"] = x07; g["dyn_roll_oa"] = oa7; g["dyn_roll_od"] = od7; g["dyn_roll_path"] = paths7
+    cx, cy, cyaw, sp = lev[:, 1].copy(), lev[:, 2].copy(), lev[:, 3].copy(), lev[:, 5].copy()
+    kk = rng.integers(0, lev.shape[0] - 1, m); kk[:2] = [0, lev.shape[0] - 5]
+    rs = np.column_stack([lev[kk, 1] + rng.normal(0, 0.1, m), lev[kk, 2] + rng.normal(0, 0.1, m), rng.uniform(2, 6, m),
+                          lev[kk, 3] + rng.normal(0, 0.2, m)])
+    rs[3, 3] += 2 * np.pi
+    refs7 = np.zeros((m, 7, T + 1))
+    for j in range(m):
+        s_ = D.State(x=rs[j, 0], y=rs[j, 1], v=rs[j, 2], yaw=rs[j, 3])
+        refs7[j] = dp.calc_ref_trajectory(s_, cx, cy, cyaw.copy(), sp)
+    g["dyn_ref_state"] = rs; g["dyn_ref_out"] = refs7
+    c7 = dp.config
+    g["dyn_cfg"] = np.array([c7.T, c7.DT, c7.dl, c7.WB, c7.MAX_STEER, c7.MAX_STEER_V, c7.MAX_SPEED, c7.MIN_SPEED, c7.MAX_ACCEL, c7.V_KS])
+    g["dyn_Q"] = np.asarray(c7.Q.diagonal()); g["dyn_Qf"] = np.asarray(c7.Qf.diagonal())
+    g["dyn_R"] = np.asarray(c7.R.diagonal()); g["dyn_Rd"] = np.asarray(c7.Rd.diagonal()); g["dyn_params"] = vp
+    np.savez_compressed(os.path.join(OUT, "g12_dynamic_model.npz"), **g)
     print("golden vectors written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))
