@@ -69,6 +69,8 @@ def main():
                     help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
     ap.add_argument("--generator", choices=["clothoid", "cubic"], default="clothoid",
                     help="candidate generator: clothoid = the reference's (headline); cubic = cubic Hermite spline (secondary line)")
+    ap.add_argument("--kmpc-f64", action="store_true", help="kmpc: plain fp64 evaluation instead of the f32 filter + fp64 refinement")
+    ap.add_argument("--kmpc-cost", action="store_true", help="kmpc: also request best_cost (forces an fp64 re-evaluation of every winner)")
     ap.add_argument("--rollouts", type=int, default=512)
     ap.add_argument("--horizon", type=int, default=30)
     args = ap.parse_args()
@@ -227,8 +229,10 @@ def main_kmpc(args):
     ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=2 + rank)
     d_steer, d_speed, d_bi, d_bc = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E)
 
+    ctx.kmpc_set_mode(not args.kmpc_f64)
+
     def step():
-        ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc)
+        ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc if (args.kmpc_cost or args.kmpc_f64) else None)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -256,7 +260,7 @@ def main_kmpc(args):
         value = float(E) * R * T * args.steps * world / elapsed
         out = {"metric": "rollout-steps/sec (kinematic-MPC random shooting)", "value": value, "unit": "rollout-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 arithmetic on f32 controls",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 on f32 controls" if args.kmpc_f64 else "f32 filter + f64 refinement of the near-minimum set (decision in f64)",
                "data": "synthetic",
                "config": {"workload": f"kmpc shooting: {E} egos x {R} rollouts x {T} steps per GPU (BASELINE configs[4])"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

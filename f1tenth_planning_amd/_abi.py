@@ -168,6 +168,7 @@ PROTOTYPES = {
     "f1p_clothoid_g1_batch": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),
     "f1p_kmpc_shoot_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(KmpcCfg), _P, _P, _P, _P, _P]),
     "f1p_kmpc_shoot_dev": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(KmpcCfg), _P, _P, _P, _P, _P]),
+    "f1p_kmpc_set_mode": (C.c_int, [_P, _I, _P, _P]),
     "f1p_kmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(KmpcCfg), _P]),
     "f1p_kmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),
     "f1p_kmpc_sample_controls_dev": (C.c_int, [_P, _P, _I, C.POINTER(KmpcCfg), C.c_uint64, _D, _D]),

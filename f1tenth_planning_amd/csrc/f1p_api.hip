@@ -544,6 +544,14 @@ int f1p_kmpc_shoot_batch(f1p_ctx* ctx, const double* x0, const double* ref, cons
     return s.finish();
 }
 
+int f1p_kmpc_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_n_refined) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->kmpc_mixed = mixed != 0;
+    ctx->d_dbg_cost32 = d_cost32;
+    ctx->d_dbg_nref = d_n_refined;
+    return F1P_OK;
+}
+
 int f1p_kmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od, int32_t E,
                            const f1p_kmpc_cfg* cfg, double* path) {
     F1P_ENTER(ctx);

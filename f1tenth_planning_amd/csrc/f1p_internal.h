@@ -31,6 +31,11 @@ struct f1p_ctx {
     char* d_arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
 
+    // shooting-MPC evaluation mode: f32 filter + fp64 refinement (default) or plain fp64; diagnostics of the filter
+    bool kmpc_mixed = true;
+    float* d_dbg_cost32 = nullptr;     // [E][R] filter costs of the next launch (test hook), or null
+    int32_t* d_dbg_nref = nullptr;     // [E] size of the refined set (-1 = fp64 fallback), or null
+
     // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -11,6 +11,10 @@
 // HBM-streaming kernel of the path: 8 B of controls per rollout-step, fp64 arithmetic on them.
 #include "f1p_internal.h"
 
+#ifndef F1P_K4_WAVES
+#define F1P_K4_WAVES 4
+#endif
+
 namespace f1p {
 
 struct KmpcStep { double x, y, v, yaw; };
@@ -44,40 +48,223 @@ __device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, c
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
 
-// all rollouts of this thread: running cost in the reference's accumulation order, first-minimum argmin
+// fp64 cost of ONE rollout r: running sum in the reference's accumulation order
+template <bool FAST>
+__device__ __forceinline__ double kmpc_rollout_cost(const float* __restrict__ ce, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
+                                                    double sy, double sv, double syaw, double dmax, int r) {
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    KmpcStep s;
+    s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
+    double cost = 0.0, pa = 0.0, pd = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double a = (double)ce[((size_t)t * 2 + 0) * R + r];
+        double d = (double)ce[((size_t)t * 2 + 1) * R + r];
+        a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
+        d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
+        if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
+        const double e0 = s.x - sref[0 * (T + 1) + t], e1 = s.y - sref[1 * (T + 1) + t];
+        const double e2 = s.v - sref[2 * (T + 1) + t], e3 = s.yaw - sref[3 * (T + 1) + t];
+        cost += ((cfg.q[0] * e0 * e0 + cfg.q[1] * e1 * e1) + cfg.q[2] * e2 * e2) + cfg.q[3] * e3 * e3;   // :331
+        cost += cfg.r[0] * a * a + cfg.r[1] * d * d;                                                     // :328
+        if (t > 0) {
+            const double da = a - pa, dd = d - pd;
+            cost += cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                                           // :334
+        }
+        kmpc_step<FAST>(s, a, d, cfg);
+        pa = a; pd = d;
+    }
+    const double e0 = s.x - sref[0 * (T + 1) + T], e1 = s.y - sref[1 * (T + 1) + T];
+    const double e2 = s.v - sref[2 * (T + 1) + T], e3 = s.yaw - sref[3 * (T + 1) + T];
+    cost += ((cfg.qf[0] * e0 * e0 + cfg.qf[1] * e1 * e1) + cfg.qf[2] * e2 * e2) + cfg.qf[3] * e3 * e3;
+    return cost;
+}
+
+// all rollouts of this thread, first-minimum argmin
 template <bool FAST>
 __device__ __forceinline__ void kmpc_rollouts(const float* __restrict__ ce, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
                                               double sy, double sv, double syaw, double dmax, int tid, double& bc, int& bi) {
-    const int T = cfg.horizon, R = cfg.n_rollouts;
-    for (int r = tid; r < R; r += blockDim.x) {
-        KmpcStep s;
-        s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
-        double cost = 0.0, pa = 0.0, pd = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double a = (double)ce[((size_t)t * 2 + 0) * R + r];
-            double d = (double)ce[((size_t)t * 2 + 1) * R + r];
-            a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
-            d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
-            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
-            const double e0 = s.x - sref[0 * (T + 1) + t], e1 = s.y - sref[1 * (T + 1) + t];
-            const double e2 = s.v - sref[2 * (T + 1) + t], e3 = s.yaw - sref[3 * (T + 1) + t];
-            cost += ((cfg.q[0] * e0 * e0 + cfg.q[1] * e1 * e1) + cfg.q[2] * e2 * e2) + cfg.q[3] * e3 * e3;   // :331
-            cost += cfg.r[0] * a * a + cfg.r[1] * d * d;                                                     // :328
-            if (t > 0) {
-                const double da = a - pa, dd = d - pd;
-                cost += cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                                           // :334
-            }
-            kmpc_step<FAST>(s, a, d, cfg);
-            pa = a; pd = d;
-        }
-        const double e0 = s.x - sref[0 * (T + 1) + T], e1 = s.y - sref[1 * (T + 1) + T];
-        const double e2 = s.v - sref[2 * (T + 1) + T], e3 = s.yaw - sref[3 * (T + 1) + T];
-        cost += ((cfg.qf[0] * e0 * e0 + cfg.qf[1] * e1 * e1) + cfg.qf[2] * e2 * e2) + cfg.qf[3] * e3 * e3;
+    for (int r = tid; r < cfg.n_rollouts; r += blockDim.x) {
+        const double cost = kmpc_rollout_cost<FAST>(ce, sref, cfg, sx, sy, sv, syaw, dmax, r);
         if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
     }
 }
 
-__global__ __launch_bounds__(256) void k_kmpc_shoot(const double* __restrict__ x0, const double* __restrict__ ref,
+// ---------------------------------------------------------------------------------------------------
+// fp32 FILTER for the mixed-precision kernel: the same rollout and cost in single precision, in coordinates relative to
+// the ego state (so every quantity is O(10) and the f32 rounding stays ~1e-6 relative).  It only has to RANK rollouts
+// coarsely: every rollout whose f32 cost is within the margin (F1P_K4_MARGIN_REL per time step, relative, + F1P_K4_MARGIN_ABS) of the f32 minimum is re-evaluated in fp64 by the code
+// above, and the decision is taken on those fp64 costs -- so the result is the fp64 argmin as long as the f32 error is below
+// half the margin (measured at T = 30: f32 error < 5 % of the margin of 1e-2 relative + 0.05 absolute; tests/test_gpu_kmpc.py
+// checks both the error against the margin and the bit-identity of the results with the plain fp64 kernel).
+// ---------------------------------------------------------------------------------------------------
+struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; };
+
+// The controls of F1P_K4_CHUNK time steps are requested up front (2 x CHUNK independent 256-byte wave loads in flight) and
+// consumed afterwards: with one load pair per step the kernel is bound by HBM latency (~1 TB/s), not bandwidth.
+#ifndef F1P_K4_CHUNK
+#define F1P_K4_CHUNK 10
+#endif
+__device__ __forceinline__ float kmpc_rollout_cost_f32(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R, int r) {
+    float x = 0.f, y = 0.f, v = k.v0, yaw = 0.f, cost = 0.f, pa = 0.f, pd = 0.f;
+    for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK) {
+        float av[F1P_K4_CHUNK], dv[F1P_K4_CHUNK];
+#pragma unroll
+        for (int j = 0; j < F1P_K4_CHUNK; ++j) {
+            const int t = t0 + j < T ? t0 + j : T - 1;                 // clamp: the tail re-reads the last step (unused)
+            av[j] = ce[((size_t)t * 2 + 0) * R + r];
+            dv[j] = ce[((size_t)t * 2 + 1) * R + r];
+        }
+#pragma unroll
+        for (int j = 0; j < F1P_K4_CHUNK; ++j) {
+            const int t = t0 + j;
+            if (t < T) {
+                float a = fminf(fmaxf(av[j], -k.max_accel), k.max_accel);
+                float d = fminf(fmaxf(dv[j], -k.max_steer), k.max_steer);
+                if (t > 0) d = fminf(fmaxf(d, pd - k.dmax), pd + k.dmax);
+                const float e0 = x - sref32[0 * (T + 1) + t], e1 = y - sref32[1 * (T + 1) + t];
+                const float e2 = v - sref32[2 * (T + 1) + t], e3 = yaw - sref32[3 * (T + 1) + t];
+                cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
+                if (t > 0) { const float da = a - pa, dd = d - pd; cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
+                float sn, cs;
+                __sincosf(yaw, &sn, &cs);
+                const float cy = k.c0 * cs - k.s0 * sn, sy = k.s0 * cs + k.c0 * sn;     // cos / sin of the absolute heading
+                const float vdt = v * k.dt;
+                x += vdt * cy;
+                y += vdt * sy;
+                // tan(d) for the clamped steering angle: odd Taylor polynomial to d^11 (relative error < 1e-7 for |d| <= 0.6, no
+                // transcendental issue slots); larger steering limits take the intrinsic
+                float tn;
+                if (k.max_steer <= 0.6f) {
+                    const float d2 = d * d;
+                    tn = d * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
+                } else {
+                    tn = __tanf(d);
+                }
+                yaw += v * k.inv_wb_dt * tn;
+                v = fminf(fmaxf(v + a * k.dt, k.min_speed), k.max_speed);
+                pa = a; pd = d;
+            }
+        }
+    }
+    const float e0 = x - sref32[0 * (T + 1) + T], e1 = y - sref32[1 * (T + 1) + T];
+    const float e2 = v - sref32[2 * (T + 1) + T], e3 = yaw - sref32[3 * (T + 1) + T];
+    cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3;
+    return cost;
+}
+
+// relative margin PER TIME STEP of the horizon (the f32 state error grows with the number of steps): 30 steps -> 1e-2
+#ifndef F1P_K4_MARGIN_REL
+#define F1P_K4_MARGIN_REL 3.4e-4f
+#endif
+#ifndef F1P_K4_MARGIN_ABS
+#define F1P_K4_MARGIN_ABS 5.0e-2f
+#endif
+#define F1P_K4_MAX_REFINE 64
+
+// Mixed-precision shooting: f32 filter over all rollouts (HBM-streaming, 8 B per rollout-step), fp64 refinement of the
+// near-minimum set by wave 0, decision on the fp64 costs.  `cost32_out` (nullable, [E][R]) exposes the filter costs so a
+// test can measure the f32 error against the margin.
+__global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot_mixed(const double* __restrict__ x0, const double* __restrict__ ref,
+                                                          const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
+                                                          double* __restrict__ steer, double* __restrict__ speed,
+                                                          int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
+                                                          double* __restrict__ best_seq, float* __restrict__ cost32_out,
+                                                          int32_t* __restrict__ n_refined) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* sref = reinterpret_cast<double*>(lds_raw);               // [4][T+1] absolute, fp64 (refinement)
+    double* red_d = sref + 4 * (T + 1);                               // [4]
+    float* sref32 = reinterpret_cast<float*>(red_d + 4);              // [4][T+1] relative to the ego state, f32 (filter)
+    float* c32 = sref32 + 4 * (T + 1);                                // [R] filter costs
+    float* red_f = c32 + R;                                           // [4]
+    int* list = reinterpret_cast<int*>(red_f + 4);                    // [F1P_K4_MAX_REFINE]
+    int* cnt = list + F1P_K4_MAX_REFINE;                              // [1]
+    int* red_i = cnt + 1;                                             // [4]
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
+    for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
+        const double rv = ref[(size_t)e * 4 * (T + 1) + q];
+        sref[q] = rv;
+        const int row = q / (T + 1);
+        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, then rounded
+    }
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    const float* ce = controls + (size_t)e * T * 2 * R;
+    const double dmax = cfg.max_dsteer * cfg.dt;
+    KmpcF32 k;
+    for (int i = 0; i < 4; ++i) { k.q[i] = (float)cfg.q[i]; k.qf[i] = (float)cfg.qf[i]; }
+    for (int i = 0; i < 2; ++i) { k.r[i] = (float)cfg.r[i]; k.rd[i] = (float)cfg.rd[i]; }
+    k.dt = (float)cfg.dt; k.inv_wb_dt = (float)(cfg.dt / cfg.wheelbase); k.max_steer = (float)cfg.max_steer; k.max_accel = (float)cfg.max_accel;
+    k.max_speed = (float)cfg.max_speed; k.min_speed = (float)cfg.min_speed; k.dmax = (float)dmax; k.v0 = (float)sv;
+    double s0d, c0d;
+    sincos(syaw, &s0d, &c0d);
+    k.c0 = (float)c0d; k.s0 = (float)s0d;
+
+    // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
+    float fmin_ = __builtin_huge_valf();
+    for (int r = tid; r < R; r += blockDim.x) {
+        const float c = kmpc_rollout_cost_f32(ce, sref32, k, T, R, r);
+        c32[r] = c;
+        if (cost32_out) cost32_out[(size_t)e * R + r] = c;
+        fmin_ = fminf(fmin_, c);                                       // NaN costs are ignored here and caught by the fallback below
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
+    if (lane == 0) red_f[wave] = fmin_;
+    __syncthreads();
+    fmin_ = fminf(fminf(red_f[0], red_f[1]), fminf(red_f[2], red_f[3]));
+    const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
+    // ---- pass B: the near-minimum set -> LDS list ---------------------------------------------------------------------
+    for (int r = tid; r < R; r += blockDim.x) {
+        const float c = c32[r];
+        if (!(c > thr)) {                                              // includes NaN
+            const int pos = atomicAdd(cnt, 1);
+            if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+        }
+    }
+    __syncthreads();
+    const int n = *cnt;
+    const bool sane = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4 && isfinite(fmin_);
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    if (n > F1P_K4_MAX_REFINE || n < 1 || !sane) {
+        // ---- fallback: the plain fp64 evaluation of every rollout (pathological inputs, degenerate ties) ---------------
+        if (sane) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
+        else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
+        block_argmin(bc, bi, red_d, red_i);
+        if (tid == 0 && n_refined) n_refined[e] = -1;
+    } else {
+        // ---- pass C: fp64 refinement of the listed rollouts by wave 0, decision on the fp64 costs ------------------------
+        if (wave != 0) return;
+        if (n == 1 && !best_cost) {
+            bi = list[0];                                              // a single survivor needs no fp64 cost unless it is asked for
+        } else {
+            if (lane < n) { bi = list[lane]; bc = kmpc_rollout_cost<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, bi); }
+            wave_argmin(bc, bi);
+        }
+        if (lane == 0 && n_refined) n_refined[e] = n;
+    }
+    if (tid == 0) {
+        double pd = 0.0;                                               // the winner's applied sequence: clamp, then the sequential rate limit
+        for (int t = 0; t < T; ++t) {
+            double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
+            double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
+            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
+            if (t == 0) {
+                steer[e] = d;                       // :506
+                speed[e] = sv + a * cfg.dt;         // :508
+            }
+            if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
+            else if (t == 0) break;
+            pd = d;
+        }
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+    }
+}
+
+__global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot(const double* __restrict__ x0, const double* __restrict__ ref,
                                                     const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
                                                     double* __restrict__ steer, double* __restrict__ speed,
                                                     int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
@@ -208,7 +395,14 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                       double* d_best_cost, double* d_best_seq) {
     if (E <= 0) return F1P_OK;
-    const size_t lds = sizeof(double) * (4 * (size_t)(cfg->horizon + 1) + 4) + sizeof(int) * 4;
+    const size_t T1 = (size_t)cfg->horizon + 1;
+    if (ctx->kmpc_mixed && cfg->n_rollouts <= 8192) {
+        size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(float) * (4 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 1 + 4);
+        hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
+                           *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref);
+        return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot_mixed launch");
+    }
+    const size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
     hipLaunchKernelGGL(k_kmpc_shoot, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
                        *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot launch");

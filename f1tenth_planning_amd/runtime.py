@@ -253,6 +253,11 @@ class Context:
         self._check(self.lib.f1p_kmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
         return ref
 
+    def kmpc_set_mode(self, mixed=True, d_cost32=None, d_n_refined=None):
+        """mixed: f32 filter + fp64 refinement (default) or plain fp64; optional device buffers receive the filter diagnostics"""
+        self._check(self.lib.f1p_kmpc_set_mode(self.h, 1 if mixed else 0, None if d_cost32 is None else d_cost32.ptr,
+                                               None if d_n_refined is None else d_n_refined.ptr))
+
     def kmpc_predict(self, x0, oa, od, cfg: KmpcCfg):
         """predict_motion_kinematic (kinematic_mpc.py:208-221) for E egos -> path [E, 4, T+1]"""
         x0 = _f64(x0, (-1, 4)); E = x0.shape[0]; T = cfg.horizon

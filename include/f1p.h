@@ -283,6 +283,12 @@ int f1p_kmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, co
  * -> path [E][4][T+1], rows x, y, v, yaw; column 0 is x0. */
 int f1p_kmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, const double* od, int32_t E,
                            const f1p_kmpc_cfg* cfg, double* path);
+/* Evaluation mode of f1p_kmpc_shoot_*: mixed = 1 (default): every rollout is ranked by an f32 filter that streams the
+ * controls at HBM speed, the rollouts within a safety margin of the f32 minimum are re-evaluated in fp64 and the decision is
+ * taken on those fp64 costs (identical best_idx / best_cost to the plain fp64 evaluation); mixed = 0: plain fp64.
+ * d_cost32 [E][R] f32 and d_n_refined [E] i32 (both nullable, device pointers) receive the filter costs and the size of the
+ * refined set (-1 = fp64 fallback) of the following launches -- the hook the parity tests use to measure the filter error. */
+int f1p_kmpc_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_n_refined);
 /* calc_ref_trajectory_kinematic (:162-206) for E egos against the ctx waypoints (cols x, y, v, psi):
  * states [E][4] = (x, y, v, yaw) -> ref [E][4][T+1].  The reference's in-place fix-up of cyaw (:198-203) is
  * applied to a per-ego view, never to the stored waypoints. */

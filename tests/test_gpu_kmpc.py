@@ -168,3 +168,49 @@ def test_planner_class_drop_in(golden, tracks):
         x = pl.predict_motion_kinematic(x, [a], [st])[:, 1]
     d = np.hypot(lev[:, 1] - x[0], lev[:, 2] - x[1])
     assert d.min() < 0.25 and 40 < d.argmin() < 400
+
+
+def test_mixed_precision_filter_is_exact_and_within_margin(ctx, orc):
+    """The default evaluation mode ranks the rollouts with an f32 filter and decides on fp64 re-evaluations of the near-minimum
+    set.  (1) Its outputs are bit-identical to the plain fp64 mode and to the oracle's indices; (2) the measured f32 error is far
+    inside the refinement margin (1e-2 relative + 0.05 absolute), which is what makes (1) hold by construction."""
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(21)
+    E, T, R = 512, 30, 512
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1] + rng.normal(0, 0.15, E), cl[k, 2] + rng.normal(0, 0.15, E), rng.uniform(0.2, 5.8, E),
+                              cl[k, 3] + rng.normal(0, 0.15, E)])
+    states[:8, 3] += 2 * np.pi * np.arange(8)                               # large absolute headings
+    ref = ctx.kmpc_ref(states, T)
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    ctrl = synth.make_controls(E, T, R, seed=22, sigma_a=2.0, sigma_d=0.25)
+    d_c32, d_n = ctx.alloc(4 * E * R), ctx.alloc(4 * E)
+    try:
+        ctx.kmpc_set_mode(True, d_c32, d_n)
+        mixed = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+        c32 = d_c32.download(np.float32, (E, R)).astype(np.float64)
+        nref = d_n.download(np.int32, (E,))
+        ctx.kmpc_set_mode(False)
+        plain = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+    finally:
+        ctx.kmpc_set_mode(True)
+    for key in ("best_idx", "best_cost", "steer", "speed", "best_seq"):
+        np.testing.assert_array_equal(mixed[key], plain[key], err_msg=key)
+    want = orc.kmpc_shoot_batch(states, ref, ctrl, cfg, want_all=True, nthreads=8)
+    np.testing.assert_array_equal(mixed["best_idx"], want["best_idx"])
+    c64 = want["all_cost"]
+    err = np.abs(c32 - c64)
+    rel = (err / (np.abs(c64) * 1e-2 + 5e-2)).max()                          # error in units of the margin
+    assert rel < 0.05, rel                                                   # >= 10x slack on the half-margin requirement
+    assert (nref >= 1).all() and nref.mean() < 3.0 and (nref <= 64).all()
+    # without best_cost a single survivor is accepted unrefined; still the same indices
+    d_x0, d_ref, d_ctrl = ctx.to_device(states), ctx.to_device(ref), ctx.to_device(ctrl)
+    d_steer, d_speed, d_bi = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E)
+    ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi)
+    np.testing.assert_array_equal(d_bi.download(np.int32, (E,)), want["best_idx"])
+    np.testing.assert_array_equal(d_steer.download(np.float64, (E,)), want["steer"])
+    # degenerate: all rollouts identical -> every rollout is within the margin -> fp64 fallback, first index wins
+    same = np.zeros((4, T, 2, R), np.float32)
+    out = ctx.kmpc_shoot(states[:4], ref[:4], same, cfg)
+    assert (out["best_idx"] == 0).all()
