@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=30, help="host-boundary plan() calls for p50/p95 (0 = skip)")
-    ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc"], default="lattice",
+    ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc", "pursuit"], default="lattice",
                     help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
     ap.add_argument("--generator", choices=["clothoid", "cubic"], default="clothoid",
                     help="candidate generator: clothoid = the reference's (headline); cubic = cubic Hermite spline (secondary line)")
@@ -76,6 +76,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "kmpc":
         return main_kmpc(args)
+    if args.workload == "pursuit":
+        return main_pursuit(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,6 +207,50 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    ctx.close()
+
+
+def main_pursuit(args):
+    """Secondary line: batched pure pursuit (BASELINE configs[0] run for many egos): K1 nearest segment with chunk pruning
+    + K2 look-ahead + actuation, 24 B in / 28 B out per ego; fp64-VALU bound."""
+    E = args.egos if args.egos != 4096 else 65536
+    rl = synth.make_raceline(seed=0)
+    poses = synth.make_egos(rl, E, seed=1)[:, :3]
+    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) % max(1, _abi.load_library().f1p_device_count()))
+    ctx.set_waypoints(rl)
+    d_poses = ctx.to_device(poses)
+    d_steer, d_speed, d_near, d_la, d_st = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(4 * E)
+
+    def step():
+        ctx.pure_pursuit_dev(d_poses, E, 0.8, d_steer, d_speed, d_near, d_la, d_st)
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_end() / args.steps
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "ego-plans/sec (batched pure pursuit)", "value": E * args.steps / elapsed, "unit": "plans/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"pure pursuit: {E} egos on a {len(rl)}-point raceline (BASELINE configs[0], batched)"},
+           "kernel_ms": kernel_ms}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        n_cpu = min(E, 65536)
+        t1 = time.perf_counter()
+        want = oracle.pure_pursuit_batch(poses[:n_cpu], rl, 0.8, nthreads=oracle.max_threads())
+        cpu_s = time.perf_counter() - t1
+        near = d_near.download(np.int32, (E,))[:n_cpu]
+        steer = d_steer.download(np.float64, (E,))[:n_cpu]
+        out["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "plans/s", "cores": oracle.max_threads(), "kind": "port",
+                               "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_pure_pursuit_batch"}
+        out["parity"] = {"egos_checked": int(n_cpu), "near_idx_mismatches": int((near != want["near_idx"]).sum()),
+                         "max_abs_steer_diff": float(np.abs(steer - want["steer"]).max())}
+    print(json.dumps(out))
     ctx.close()
 
 

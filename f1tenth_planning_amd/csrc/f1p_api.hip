@@ -1,7 +1,10 @@
 // f1p_api.hip -- the extern "C" surface of libf1p.so (include/f1p.h): context, device memory, scene upload,
 // host-pointer wrappers around the kernel launchers, and the RCCL exchange step.
 #include <dlfcn.h>
+#include <math.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <new>
 #include <string>
@@ -202,7 +205,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -302,13 +305,34 @@ int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncol
         soa[(size_t)3 * n + i] = col_psi >= 0 ? wp[(size_t)i * ncols + col_psi] : 0.0;
         soa[(size_t)4 * n + i] = col_kappa >= 0 ? wp[(size_t)i * ncols + col_kappa] : 0.0;
     }
+    // bounding box of every 64-segment chunk (nearest_scan_boxed); infinite = "never skip this chunk"
+    const int nchunk = (n - 1 + 63) / 64;
+    std::vector<double> box((size_t)4 * nchunk);
+    for (int c = 0; c < nchunk; ++c) {
+        const int lo = 64 * c, hi = std::min(64 * c + 64, n - 1);
+        double xmin = HUGE_VAL, xmax = -HUGE_VAL, ymin = HUGE_VAL, ymax = -HUGE_VAL;
+        bool open_box = false;
+        for (int i = lo; i <= hi; ++i) {
+            const double x = soa[i], y = soa[(size_t)n + i];
+            if (!(fabs(x) <= 1.0e6) || !(fabs(y) <= 1.0e6)) open_box = true;
+            if (i < hi) {
+                const double dx = soa[i + 1] - x, dy = soa[(size_t)n + i + 1] - y;
+                if (!(dx * dx + dy * dy >= 1e-300)) open_box = true;   // zero-length (0/0 = NaN wins np.argmin) or NaN
+            }
+            xmin = std::min(xmin, x); xmax = std::max(xmax, x); ymin = std::min(ymin, y); ymax = std::max(ymax, y);
+        }
+        if (open_box) { xmin = ymin = -HUGE_VAL; xmax = ymax = HUGE_VAL; }
+        box[4 * (size_t)c] = xmin; box[4 * (size_t)c + 1] = xmax; box[4 * (size_t)c + 2] = ymin; box[4 * (size_t)c + 3] = ymax;
+    }
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n != ctx->n_wp) {
-        double** ps[] = {&ctx->d_wx, &ctx->d_wy, &ctx->d_wv, &ctx->d_wpsi, &ctx->d_wkappa};
+        double** ps[] = {&ctx->d_wx, &ctx->d_wy, &ctx->d_wv, &ctx->d_wpsi, &ctx->d_wkappa, &ctx->d_wbox};
         for (double** p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
         ctx->n_wp = 0;
-        for (double** p : ps) F1P_HIP(ctx, hipMalloc((void**)p, sizeof(double) * (size_t)n));
+        for (double** p : ps)
+            F1P_HIP(ctx, hipMalloc((void**)p, sizeof(double) * (p == &ctx->d_wbox ? (size_t)4 * nchunk : (size_t)n)));
     }
+    F1P_HIP(ctx, hipMemcpy(ctx->d_wbox, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice));
     const size_t b = sizeof(double) * (size_t)n;
     F1P_HIP(ctx, hipMemcpy(ctx->d_wx, soa.data(), b, hipMemcpyHostToDevice));
     F1P_HIP(ctx, hipMemcpy(ctx->d_wy, soa.data() + n, b, hipMemcpyHostToDevice));

@@ -14,6 +14,9 @@
 #define F1P_WAVE 64
 #define F1P_PI 3.14159265358979323846
 #define F1P_LA_NONE INT32_MIN
+#ifndef F1P_NEAREST_PRUNE
+#define F1P_NEAREST_PRUNE 1   // 0: full scan (A/B knob; results are identical)
+#endif
 
 namespace f1p {
 
@@ -150,6 +153,62 @@ __device__ __forceinline__ void nearest_scan(double px, double py, const double*
     for (int i = tid; i < n - 1; i += nthreads) {
         const SegProj s = seg_project(px, py, wx[i], wy[i], wx[i + 1], wy[i + 1]);
         if (argmin_better(s.d, i, best_d, best_i)) { best_d = s.d; best_i = i; }
+    }
+}
+
+// The same scan with whole 64-segment chunks skipped when they cannot hold the minimum.  `box` [ceil((n-1)/64)][4] =
+// (xmin, xmax, ymin, ymax) of the waypoints of chunk c (rows 64c .. min(64c+64, n-1)), built by f1p_set_waypoints;
+// a chunk with a zero-length segment or a non-finite / huge coordinate gets an infinite box and is never skipped
+// (np.argmin returns the first NaN, so such a segment can win at any distance).
+// Upper bound: the distance to 64 sampled waypoints (a segment is never farther than its end points).  A chunk is
+// skipped iff dist^2(point, box) > ub^2 (1 + 1e-6) + 1e-9: with |coordinates| <= 1e6 the rounding of the projected
+// point is <= 3e-10, orders below that margin, so every skipped segment's computed distance is strictly larger than
+// the computed minimum and the (value, index) argmin is unchanged -- the result is bit-identical to nearest_scan.
+// Surviving chunks are dealt round-robin to the waves.  `nthreads` must be a multiple of 64 and every lane of every
+// wave must call this (ballot inside).
+__device__ __forceinline__ void nearest_scan_boxed(double px, double py, const double* __restrict__ wx,
+                                                   const double* __restrict__ wy, const double* __restrict__ box, int n,
+                                                   int tid, int nthreads, double& best_d, int& best_i) {
+#if !F1P_NEAREST_PRUNE
+    nearest_scan(px, py, wx, wy, n, tid, nthreads, best_d, best_i);
+    return;
+#endif
+    best_d = __builtin_huge_val();
+    best_i = 0x7fffffff;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    const int nseg = n - 1;
+    const int nchunk = (nseg + 63) >> 6;
+    const int stride = (n + 63) >> 6;
+    int j = lane * stride;
+    if (j > n - 1) j = n - 1;
+    const double ex = px - wx[j], ey = py - wy[j];
+    double ub2 = ex * ex + ey * ey;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ub2 = __builtin_fmin(ub2, shfl_xor_d(ub2, m));   // fmin drops NaN samples
+    const double thr = ub2 * (1.0 + 1e-6) + 1e-9;
+    int turn = 0;
+    for (int cb = 0; cb < nchunk; cb += 64) {
+        const int c = cb + lane;
+        bool keep = false;
+        if (c < nchunk) {
+            const double xmin = box[4 * c], xmax = box[4 * c + 1], ymin = box[4 * c + 2], ymax = box[4 * c + 3];
+            const double dx = __builtin_fmax(__builtin_fmax(xmin - px, px - xmax), 0.0);
+            const double dy = __builtin_fmax(__builtin_fmax(ymin - py, py - ymax), 0.0);
+            keep = !(dx * dx + dy * dy > thr);      // NaN anywhere keeps the chunk
+        }
+        unsigned long long m = __ballot(keep);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (turn == wave) {
+                const int i = ((cb + b) << 6) + lane;
+                if (i < nseg) {
+                    const SegProj s = seg_project(px, py, wx[i], wy[i], wx[i + 1], wy[i + 1]);
+                    if (argmin_better(s.d, i, best_d, best_i)) { best_d = s.d; best_i = i; }
+                }
+            }
+            if (++turn == nw) turn = 0;
+        }
     }
 }
 

@@ -20,6 +20,7 @@ struct f1p_ctx {
     bool has_psi = false;
     double *d_wx = nullptr, *d_wy = nullptr, *d_wv = nullptr, *d_wpsi = nullptr, *d_wkappa = nullptr;
     bool has_kappa = false;
+    double* d_wbox = nullptr;   // [ceil((n_wp-1)/64)][4] chunk bounding boxes for nearest_scan_boxed
 
     // occupancy grid, bit-packed and row-flipped
     bool has_grid = false;

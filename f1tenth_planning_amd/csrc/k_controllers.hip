@@ -14,11 +14,12 @@ struct FrontErr { double theta_e, ef; int idx; };
 // front-axle point -> nearest raceline segment -> cross-track and heading error (stanley.py:57-88 == lqr.py:60-103)
 __device__ __forceinline__ FrontErr front_axle_errors(double x, double y, double theta, double wheelbase,
                                                       const double* __restrict__ wx, const double* __restrict__ wy,
-                                                      const double* __restrict__ wpsi, int n, double* sd, int* si) {
+                                                      const double* __restrict__ wpsi, const double* __restrict__ wbox, int n,
+                                                      double* sd, int* si) {
     const double fx = x + wheelbase * cos(theta);            // stanley.py:66
     const double fy = y + wheelbase * sin(theta);            // :67
     double bd; int bi;
-    nearest_scan(fx, fy, wx, wy, n, threadIdx.x, blockDim.x, bd, bi);   // :69
+    nearest_scan_boxed(fx, fy, wx, wy, wbox, n, threadIdx.x, blockDim.x, bd, bi);   // :69
     block_argmin(bd, bi, sd, si);
     const SegProj s = seg_project(fx, fy, wx[bi], wy[bi], wx[bi + 1], wy[bi + 1]);
     const double vx = fx - s.qx, vy = fy - s.qy;             // :70
@@ -34,14 +35,14 @@ __device__ __forceinline__ FrontErr front_axle_errors(double x, double y, double
 
 __global__ __launch_bounds__(256) void k_stanley(const double* __restrict__ states, int E, double wheelbase, double k_path,
                                                  const double* __restrict__ wx, const double* __restrict__ wy,
-                                                 const double* __restrict__ wv, const double* __restrict__ wpsi, int n,
-                                                 double* __restrict__ steer, double* __restrict__ speed,
+                                                 const double* __restrict__ wv, const double* __restrict__ wpsi,
+                                                 const double* __restrict__ wbox, int n, double* __restrict__ steer, double* __restrict__ speed,
                                                  int32_t* __restrict__ near_idx) {
     __shared__ double sd[4];
     __shared__ int si[4];
     const int e = blockIdx.x;
     if (e >= E) return;
-    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, n, sd, si);
+    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, wbox, n, sd, si);
     if (threadIdx.x == 0) {
         const double cte_front = atan2(k_path * fe.ef, states[4 * e + 3]);   // stanley.py:110
         steer[e] = cte_front + fe.theta_e;                                   // :111
@@ -145,13 +146,14 @@ struct LqrParams { double wheelbase, ts, q[4], r, eps; int max_iter; };
 __global__ __launch_bounds__(256) void k_lqr(const double* __restrict__ states, double* __restrict__ err, int E, LqrParams p,
                                              const double* __restrict__ wx, const double* __restrict__ wy,
                                              const double* __restrict__ wv, const double* __restrict__ wpsi,
-                                             const double* __restrict__ wkappa, int n, double* __restrict__ steer,
+                                             const double* __restrict__ wkappa, const double* __restrict__ wbox, int n,
+                                             double* __restrict__ steer,
                                              double* __restrict__ speed, int32_t* __restrict__ near_idx) {
     __shared__ double sd[4];
     __shared__ int si[4];
     const int e = blockIdx.x;
     if (e >= E) return;
-    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], p.wheelbase, wx, wy, wpsi, n, sd, si);
+    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], p.wheelbase, wx, wy, wpsi, wbox, n, sd, si);
     if (threadIdx.x == 0) {
         const double v = states[4 * e + 3];
         const double e_old = err[2 * e], th_old = err[2 * e + 1];                               // lqr.py:136-137
@@ -172,7 +174,7 @@ int launch_stanley(f1p_ctx* ctx, const double* d_states, int E, double wheelbase
                    double* d_speed, int32_t* d_near) {
     if (E <= 0) return F1P_OK;
     hipLaunchKernelGGL(k_stanley, dim3(E), dim3(256), 0, ctx->stream, d_states, E, wheelbase, k_path, ctx->d_wx, ctx->d_wy,
-                       ctx->d_wv, ctx->d_wpsi, ctx->n_wp, d_steer, d_speed, d_near);
+                       ctx->d_wv, ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, d_steer, d_speed, d_near);
     return check_hip(ctx, hipGetLastError(), "k_stanley launch");
 }
 
@@ -183,7 +185,7 @@ int launch_lqr(f1p_ctx* ctx, const double* d_states, double* d_err, int E, doubl
     p.wheelbase = wheelbase; p.ts = ts; p.r = r; p.eps = eps; p.max_iter = max_iter;
     for (int i = 0; i < 4; ++i) p.q[i] = q[i];
     hipLaunchKernelGGL(k_lqr, dim3(E), dim3(256), 0, ctx->stream, d_states, d_err, E, p, ctx->d_wx, ctx->d_wy, ctx->d_wv,
-                       ctx->d_wpsi, ctx->d_wkappa, ctx->n_wp, d_steer, d_speed, d_near);
+                       ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->n_wp, d_steer, d_speed, d_near);
     return check_hip(ctx, hipGetLastError(), "k_lqr launch");
 }
 

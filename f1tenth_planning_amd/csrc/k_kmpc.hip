@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256) void k_kmpc_predict(const double* __restrict__
 // (cx, cy, sp, cyaw) = (wx, wy, wv, wpsi).  ref [E][4][T+1].
 __global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
                                                   const double* __restrict__ wx, const double* __restrict__ wy,
-                                                  const double* __restrict__ wv, const double* __restrict__ wpsi, int n,
+                                                  const double* __restrict__ wv, const double* __restrict__ wpsi,
+                                                  const double* __restrict__ wbox, int n,
                                                   double* __restrict__ ref) {
     __shared__ double sd[4];
     __shared__ int si[4];
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ sta
     if (e >= E) return;
     const double px = states[4 * e], py = states[4 * e + 1], v = states[4 * e + 2], yaw = states[4 * e + 3];
     double bd; int ind;
-    nearest_scan(px, py, wx, wy, n, threadIdx.x, blockDim.x, bd, ind);   // :180
+    nearest_scan_boxed(px, py, wx, wy, wbox, n, threadIdx.x, blockDim.x, bd, ind);   // :180
     block_argmin(bd, ind, sd, si);
     const double travel = fabs(v) * dt;   // :189
     const double dind = travel / dl;      // :190
@@ -418,7 +419,7 @@ int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, co
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref) {
     if (E <= 0) return F1P_OK;
     hipLaunchKernelGGL(k_kmpc_ref, dim3(E), dim3(256), 0, ctx->stream, d_states, E, horizon, dt, dl, ctx->d_wx, ctx->d_wy,
-                       ctx->d_wv, ctx->d_wpsi, ctx->n_wp, d_ref);
+                       ctx->d_wv, ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, d_ref);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_ref launch");
 }
 

@@ -499,7 +499,7 @@ struct LatticeArgs {
     const double* goals;       // [E][C][3] or null
     const double* prev_theta;  // [E][S] or null
     int E, mode;
-    const double *wx, *wy, *wv, *wpsi;
+    const double *wx, *wy, *wv, *wpsi, *wbox;
     int n;
     GridDev grid;
     int has_grid;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
 
     // ---- 1. nearest raceline segment (K1 logic) ------------------------------------------------------
     double nd; int ni;
-    nearest_scan(px, py, a.wx, a.wy, a.n, tid, blockDim.x, nd, ni);
+    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, tid, blockDim.x, nd, ni);
     block_argmin(nd, ni, red_d, red_i);
     const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
 
@@ -791,7 +791,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     LatticeArgs a;
     a.poses = d_poses; a.goals = d_goals; a.prev_theta = d_prev_theta;
     a.E = E; a.mode = mode;
-    a.wx = ctx->d_wx; a.wy = ctx->d_wy; a.wv = ctx->d_wv; a.wpsi = ctx->d_wpsi; a.n = ctx->n_wp;
+    a.wx = ctx->d_wx; a.wy = ctx->d_wy; a.wv = ctx->d_wv; a.wpsi = ctx->d_wpsi; a.wbox = ctx->d_wbox; a.n = ctx->n_wp;
     a.grid = grid_dev(ctx);
     a.has_grid = ctx->has_grid ? 1 : 0;
     a.emit_idx = d_emit_idx; a.emit_cost = d_emit_cost;

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 // calc_ref_trajectory :195-233; states [E][4] = (x, y, v, yaw); ref [E][7][T+1] rows x, y, 0, v, yaw, 0, 0
 __global__ __launch_bounds__(256) void k_stmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
                                                    const double* __restrict__ wx, const double* __restrict__ wy,
-                                                   const double* __restrict__ wv, const double* __restrict__ wpsi, int n,
+                                                   const double* __restrict__ wv, const double* __restrict__ wpsi,
+                                                  const double* __restrict__ wbox, int n,
                                                    double* __restrict__ ref) {
     __shared__ double sd[4];
     __shared__ int si[4];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_stmpc_ref(const double* __restrict__ st
     if (e >= E) return;
     const double px = states[4 * e], py = states[4 * e + 1], v = states[4 * e + 2], yaw = states[4 * e + 3];
     double bd; int ind;
-    nearest_scan(px, py, wx, wy, n, threadIdx.x, blockDim.x, bd, ind);
+    nearest_scan_boxed(px, py, wx, wy, wbox, n, threadIdx.x, blockDim.x, bd, ind);
     block_argmin(bd, ind, sd, si);
     const double dind = (fabs(v) * dt) / dl;
     double* r = ref + (size_t)e * 7 * (T + 1);
@@ -193,7 +194,7 @@ int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, co
 int launch_stmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref) {
     if (E <= 0) return F1P_OK;
     hipLaunchKernelGGL(k_stmpc_ref, dim3(E), dim3(256), 0, ctx->stream, d_states, E, horizon, dt, dl, ctx->d_wx, ctx->d_wy, ctx->d_wv,
-                       ctx->d_wpsi, ctx->n_wp, d_ref);
+                       ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, d_ref);
     return check_hip(ctx, hipGetLastError(), "k_stmpc_ref launch");
 }
 

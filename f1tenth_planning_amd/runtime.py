@@ -195,6 +195,14 @@ class Context:
                                                     _ptr(out["near_idx"]), _ptr(out["la_idx"]), _ptr(out["status"])))
         return out
 
+    def pure_pursuit_dev(self, d_poses, E, lookahead, d_steer, d_speed, d_near_idx=None, d_la_idx=None, d_status=None,
+                         wheelbase=0.33, max_reacquire=20.0):
+        """Asynchronous launch on HBM-resident buffers; poses [E][3]."""
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_pure_pursuit_dev(self.h, p(d_poses), int(E), float(lookahead), float(wheelbase),
+                                                  float(max_reacquire), p(d_steer), p(d_speed), p(d_near_idx), p(d_la_idx),
+                                                  p(d_status)))
+
     # ---- Stanley / LQR (SURVEY 8f rank 1) --------------------------------------------------------------------
     def stanley(self, states, wheelbase=0.33, k_path=5.0):
         st = _f64(states, (-1, 4)); E = st.shape[0]

@@ -130,3 +130,32 @@ def test_planner_class_drop_in(golden, tracks):
         planner.plan(0, 0, 0, 0.8, waypoints=np.zeros((5, 2)))
     out = planner.plan_batch(g["poses"][g["lookahead"] == 0.8], 0.8, waypoints=tracks["spielberg"])
     np.testing.assert_allclose(out["steer"], g["steer_speed"][g["lookahead"] == 0.8, 0], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 65, 66, 129, 1000, 4097, 9000])
+def test_nearest_chunk_pruning_is_exact(ctx, orc, n):
+    """nearest_scan_boxed skips 64-segment chunks by bounding box; the (value, index) argmin must not change:
+    ragged chunk counts (more than 64 chunks at n = 9000), zero-length segments (their 0/0 = NaN wins np.argmin at any
+    distance), integer-lattice polylines with exact distance ties, and queries far outside the track."""
+    rng = np.random.default_rng(n)
+    ang = np.linspace(0, 2 * np.pi, n)
+    r = 20.0 + 3.0 * np.sin(5 * ang)
+    wp = np.column_stack([r * np.cos(ang), r * np.sin(ang), np.ones(n)])
+    q = np.concatenate([wp[rng.integers(0, n, 200), :2] + rng.normal(0, 0.5, (200, 2)),
+                        rng.uniform(-30, 30, (100, 2)), rng.uniform(-1e4, 1e4, (20, 2)), wp[rng.integers(0, n, 20), :2]])
+    cases = [wp]
+    lat = wp.copy(); lat[:, :2] = np.round(lat[:, :2])            # many duplicate rows (NaN segments) and ties
+    cases.append(lat)
+    if n > 70:
+        dup = wp.copy(); dup[n // 2 + 1] = dup[n // 2]            # exactly one zero-length segment
+        cases.append(dup)
+        sq = wp.copy(); sq[:, :2] = np.round(sq[:, :2] * 0.5) * 2.0; sq = sq[np.r_[True, (np.diff(sq[:, :2], axis=0) != 0).any(1)]]
+        if len(sq) >= 2:
+            cases.append(sq)                                      # lattice without duplicates: exact ties, no NaN
+    for w in cases:
+        ctx.set_waypoints(w, cols=(0, 1, 2, -1))
+        pr, d, t, i = ctx.nearest_point(q)
+        for e in range(len(q)):
+            p0, d0, t0, i0 = orc.nearest_point(q[e], w[:, :2])
+            assert i[e] == i0, (n, e)
+            np.testing.assert_array_equal(np.array([d[e], t[e], *pr[e]]), np.array([d0, t0, *p0]))
