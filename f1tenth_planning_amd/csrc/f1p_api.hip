@@ -205,7 +205,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -345,31 +345,79 @@ int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncol
     return F1P_OK;
 }
 
+static void drop_grid(f1p_ctx* ctx) {
+    if (ctx->d_bits) (void)hipFree(ctx->d_bits);
+    if (ctx->d_bits0) (void)hipFree(ctx->d_bits0);
+    ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0;
+}
+
 int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
                  int32_t occupied_below) {
     F1P_ENTER(ctx);
     if (!img) {   // clear
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_bits) (void)hipFree(ctx->d_bits);
-        ctx->d_bits = nullptr; ctx->has_grid = false;
+        drop_grid(ctx);
         return F1P_OK;
     }
     if (w < 1 || h < 1 || w > 65535 || h > 65535) return set_error(ctx, F1P_EINVAL, "grid size out of range");
     if (!(res > 0.0)) return set_error(ctx, F1P_EINVAL, "resolution must be > 0");
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_bits) { (void)hipFree(ctx->d_bits); ctx->d_bits = nullptr; ctx->has_grid = false; }
+    drop_grid(ctx);
     ctx->gw = w; ctx->gh = h; ctx->gwwords = (w + 31) / 32;
     ctx->res = res; ctx->inv_res = 1.0 / res; ctx->ox = ox; ctx->oy = oy;
+    const size_t bit_bytes = sizeof(uint32_t) * (size_t)ctx->gwwords * h;
     uint8_t* d_img = nullptr;
     F1P_HIP(ctx, hipMalloc((void**)&d_img, (size_t)w * h));
-    int rc = check_hip(ctx, hipMalloc((void**)&ctx->d_bits, sizeof(uint32_t) * (size_t)ctx->gwwords * h), "hipMalloc(bits)");
+    int rc = check_hip(ctx, hipMalloc((void**)&ctx->d_bits0, bit_bytes), "hipMalloc(bits)");
+    if (rc == F1P_OK) rc = check_hip(ctx, hipMalloc((void**)&ctx->d_bits, bit_bytes), "hipMalloc(bits)");
     if (rc == F1P_OK) rc = check_hip(ctx, hipMemcpyAsync(d_img, img, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(img)");
     if (rc == F1P_OK) rc = launch_pack_grid(ctx, d_img, w, h, occupied_below);
+    if (rc == F1P_OK) rc = check_hip(ctx, hipMemcpyAsync(ctx->d_bits, ctx->d_bits0, bit_bytes, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync(bits)");
     if (rc == F1P_OK) rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     (void)hipFree(d_img);
-    if (rc != F1P_OK) { if (ctx->d_bits) (void)hipFree(ctx->d_bits); ctx->d_bits = nullptr; return rc; }
+    if (rc != F1P_OK) { drop_grid(ctx); return rc; }
     ctx->has_grid = true;
     return F1P_OK;
+}
+
+static int edt_cap_check(f1p_ctx* ctx, int64_t cap) {
+    if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
+    if (cap < 1 || cap > 8192) return set_error(ctx, F1P_EINVAL, "distance cap must be within 1..8192 cells");
+    return F1P_OK;
+}
+
+int f1p_grid_distance_batch(f1p_ctx* ctx, float* dist, int32_t cap_cells) {
+    F1P_ENTER(ctx);
+    if (!dist) return set_error(ctx, F1P_EINVAL, "dist is NULL");
+    int rc = edt_cap_check(ctx, cap_cells);
+    if (rc) return rc;
+    const size_t n = (size_t)ctx->gw * ctx->gh;
+    float* d_dist = nullptr;
+    F1P_HIP(ctx, hipMalloc((void**)&d_dist, sizeof(float) * n));
+    rc = launch_grid_edt(ctx, cap_cells, 0u, d_dist, nullptr, nullptr);
+    if (rc == F1P_OK) rc = check_hip(ctx, hipMemcpy(dist, d_dist, sizeof(float) * n, hipMemcpyDeviceToHost), "hipMemcpy(dist)");
+    (void)hipFree(d_dist);
+    return rc;
+}
+
+int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
+    F1P_ENTER(ctx);
+    if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
+    if (!(radius >= 0.0) || !isfinite(radius)) return set_error(ctx, F1P_EINVAL, "inflation radius must be finite and >= 0");
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (radius == 0.0) {
+        F1P_HIP(ctx, hipMemcpy(ctx->d_bits, ctx->d_bits0, sizeof(uint32_t) * (size_t)ctx->gwwords * ctx->gh, hipMemcpyDeviceToDevice));
+        ctx->inflate_radius = 0.0;
+        return F1P_OK;
+    }
+    const double q = radius * ctx->inv_res;
+    const double thr = ceil(q * q);                       // integer d2 < q^2  <=>  d2 < ceil(q^2)
+    const int64_t cap = (int64_t)ceil(q) + 1;
+    int rc = edt_cap_check(ctx, cap);
+    if (rc) return rc;
+    rc = launch_grid_edt(ctx, (int)cap, (uint32_t)thr, nullptr, nullptr, ctx->d_bits);
+    if (rc == F1P_OK) ctx->inflate_radius = radius;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -24,7 +24,9 @@ struct f1p_ctx {
 
     // occupancy grid, bit-packed and row-flipped
     bool has_grid = false;
-    uint32_t* d_bits = nullptr;
+    uint32_t* d_bits = nullptr;    // active collision bitmap (the uploaded grid, or its inflation by f1p_inflate_grid)
+    uint32_t* d_bits0 = nullptr;   // the grid as uploaded
+    double inflate_radius = 0.0;
     int gw = 0, gh = 0, gwwords = 0;
     double res = 0, inv_res = 0, ox = 0, oy = 0;
 
@@ -71,6 +73,7 @@ int launch_pure_pursuit(f1p_ctx* ctx, const double* d_poses, int E, double looka
                         double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near, int32_t* d_la,
                         int32_t* d_status);
 int launch_pack_grid(f1p_ctx* ctx, const uint8_t* d_img, int w, int h, int occupied_below);
+int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uint32_t* d_d2, uint32_t* d_bits_out);
 
 enum LatticeMode { LATTICE_FULL = 0, LATTICE_EVAL = 1, LATTICE_EMIT = 2 };
 int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,

@@ -126,7 +126,7 @@ int launch_pure_pursuit(f1p_ctx* ctx, const double* d_poses, int E, double looka
 int launch_pack_grid(f1p_ctx* ctx, const uint8_t* d_img, int w, int h, int occupied_below) {
     dim3 grid((ctx->gwwords + 255) / 256, h);
     hipLaunchKernelGGL(k_pack_grid, grid, dim3(256), 0, ctx->stream, d_img, w, h, ctx->gwwords, occupied_below,
-                       ctx->d_bits);
+                       ctx->d_bits0);
     return check_hip(ctx, hipGetLastError(), "k_pack_grid launch");
 }
 

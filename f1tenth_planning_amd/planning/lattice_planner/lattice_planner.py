@@ -59,6 +59,7 @@ class LatticePlanner():
         self._device = device
         self._ctx = None
         self._map = None
+        self._inflate = 0.0
 
     # ---- plug-in API (lattice_planner.py:57-111) -------------------------------------------------------------
     def add_cost_function(self, func):
@@ -105,10 +106,12 @@ class LatticePlanner():
                 raise ValueError("generator must be 'clothoid' or 'cubic'")
             self.generator = generator
 
-    def set_map(self, image, resolution, origin, occupied_thresh=0.65, negate=0):
+    def set_map(self, image, resolution, origin, occupied_thresh=0.65, negate=0, inflate=0.0):
         """Occupancy image in the ROS map_server layout (examples/control/Spielberg_map.yaml:1-6): u8 [h, w], row 0 at
         the top, `origin` = world (x, y[, yaw]) of the lower-left pixel.  A cell is occupied when its occupancy
-        probability (255 - v)/255 (v/255 if negate) exceeds occupied_thresh."""
+        probability (255 - v)/255 (v/255 if negate) exceeds occupied_thresh.  `inflate` (metres) dilates the occupied set by
+        a disc on the device (distance-transform preprocessor), turning the per-station point test into a disc-footprint
+        test -- e.g. 0.155 for the half width of the reference's 0.58 m x 0.31 m vehicle (kinematic_mpc.py:60-61)."""
         image = np.asarray(image)
         if image.ndim != 2:
             raise ValueError("map image must be 2-D")
@@ -119,14 +122,17 @@ class LatticePlanner():
             img = 255 - img
         occupied_below = int(np.ceil(255.0 * (1.0 - occupied_thresh)))      # v < 255 (1 - thresh)  <=>  p > thresh
         self._map = (np.ascontiguousarray(img), float(resolution), (float(origin[0]), float(origin[1])), occupied_below)
+        self._inflate = float(inflate)
         if self._ctx is not None:
             self._ctx.set_grid(*self._map)
+            if self._inflate > 0.0:
+                self._ctx.inflate_grid(self._inflate)
 
-    def load_map(self, yaml_path):
+    def load_map(self, yaml_path, inflate=0.0):
         """Read a ROS map_server YAML + image (examples/control/Spielberg_map.yaml) and install it as the occupancy grid."""
         from ...io import load_map
         m = load_map(yaml_path)
-        self.set_map(m["image"], m["resolution"], m["origin"], occupied_thresh=m["occupied_thresh"], negate=0)   # negate already applied
+        self.set_map(m["image"], m["resolution"], m["origin"], occupied_thresh=m["occupied_thresh"], negate=0, inflate=inflate)   # negate already applied
         return m
 
     # ---- reference methods ------------------------------------------------------------------------------------------
@@ -165,6 +171,8 @@ class LatticePlanner():
             self._ctx = Context(dev)
             if self._map is not None:
                 self._ctx.set_grid(*self._map)
+                if self._inflate > 0.0:
+                    self._ctx.inflate_grid(self._inflate)
         return self._ctx
 
     def _bind(self, waypoints):

@@ -163,6 +163,20 @@ class Context:
         self._check(self.lib.f1p_set_grid(self.h, _ptr(img), img.shape[1], img.shape[0], float(resolution),
                                           float(origin[0]), float(origin[1]), int(occupied_below)))
         self.has_grid = True
+        self._grid_shape = (int(img.shape[0]), int(img.shape[1]))
+
+    def grid_distance(self, cap_cells=64):
+        """Euclidean distance transform of the installed grid -> f32 [h, w] metres in the image's row order, saturated at
+        cap_cells * resolution (f1p_grid_distance_batch)."""
+        if not self.has_grid:
+            raise F1PError(_abi.F1P_ESTATE, "occupancy grid not set")
+        dist = np.empty(self._grid_shape, dtype=np.float32)
+        self._check(self.lib.f1p_grid_distance_batch(self.h, _ptr(dist), int(cap_cells)))
+        return dist
+
+    def inflate_grid(self, radius):
+        """Dilate the collision bitmap by a disc of `radius` metres (0 restores the uploaded grid)."""
+        self._check(self.lib.f1p_inflate_grid(self.h, float(radius)))
 
     # ---- leaf kernels ----------------------------------------------------------------------------------
     def nearest_point(self, pts):

@@ -182,6 +182,18 @@ int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncol
 int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
                  int32_t occupied_below);
 
+/* Occupancy -> distance-transform preprocessor (the reference's collision hook is the stub
+ * map_collision(points, map), utils/utils.py:297-301, and its vehicle is 0.58 m x 0.31 m, kinematic_mpc.py:60-61).
+ * dist: row-major [h][w] f32 in the image's row order (row 0 = top): Euclidean distance in metres between cell centres
+ * from every cell to the nearest occupied cell of the grid installed by f1p_set_grid (0 on occupied cells; cells
+ * outside the image count as occupied, like the collision test), saturated at cap_cells * resolution.  The squared
+ * distance in cells is an exact integer, so the result is bit-identical to the CPU restatement. */
+int f1p_grid_distance_batch(f1p_ctx* ctx, float* dist, int32_t cap_cells);
+/* Make the collision test footprint-aware: the active bitmap becomes the uploaded grid dilated by a disc of `radius`
+ * metres (a cell is occupied iff its distance to an occupied cell is < radius), so the point test of every station is a
+ * disc test.  radius = 0 restores the uploaded grid.  Planning kernels are unchanged. */
+int f1p_inflate_grid(f1p_ctx* ctx, double radius);
+
 /* ------------------------------------------------------------------------------------------------
  * Leaf kernels of utils/utils.py, batched over E query points against the ctx waypoints.
  * ---------------------------------------------------------------------------------------------- */

@@ -924,3 +924,59 @@ ORC_API void orc_stmpc_shoot_batch(const double* x0, const double* ref, const fl
         free(seq);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Occupancy -> distance transform / disc inflation.  No reference code: the     */
+/* reference's collision hook is the stub map_collision (utils/utils.py:297-301).  Definition, by      */
+/* exhaustive search: squared Euclidean distance in cells from cell (gx, gy) to the nearest occupied    */
+/* cell, cells outside the image being occupied, saturated at cap^2.                                    */
+/* ------------------------------------------------------------------------------------------------ */
+static int orc_cell_occ_idx(const orc_grid* g, int gx, int gy) {
+    if (gx < 0 || gy < 0 || gx >= g->w || gy >= g->h) return 1;
+    return g->img[(size_t)(g->h - 1 - gy) * g->w + gx] < g->occupied_below;
+}
+
+/* d2 [h][w] indexed [gy][gx] (gy = 0 is the BOTTOM image row) */
+ORC_API void orc_grid_d2(const orc_grid* g, int cap, uint32_t* d2, int nthreads) {
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int gy = 0; gy < g->h; ++gy)
+        for (int gx = 0; gx < g->w; ++gx) {
+            uint32_t best = (uint32_t)cap * (uint32_t)cap;
+            for (int dy = -cap; dy <= cap; ++dy) {
+                if ((uint32_t)(dy * dy) >= best) continue;
+                for (int dx = -cap; dx <= cap; ++dx) {
+                    uint32_t q = (uint32_t)(dx * dx + dy * dy);
+                    if (q < best && orc_cell_occ_idx(g, gx + dx, gy + dy)) best = q;
+                }
+            }
+            d2[(size_t)gy * g->w + gx] = best;
+        }
+}
+
+/* dist [h][w] f32 metres in IMAGE row order (row 0 = top), like f1p_grid_distance_batch */
+ORC_API void orc_grid_distance(const orc_grid* g, int cap, float* dist, int nthreads) {
+    uint32_t* d2 = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)g->w * g->h);
+    orc_grid_d2(g, cap, d2, nthreads);
+    for (int gy = 0; gy < g->h; ++gy)
+        for (int gx = 0; gx < g->w; ++gx)
+            dist[(size_t)(g->h - 1 - gy) * g->w + gx] = (float)(g->res * sqrt((double)d2[(size_t)gy * g->w + gx]));
+    free(d2);
+}
+
+/* out [h][w] u8, image row order: 0 where the distance to an occupied cell is < radius, else the input value */
+ORC_API void orc_inflate_image(const orc_grid* g, double radius, uint8_t* out, int nthreads) {
+    double q = radius * (1.0 / g->res);
+    double thr = ceil(q * q);
+    int cap = (int)ceil(q) + 1;
+    uint32_t* d2 = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)g->w * g->h);
+    orc_grid_d2(g, cap, d2, nthreads);
+    for (int gy = 0; gy < g->h; ++gy)
+        for (int gx = 0; gx < g->w; ++gx) {
+            size_t k = (size_t)(g->h - 1 - gy) * g->w + gx;
+            out[k] = ((double)d2[(size_t)gy * g->w + gx] < thr) ? 0 : g->img[k];
+        }
+    free(d2);
+}

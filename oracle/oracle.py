@@ -145,6 +145,22 @@ def make_grid(img, res, ox, oy, occupied_below):
     return g, img  # keep img alive
 
 
+def grid_distance(img, res, occupied_below, cap_cells, nthreads=1):
+    """Exhaustive-search distance transform -> f32 [h, w] metres, image row order (orc_grid_distance)."""
+    g, keep = make_grid(img, res, 0.0, 0.0, occupied_below)
+    out = np.empty(keep.shape, dtype=np.float32)
+    lib().orc_grid_distance(C.byref(g), C.c_int(int(cap_cells)), _p(out), C.c_int(nthreads))
+    return out
+
+
+def inflate_image(img, res, occupied_below, radius, nthreads=1):
+    """u8 image with every cell closer than `radius` to an occupied cell set to 0 (orc_inflate_image)."""
+    g, keep = make_grid(img, res, 0.0, 0.0, occupied_below)
+    out = np.empty(keep.shape, dtype=np.uint8)
+    lib().orc_inflate_image(C.byref(g), C.c_double(radius), _p(out), C.c_int(nthreads))
+    return out
+
+
 def cell_occupied(grid, x, y):
     lib().orc_cell_occupied.restype = C.c_int
     return bool(lib().orc_cell_occupied(C.byref(grid), C.c_double(x), C.c_double(y)))
