@@ -147,6 +147,8 @@ PROTOTYPES = {
     "f1p_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(_I), C.c_char_p, C.c_size_t]),
     "f1p_dev_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "f1p_dev_free": (C.c_int, [_P, _P]),
+    "f1p_host_alloc": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_size_t]),
+    "f1p_host_free": (C.c_int, [_P, _P]),
     "f1p_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "f1p_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "f1p_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),

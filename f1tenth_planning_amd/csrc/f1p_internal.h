@@ -12,6 +12,8 @@ struct f1p_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t copy_stream = nullptr;           // D2H of one slice of a large batch while the next slice is planned
+    hipEvent_t ev_chunk[8] = {};
     std::string err;
     hipDeviceProp_t prop;
 

@@ -79,6 +79,8 @@ class Context:
         self.n_waypoints = 0
         self._wp_key = None
         self.has_grid = False
+        self._pinned = {}        # (tag, shape, dtype) -> numpy view of page-locked memory
+        self._pinned_ptrs = []
 
     # ---- housekeeping ------------------------------------------------------------------------------
     def _check(self, rc):
@@ -87,6 +89,10 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None) is not None:
+            for ptr in self._pinned_ptrs:
+                self.lib.f1p_host_free(self.h, ptr)
+            self._pinned_ptrs = []
+            self._pinned = {}
             self.lib.f1p_destroy(self.h)
             self.h = None
 
@@ -112,6 +118,23 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def pinned(self, tag, shape, dtype):
+        """numpy array on page-locked host memory (f1p_host_alloc), cached per (tag, shape, dtype) and owned by the
+        context: valid until close().  The *_batch calls DMA directly from / into such arrays."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        key = (tag, shape, dtype.str)
+        arr = self._pinned.get(key)
+        if arr is None:
+            nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+            ptr = C.c_void_p()
+            self._check(self.lib.f1p_host_alloc(self.h, C.byref(ptr), C.c_size_t(nbytes)))
+            self._pinned_ptrs.append(ptr)
+            buf = (C.c_char * nbytes).from_address(ptr.value)
+            arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+            self._pinned[key] = arr
+        return arr
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -235,14 +258,26 @@ class Context:
         return out
 
     # ---- lattice -------------------------------------------------------------------------------------------
-    def lattice_plan(self, poses, cfg: LatticeCfg, goals=None, prev_theta=None, want_traj=True, want_all=False):
+    def lattice_plan(self, poses, cfg: LatticeCfg, goals=None, prev_theta=None, want_traj=True, want_all=False,
+                     reuse_outputs=False):
+        """reuse_outputs: results land in page-locked arrays owned by the context (no bounce buffers, no fresh pages per
+        call); they are overwritten by the next call with the same batch shape."""
         poses = _f64(poses, (-1, 4)); E = poses.shape[0]; Cn = cfg.n_cand; S = cfg.n_stations
         g = None if goals is None else _f64(goals, (E, Cn, 3))
         pt = None if prev_theta is None else _f64(prev_theta, (E, S))
-        out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
-                   status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
-        if want_traj:
-            out["best_traj"] = np.empty((E, S, 4))
+        if reuse_outputs:
+            pin = self.pinned
+            hp = pin("lat_poses", (E, 4), np.float64); hp[...] = poses; poses = hp
+            out = dict(steer=pin("lat_steer", E, np.float64), speed=pin("lat_speed", E, np.float64),
+                       best_idx=pin("lat_bidx", E, np.int32), best_cost=pin("lat_bcost", E, np.float64),
+                       status=pin("lat_status", E, np.int32), near_idx=pin("lat_near", E, np.int32))
+            if want_traj:
+                out["best_traj"] = pin("lat_traj", (E, S, 4), np.float64)
+        else:
+            out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
+                       status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
+            if want_traj:
+                out["best_traj"] = np.empty((E, S, 4))
         if want_all:
             out["all_cost"] = np.empty((E, Cn)); out["all_traj"] = np.empty((E, Cn, S, 4))
         self._check(self.lib.f1p_lattice_plan_batch(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),

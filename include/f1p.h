@@ -154,6 +154,10 @@ int f1p_h2d(f1p_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);  /
 int f1p_d2h(f1p_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);  /* async on the ctx stream */
 int f1p_memset(f1p_ctx* ctx, void* dst_dev, int value, size_t bytes);          /* async on the ctx stream */
 int f1p_sync(f1p_ctx* ctx);                                                    /* hipStreamSynchronize   */
+/* page-locked host memory: the *_batch entry points DMA straight from / into such buffers instead of going through
+ * the runtime's bounce buffers (a plan() that hands over pinned pose / result arrays saves ~0.1 ms per 4096 egos) */
+int f1p_host_alloc(f1p_ctx* ctx, void** hptr, size_t bytes);
+int f1p_host_free(f1p_ctx* ctx, void* hptr);
 
 /* HIP-event timing on the ctx stream (the stream the kernels are launched on):
  * f1p_timer_begin records an event, f1p_timer_end records a second one, synchronises it and returns the

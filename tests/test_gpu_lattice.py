@@ -198,3 +198,21 @@ def test_cubic_generator_vs_oracle(ctx, orc, scene):
     _compare(g2, w2, tol_traj=1e-12)
     with pytest.raises(ValueError):
         _abi.lattice_cfg(generator="bezier")
+
+
+def test_pinned_pipelined_batch_equals_plain_batch(ctx, scene):
+    """With page-locked result arrays a batch >= 2048 egos is planned in two slices whose D2H overlaps the next slice
+    (f1p_lattice_plan_batch); every output must be bit-identical to the single-launch path, also for an odd split."""
+    rl, img, origin = scene
+    cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50)
+    for E in (2049, 4096):
+        poses = synth.make_egos(rl, E, seed=77)
+        plain = ctx.lattice_plan(poses, cfg)
+        pinned = ctx.lattice_plan(poses, cfg, reuse_outputs=True)
+        for k in plain:
+            np.testing.assert_array_equal(np.asarray(pinned[k]), plain[k], err_msg=k)
+        prev = plain["best_traj"][:, :, 2].copy()
+        a = ctx.lattice_plan(poses, cfg, prev_theta=prev)
+        b = ctx.lattice_plan(poses, cfg, prev_theta=prev, reuse_outputs=True)
+        for k in a:
+            np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=k)
