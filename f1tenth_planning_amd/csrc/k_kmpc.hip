@@ -94,7 +94,7 @@ __device__ __forceinline__ void kmpc_rollouts(const float* __restrict__ ce, cons
 // the ego state (so every quantity is O(10) and the f32 rounding stays ~1e-6 relative).  It only has to RANK rollouts
 // coarsely: every rollout whose f32 cost is within the margin (F1P_K4_MARGIN_REL per time step, relative, + F1P_K4_MARGIN_ABS) of the f32 minimum is re-evaluated in fp64 by the code
 // above, and the decision is taken on those fp64 costs -- so the result is the fp64 argmin as long as the f32 error is below
-// half the margin (measured at T = 30: f32 error < 5 % of the margin of 1e-2 relative + 0.05 absolute; tests/test_gpu_kmpc.py
+// half the margin (measured at T = 30: f32 error = 2.5 % of the margin of 1e-4 relative + 0.02 absolute; tests/test_gpu_kmpc.py
 // checks both the error against the margin and the bit-identity of the results with the plain fp64 kernel).
 // ---------------------------------------------------------------------------------------------------
 struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; };
@@ -103,6 +103,15 @@ struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_a
 // consumed afterwards: with one load pair per step the kernel is bound by HBM latency (~1 TB/s), not bandwidth.
 #ifndef F1P_K4_CHUNK
 #define F1P_K4_CHUNK 10
+#endif
+#ifndef F1P_K4_PACKED
+#define F1P_K4_PACKED 1
+#endif
+#ifndef F1P_K4_WAVES_FILTER
+#define F1P_K4_WAVES_FILTER 4
+#endif
+#ifndef F1P_K4_CHUNK2
+#define F1P_K4_CHUNK2 5   // time steps per register buffer of the packed filter (4 x CHUNK2 VGPRs)
 #endif
 __device__ __forceinline__ float kmpc_rollout_cost_f32(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R, int r) {
     float x = 0.f, y = 0.f, v = k.v0, yaw = 0.f, cost = 0.f, pa = 0.f, pd = 0.f;
@@ -152,71 +161,250 @@ __device__ __forceinline__ float kmpc_rollout_cost_f32(const float* __restrict__
     return cost;
 }
 
-// relative margin PER TIME STEP of the horizon (the f32 state error grows with the number of steps): 30 steps -> 1e-2
+// Two rollouts per thread in the lanes of packed-f32 instructions: plain f32 VALU ops issue 16 lanes per clock on CDNA4 and
+// only v_pk_{fma,mul,add}_f32 reach the 32-lane f32 rate, so the filter -- which is VALU-bound once the control stream is
+// prefetched -- evaluates rollouts r0 and r1 as the two halves of <2 x float> values.  Clamps are single v_med3_f32.
+typedef float f1p_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f1p_f2 med3x2(f1p_f2 x, float lo, float hi) {
+    f1p_f2 r;
+    r.x = __builtin_amdgcn_fmed3f(x.x, lo, hi);
+    r.y = __builtin_amdgcn_fmed3f(x.y, lo, hi);
+    return r;
+}
+// POLY: the heading phasor (cos yaw, sin yaw) is carried along and rotated by the step's heading increment with degree-8 / 9
+// Taylor polynomials (|increment| <= 0.85 rad, checked by the caller) -- packed FMAs instead of four quarter-rate
+// v_sin / v_cos per step; tan of the clamped steering angle likewise (|d| <= 0.6).  Contraction is on in here: this is the
+// filter, its error budget is the refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
+struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd, hc, hs; };
+
+__device__ __forceinline__ void kmpc_load_chunk2(const float* __restrict__ ce, int T, int R, int r0, int r1, int t0,
+                                                 f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
+#pragma unroll
+    for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
+        const int t = t0 + j < T ? t0 + j : T - 1;                     // clamp: the tail re-reads the last step (unused)
+        const float* row = ce + (size_t)t * 2 * R;
+        av[j].x = row[r0]; av[j].y = row[r1];
+        dv[j].x = row[R + r0]; dv[j].y = row[R + r1];
+    }
+}
+
+template <bool POLY>
+__device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, const KmpcF32& k, int T, int t0,
+                                            const f1p_f2 (&av)[F1P_K4_CHUNK2], const f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
+        const int t = t0 + j;
+        if (t < T) {
+            const f1p_f2 a = med3x2(av[j], -k.max_accel, k.max_accel);
+            f1p_f2 d = med3x2(dv[j], -k.max_steer, k.max_steer);
+            if (t > 0) {
+                const f1p_f2 lo = s.pd - k.dmax, hi = s.pd + k.dmax;
+                d.x = __builtin_amdgcn_fmed3f(d.x, lo.x, hi.x);
+                d.y = __builtin_amdgcn_fmed3f(d.y, lo.y, hi.y);
+            }
+            const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + t], e1 = s.y - sref32[1 * (T + 1) + t];
+            const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + t], e3 = s.yaw - sref32[3 * (T + 1) + t];
+            s.cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
+            if (t > 0) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
+            f1p_f2 cy, sy;                                             // cos / sin of the absolute heading
+            if (POLY) {
+                cy = s.hc; sy = s.hs;
+            } else {
+                float sn0, cs0, sn1, cs1;
+                __sincosf(s.yaw.x, &sn0, &cs0);
+                __sincosf(s.yaw.y, &sn1, &cs1);
+                f1p_f2 sn, cs;
+                sn.x = sn0; sn.y = sn1; cs.x = cs0; cs.y = cs1;
+                cy = k.c0 * cs - k.s0 * sn; sy = k.s0 * cs + k.c0 * sn;
+            }
+            const f1p_f2 vdt = s.v * k.dt;
+            s.x += vdt * cy;
+            s.y += vdt * sy;
+            f1p_f2 tn;
+            if (POLY) {                                                // odd Taylor polynomial to d^11: relative error < 1e-7 for |d| <= 0.6
+                const f1p_f2 d2 = d * d;
+                tn = d * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
+            } else {
+                tn.x = __tanf(d.x); tn.y = __tanf(d.y);
+            }
+            const f1p_f2 dyaw = s.v * k.inv_wb_dt * tn;
+            s.yaw += dyaw;
+            if (POLY) {
+                const f1p_f2 z = dyaw * dyaw;
+                const f1p_f2 sd = dyaw * (1.0f + z * (-0.16666667f + z * (8.3333333e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f))));
+                const f1p_f2 cd = 1.0f + z * (-0.5f + z * (4.1666667e-2f + z * (-1.3888889e-3f + z * 2.4801587e-5f)));
+                const f1p_f2 nc = s.hc * cd - s.hs * sd;
+                s.hs = s.hs * cd + s.hc * sd;
+                s.hc = nc;
+            }
+            s.v = med3x2(s.v + a * k.dt, k.min_speed, k.max_speed);
+            s.pa = a; s.pd = d;
+        }
+    }
+}
+
+// POLY: the heading phasor (cos yaw, sin yaw) is carried along and rotated by the step's heading increment with degree-8 / 9
+// Taylor polynomials (|increment| <= 0.85 rad, checked by the caller) -- packed FMAs instead of four quarter-rate
+// v_sin / v_cos per step; tan of the clamped steering angle likewise (|d| <= 0.6).  Contraction is on in the step function:
+// this is the filter, its error budget is the refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
+// The controls of F1P_K4_CHUNK2 time steps are requested up front (4 x CHUNK2 independent 256-byte wave loads in flight).
+template <bool POLY>
+__device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R,
+                                                         int r0, int r1) {
+    KmpcState2 s;
+    s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f; s.hc = k.c0; s.hs = k.s0;
+    for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK2) {
+        f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
+        kmpc_load_chunk2(ce, T, R, r0, r1, t0, a0, d0);
+        kmpc_steps2<POLY>(s, sref32, k, T, t0, a0, d0);
+    }
+    const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + T], e1 = s.y - sref32[1 * (T + 1) + T];
+    const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + T], e3 = s.yaw - sref32[3 * (T + 1) + T];
+    s.cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3;
+    return s.cost;
+}
+
+// Refinement margin.  Measured f32 filter error against the fp64 cost (tools/f32_filter_error.py on the GPU: T = 8, 30, 60,
+// three control distributions, headings up to 14 pi): relative error <= 1.4 T u with u = 2^-24, i.e. 2.5e-6 at T = 30.  The
+// relative margin is 57 T u PER TIME STEP of the horizon (1e-4 at T = 30): 40x the measured error, 20x the half-margin the
+// exactness argument needs; the absolute part covers costs near zero.  tests/test_gpu_kmpc.py re-measures the ratio.
 #ifndef F1P_K4_MARGIN_REL
-#define F1P_K4_MARGIN_REL 3.4e-4f
+#define F1P_K4_MARGIN_REL 3.4e-6f
 #endif
 #ifndef F1P_K4_MARGIN_ABS
-#define F1P_K4_MARGIN_ABS 5.0e-2f
+#define F1P_K4_MARGIN_ABS 2.0e-2f
 #endif
 #define F1P_K4_MAX_REFINE 64
 
-// Mixed-precision shooting: f32 filter over all rollouts (HBM-streaming, 8 B per rollout-step), fp64 refinement of the
-// near-minimum set by wave 0, decision on the fp64 costs.  `cost32_out` (nullable, [E][R]) exposes the filter costs so a
-// test can measure the f32 error against the margin.
-__global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot_mixed(const double* __restrict__ x0, const double* __restrict__ ref,
-                                                          const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
+// the winner's applied sequence (clamp, then the sequential rate limit) and the per-ego outputs; one thread
+__device__ __forceinline__ void kmpc_emit(const float* __restrict__ ce, const f1p_kmpc_cfg& cfg, double sv, double dmax, int e, int bi,
+                                          double bc, double* __restrict__ steer, double* __restrict__ speed,
+                                          int32_t* __restrict__ best_idx, double* __restrict__ best_cost, double* __restrict__ best_seq) {
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    double pd = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
+        double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
+        if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
+        if (t == 0) {
+            steer[e] = d;                       // :506  steer_output = odelta_v[0]
+            speed[e] = sv + a * cfg.dt;         // :508  speed_output = v + oa[0] * DTK
+        }
+        if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
+        else if (t == 0) break;
+        pd = d;
+    }
+    best_idx[e] = bi;
+    if (best_cost) best_cost[e] = bc;
+}
+
+// fp64 re-evaluation by the whole workgroup (all 256 threads must call it; workgroup-uniform arguments).  n > 0: the listed
+// survivors, one lane each; n < 0: every rollout, one lane per rollout (the code of the plain kernel).  `sref` is LDS scratch
+// of 4 (T+1) + 4 doubles + 4 ints.
+__device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref, const float* __restrict__ ce, const f1p_kmpc_cfg& cfg,
+                                                  double sx, double sy, double sv, double syaw, int e, int n, const int* list, double* sref,
+                                                  double* __restrict__ steer, double* __restrict__ speed, int32_t* __restrict__ best_idx,
+                                                  double* __restrict__ best_cost, double* __restrict__ best_seq, int32_t* __restrict__ n_refined) {
+    const int T = cfg.horizon, tid = threadIdx.x;
+    double* red_d = sref + 4 * (T + 1);
+    int* red_i = reinterpret_cast<int*>(red_d + 4);
+    for (int q = tid; q < 4 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 4 * (T + 1) + q];
+    __syncthreads();
+    const double dmax = cfg.max_dsteer * cfg.dt;
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    if (n > 0) {
+        if (tid < n) { bi = list[tid]; bc = kmpc_rollout_cost<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, bi); }
+    } else {
+        const bool fast = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4;   // workgroup-uniform
+        if (fast) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
+        else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
+    }
+    block_argmin(bc, bi, red_d, red_i);
+    if (tid == 0) {
+        kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq);
+        if (n_refined) n_refined[e] = n;
+    }
+}
+
+// Mixed-precision shooting: the f32 filter over all rollouts (HBM-streaming, 8 B per rollout-step), then -- only for the ~1 %
+// of the egos whose near-minimum set holds more than one rollout, or when the cost is requested -- the fp64 re-evaluation
+// of that set by the same workgroup (kmpc_refine_block: the reference's arithmetic, decision on those fp64 costs, so index,
+// cost and outputs are bit-identical to k_kmpc_shoot).  The filter's constants arrive converted from the host as a kernel
+// argument (SGPRs).  `cost32_out` (nullable, [E][R]) exposes the filter costs so a test can measure the f32 error against
+// the margin; `n_refined` (nullable) the size of the refined set (-1: everything in fp64).
+__global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(const double* __restrict__ x0, const double* __restrict__ ref,
+                                                          const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg, KmpcF32 kf,
                                                           double* __restrict__ steer, double* __restrict__ speed,
                                                           int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
                                                           double* __restrict__ best_seq, float* __restrict__ cost32_out,
                                                           int32_t* __restrict__ n_refined) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* sref = reinterpret_cast<double*>(lds_raw);               // [4][T+1] absolute, fp64 (refinement)
-    double* red_d = sref + 4 * (T + 1);                               // [4]
-    float* sref32 = reinterpret_cast<float*>(red_d + 4);              // [4][T+1] relative to the ego state, f32 (filter)
+    float* sref32 = reinterpret_cast<float*>(lds_raw);                // [4][T+1] relative to the ego state, f32
     float* c32 = sref32 + 4 * (T + 1);                                // [R] filter costs
     float* red_f = c32 + R;                                           // [4]
     int* list = reinterpret_cast<int*>(red_f + 4);                    // [F1P_K4_MAX_REFINE]
     int* cnt = list + F1P_K4_MAX_REFINE;                              // [1]
-    int* red_i = cnt + 1;                                             // [4]
+    double* sref = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(cnt + 1) + 7) & ~(uintptr_t)7);   // [4][T+1] + [4] + int [4]: fp64 refinement only
     const int e = blockIdx.x;
     if (e >= E) return;
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
+    const float* ce = controls + (size_t)e * T * 2 * R;
+    if (!(fabs(syaw) <= 1.0e4) || !(fabs(cfg.max_steer) <= 1.0e4)) {  // workgroup-uniform: outside the fast paths' ranges
+        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
+        return;
+    }
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
-        sref[q] = rv;
         const int row = q / (T + 1);
         sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, then rounded
     }
     if (tid == 0) *cnt = 0;
     __syncthreads();
-    const float* ce = controls + (size_t)e * T * 2 * R;
-    const double dmax = cfg.max_dsteer * cfg.dt;
-    KmpcF32 k;
-    for (int i = 0; i < 4; ++i) { k.q[i] = (float)cfg.q[i]; k.qf[i] = (float)cfg.qf[i]; }
-    for (int i = 0; i < 2; ++i) { k.r[i] = (float)cfg.r[i]; k.rd[i] = (float)cfg.rd[i]; }
-    k.dt = (float)cfg.dt; k.inv_wb_dt = (float)(cfg.dt / cfg.wheelbase); k.max_steer = (float)cfg.max_steer; k.max_accel = (float)cfg.max_accel;
-    k.max_speed = (float)cfg.max_speed; k.min_speed = (float)cfg.min_speed; k.dmax = (float)dmax; k.v0 = (float)sv;
+    // the constants arrive converted from the host (kernel argument -> SGPRs); the three per-ego values are made scalar too,
+    // so the filter's VGPRs hold only the two rollouts' state and the control buffers
+    KmpcF32 k = kf;
     double s0d, c0d;
-    sincos(syaw, &s0d, &c0d);
-    k.c0 = (float)c0d; k.s0 = (float)s0d;
+    sincos_core(syaw, &s0d, &c0d);
+    k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
+    k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
+    k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
 
     // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
     float fmin_ = __builtin_huge_valf();
+#if F1P_K4_PACKED
+    // polynomial phasor / tan only inside their proven ranges (workgroup-uniform): |steer| <= 0.6 rad and a heading increment
+    // per step of at most 0.85 rad at the speed limits
+    const float vmax = fmaxf(fabsf(k.max_speed), fmaxf(fabsf(k.min_speed), fabsf(k.v0)));
+    const bool poly = k.max_steer <= 0.6f && vmax * fabsf(k.inv_wb_dt) * 0.6841368f <= 0.85f;     // tan(0.6) = 0.68413...
+    for (int r = tid; r < R; r += 2 * blockDim.x) {                    // rollouts r and r + 256 share the packed lanes
+        const int r1 = r + (int)blockDim.x < R ? r + (int)blockDim.x : r;
+        const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(ce, sref32, k, T, R, r, r1) : kmpc_rollout_cost_f32x2<false>(ce, sref32, k, T, R, r, r1);
+        c32[r] = c.x;
+        if (cost32_out) cost32_out[(size_t)e * R + r] = c.x;
+        fmin_ = fminf(fmin_, c.x);                                     // NaN costs are ignored here and caught below
+        if (r1 != r) {
+            c32[r1] = c.y;
+            if (cost32_out) cost32_out[(size_t)e * R + r1] = c.y;
+            fmin_ = fminf(fmin_, c.y);
+        }
+    }
+#else
     for (int r = tid; r < R; r += blockDim.x) {
         const float c = kmpc_rollout_cost_f32(ce, sref32, k, T, R, r);
         c32[r] = c;
         if (cost32_out) cost32_out[(size_t)e * R + r] = c;
-        fmin_ = fminf(fmin_, c);                                       // NaN costs are ignored here and caught by the fallback below
+        fmin_ = fminf(fmin_, c);
     }
+#endif
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
     if (lane == 0) red_f[wave] = fmin_;
     __syncthreads();
     fmin_ = fminf(fminf(red_f[0], red_f[1]), fminf(red_f[2], red_f[3]));
     const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
-    // ---- pass B: the near-minimum set -> LDS list ---------------------------------------------------------------------
+    // ---- pass B: the near-minimum set -> list -------------------------------------------------------------------------
     for (int r = tid; r < R; r += blockDim.x) {
         const float c = c32[r];
         if (!(c > thr)) {                                              // includes NaN
@@ -226,41 +414,15 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot_mixed(const do
     }
     __syncthreads();
     const int n = *cnt;
-    const bool sane = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4 && isfinite(fmin_);
-    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
-    if (n > F1P_K4_MAX_REFINE || n < 1 || !sane) {
-        // ---- fallback: the plain fp64 evaluation of every rollout (pathological inputs, degenerate ties) ---------------
-        if (sane) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
-        else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
-        block_argmin(bc, bi, red_d, red_i);
-        if (tid == 0 && n_refined) n_refined[e] = -1;
+    if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
+        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
+    } else if (n == 1 && !best_cost) {
+        if (tid == 0) {                                                // a single survivor needs no fp64 cost unless it is asked for
+            kmpc_emit(ce, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq);
+            if (n_refined) n_refined[e] = 1;
+        }
     } else {
-        // ---- pass C: fp64 refinement of the listed rollouts by wave 0, decision on the fp64 costs ------------------------
-        if (wave != 0) return;
-        if (n == 1 && !best_cost) {
-            bi = list[0];                                              // a single survivor needs no fp64 cost unless it is asked for
-        } else {
-            if (lane < n) { bi = list[lane]; bc = kmpc_rollout_cost<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, bi); }
-            wave_argmin(bc, bi);
-        }
-        if (lane == 0 && n_refined) n_refined[e] = n;
-    }
-    if (tid == 0) {
-        double pd = 0.0;                                               // the winner's applied sequence: clamp, then the sequential rate limit
-        for (int t = 0; t < T; ++t) {
-            double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
-            double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
-            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
-            if (t == 0) {
-                steer[e] = d;                       // :506
-                speed[e] = sv + a * cfg.dt;         // :508
-            }
-            if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
-            else if (t == 0) break;
-            pd = d;
-        }
-        best_idx[e] = bi;
-        if (best_cost) best_cost[e] = bc;
+        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
     }
 }
 
@@ -287,24 +449,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot(const double* 
     if (fast) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     block_argmin(bc, bi, red_d, red_i);
-    if (tid == 0) {
-        // the winner's applied sequence: clamp, then the sequential rate limit
-        double pd = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
-            double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
-            if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
-            if (t == 0) {
-                steer[e] = d;                       // :506  steer_output = odelta_v[0]
-                speed[e] = sv + a * cfg.dt;         // :508  speed_output = v + oa[0] * DTK
-            }
-            if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
-            else if (t == 0) break;
-            pd = d;
-        }
-        best_idx[e] = bi;
-        if (best_cost) best_cost[e] = bc;
-    }
+    if (tid == 0) kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq);
 }
 
 // predict_motion_kinematic :208-221: one thread per ego, T sequential steps, path [E][4][T+1]
@@ -398,9 +543,16 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
     if (E <= 0) return F1P_OK;
     const size_t T1 = (size_t)cfg->horizon + 1;
     if (ctx->kmpc_mixed && cfg->n_rollouts <= 8192) {
-        size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(float) * (4 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 1 + 4);
-        hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
-                           *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref);
+        KmpcF32 kf;
+        for (int i = 0; i < 4; ++i) { kf.q[i] = (float)cfg->q[i]; kf.qf[i] = (float)cfg->qf[i]; }
+        for (int i = 0; i < 2; ++i) { kf.r[i] = (float)cfg->r[i]; kf.rd[i] = (float)cfg->rd[i]; }
+        kf.dt = (float)cfg->dt; kf.inv_wb_dt = (float)(cfg->dt / cfg->wheelbase); kf.max_steer = (float)cfg->max_steer;
+        kf.max_accel = (float)cfg->max_accel; kf.max_speed = (float)cfg->max_speed; kf.min_speed = (float)cfg->min_speed;
+        kf.dmax = (float)(cfg->max_dsteer * cfg->dt); kf.c0 = 1.f; kf.s0 = 0.f; kf.v0 = 0.f;
+        const size_t lds = sizeof(float) * (4 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 1) + 8 +
+                           sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
+        hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, kf,
+                           d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref);
         return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot_mixed launch");
     }
     const size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;

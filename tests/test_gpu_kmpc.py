@@ -173,7 +173,7 @@ def test_planner_class_drop_in(golden, tracks):
 def test_mixed_precision_filter_is_exact_and_within_margin(ctx, orc):
     """The default evaluation mode ranks the rollouts with an f32 filter and decides on fp64 re-evaluations of the near-minimum
     set.  (1) Its outputs are bit-identical to the plain fp64 mode and to the oracle's indices; (2) the measured f32 error is far
-    inside the refinement margin (1e-2 relative + 0.05 absolute), which is what makes (1) hold by construction."""
+    inside the refinement margin (3.4e-6 T relative = 1e-4 at T = 30, + 0.02 absolute), which is what makes (1) hold."""
     cl = synth.make_centerline(seed=2)
     ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
     rng = np.random.default_rng(21)
@@ -201,8 +201,8 @@ def test_mixed_precision_filter_is_exact_and_within_margin(ctx, orc):
     np.testing.assert_array_equal(mixed["best_idx"], want["best_idx"])
     c64 = want["all_cost"]
     err = np.abs(c32 - c64)
-    rel = (err / (np.abs(c64) * 1e-2 + 5e-2)).max()                          # error in units of the margin
-    assert rel < 0.05, rel                                                   # >= 10x slack on the half-margin requirement
+    rel = (err / (np.abs(c64) * 3.4e-6 * T + 2e-2)).max()                    # error in units of the margin
+    assert rel < 0.1, rel                                                    # >= 5x slack on the half-margin requirement
     assert (nref >= 1).all() and nref.mean() < 3.0 and (nref <= 64).all()
     # without best_cost a single survivor is accepted unrefined; still the same indices
     d_x0, d_ref, d_ctrl = ctx.to_device(states), ctx.to_device(ref), ctx.to_device(ctrl)
