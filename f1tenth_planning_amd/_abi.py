@@ -25,7 +25,7 @@ class LatticeCfg(C.Structure):
     _fields_ = [
         ("n_stations", C.c_int32), ("n_lookahead", C.c_int32), ("n_width", C.c_int32),
         ("n_shift", C.c_int32), ("n_cull", C.c_int32), ("check_collision", C.c_int32),
-        ("cand_begin", C.c_int32), ("cand_count", C.c_int32), ("generator", C.c_int32), ("reserved0", C.c_int32),
+        ("cand_begin", C.c_int32), ("cand_count", C.c_int32), ("generator", C.c_int32), ("prune", C.c_int32),
         ("lookahead", C.c_double * MAX_LOOKAHEADS), ("width", C.c_double * MAX_WIDTHS),
         ("w_length", C.c_double), ("w_max_kappa", C.c_double), ("w_mean_kappa", C.c_double),
         ("w_similarity", C.c_double), ("track_lookahead", C.c_double), ("wheelbase", C.c_double),
@@ -76,8 +76,8 @@ def stmpc_cfg(horizon=40, n_rollouts=512, dt=0.025, wheelbase=0.33, max_steer=0.
 
 def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, weights=(1.0, 0.0, 0.0, 0.0),
                 n_shift=1, n_cull=1, check_collision=True, track_lookahead=0.8, wheelbase=0.33,
-                max_reacquire=20.0, cand_begin=0, cand_count=0, generator="clothoid"):
-    """Build a LatticeCfg.  Defaults are the reference's: look-aheads [0.4, 0.6, 0.8, 1.0] and
+                max_reacquire=20.0, cand_begin=0, cand_count=0, generator="clothoid", prune=False):
+    """Build a LatticeCfg.  prune: branch and bound over the candidates (bit-identical outputs, fewer station loops).  Defaults are the reference's: look-aheads [0.4, 0.6, 0.8, 1.0] and
     widths linspace(-1, 1, 7) (lattice_planner.py:228-229), 100 stations (:197), tracker look-ahead 0.8
     (:211), tracker wheelbase 0.33 (:55), only the length cost runnable (:268-271)."""
     import numpy as np
@@ -98,6 +98,7 @@ def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, we
     cfg.check_collision = 1 if check_collision else 0
     cfg.cand_begin = int(cand_begin)
     cfg.cand_count = int(cand_count)
+    cfg.prune = 1 if prune else 0
     gens = {"clothoid": GEN_CLOTHOID, "cubic": GEN_CUBIC, GEN_CLOTHOID: GEN_CLOTHOID, GEN_CUBIC: GEN_CUBIC}
     if generator not in gens:
         raise ValueError("generator must be 'clothoid' or 'cubic'")

@@ -512,6 +512,7 @@ struct LatticeArgs {
     double *best_traj, *all_cost, *all_traj;
     int tile_rows, tile_words;  // LDS occupancy tile: rows x (32-cell words)
     int stage_offset;           // byte offset of the staging tiles in dynamic LDS (materialised mode)
+    int bb_offset;              // byte offset of the branch-and-bound sort keys in dynamic LDS (PRUNE instantiation)
 };
 
 // goal of candidate c in the ego frame; false when it has no goal (look-ahead circle missed the raceline)
@@ -541,7 +542,8 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
 }
 
 // STAGING = materialised mode (all_traj requested): a second instantiation, so the fused kernel keeps its register budget
-template <bool STAGING, int GEN>
+// PRUNE = branch and bound over the candidates (cfg.prune, clothoid generator, winner-only outputs): a third instantiation.
+template <bool STAGING, int GEN, bool PRUNE = false>
 __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
@@ -633,7 +635,104 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
     __syncthreads();
 
     double bc; int bi;
-    if (a.mode != LATTICE_EMIT) {
+    if (PRUNE && a.mode != LATTICE_EMIT) {
+        // ---- 4'. branch and bound: fit every candidate, bound its cost from below, evaluate in order of the bound ----------
+        // Every cost term is >= 0 (the launcher checks the weights), so right after the fit
+        //     LB = w_len / L + w_maxk max(|kappa(0)|, |kappa(s_last)|) + w_meank |sum_i kappa(s_i)| / S   <=   cost
+        // (|kappa| of a clothoid is extremal at an end, both ends ARE stations, and |sum| <= sum | |; the similarity term and an
+        // occupancy hit only raise the cost).  LB is scaled by (1 - 1e-12) and its low 8 mantissa bits are cleared (they carry
+        // the candidate's slot in the sort key), which keeps it a lower bound of the COMPUTED cost.  Candidates are sorted by LB;
+        // wave (round + rot) & 3 runs the station loop for the next 64 of them while LB <= best cost so far.  A candidate is
+        // skipped only if LB > best, i.e. its cost is strictly larger than the final minimum: cost, index (first minimum) and
+        // trajectory are bit-identical to the exhaustive loop below.
+        unsigned long long* bb_key = reinterpret_cast<unsigned long long*>(lds_raw + a.bb_offset);   // [256]
+        double* bb_cost = reinterpret_cast<double*>(bb_key + 256);                                    // [1]
+        int* bb_idx = reinterpret_cast<int*>(bb_cost + 1);                                            // [1]
+        const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
+        const int rot = (int)((blockIdx.x * 2654435761u) >> 20) & 3;
+        if (tid == 0) { *bb_cost = __builtin_huge_val(); *bb_idx = 0x7fffffff; }
+        bc = __builtin_huge_val(); bi = 0x7fffffff;
+        for (int cb = c0; cb < c1; cb += blockDim.x) {
+            const int c = cb + tid;
+            double gx = 0.0, gy = 0.0, gth = 0.0;
+            const bool gok = c < c1 && candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+            Clothoid cl;
+            cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
+            if (gok) cl = g1_fit(gx, gy, gth);
+            slot[4 * tid] = cl.k0; slot[4 * tid + 1] = cl.dk; slot[4 * tid + 2] = cl.L; slot[4 * tid + 3] = cl.ok ? 1.0 : 0.0;
+            if (c == c0) { win[0] = cl.k0; win[1] = cl.dk; win[2] = cl.L; win[3] = cl.ok ? 1.0 : 0.0; }   // the answer when nothing is feasible
+            double lb = __builtin_huge_val();
+            if (cl.ok) {
+                const double ds = cl.L / (double)den;
+                const double k_last = fabs(cl.k0 + cl.dk * ((double)(S - 1) * ds));           // the station loop's own expression
+                const double maxk = fmax(fabs(cl.k0), k_last);
+                const double sumk = fabs((double)S * cl.k0 + cl.dk * ds * (0.5 * (double)S * (double)(S - 1)));
+                lb = (cfg.w_length * (1.0 / cl.L) + cfg.w_max_kappa * maxk + cfg.w_mean_kappa * (sumk / (double)S)) * (1.0 - 1e-12);
+                if (!(lb >= 0.0)) lb = 0.0;                                                  // NaN: no bound
+            }
+            unsigned long long key = ((unsigned long long)__double_as_longlong(lb) & ~0xffull) | (unsigned long long)tid;
+            // bitonic sort of the 256 keys: partners inside a wave by shuffle, across waves through LDS
+            for (int k = 2; k <= 256; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    unsigned long long other;
+                    if (j >= 64) {
+                        __syncthreads();
+                        bb_key[tid] = key;
+                        __syncthreads();
+                        other = bb_key[tid ^ j];
+                    } else {
+                        const unsigned int lo = __shfl_xor((unsigned int)key, j, 64), hi = __shfl_xor((unsigned int)(key >> 32), j, 64);
+                        other = ((unsigned long long)hi << 32) | lo;
+                    }
+                    const bool take_min = ((tid & j) == 0) == ((tid & k) == 0);
+                    const bool other_less = other < key;
+                    key = (take_min == other_less) ? other : key;
+                }
+            }
+            __syncthreads();
+            bb_key[tid] = key;
+            __syncthreads();
+            for (int r = 0; r < 4; ++r) {
+                const double lb_first = __longlong_as_double((long long)(bb_key[64 * r] & ~0xffull));
+                // workgroup-uniform; a NaN best (NaN in prev_theta: np.argmin takes the first NaN) means "no bound"
+                if (!(lb_first <= bc || bc != bc) || !(lb_first < __builtin_huge_val())) break;
+                if (wave == ((r + rot) & 3)) {
+                    const unsigned long long kj = bb_key[64 * r + lane];
+                    const int j = (int)(kj & 0xffull);
+                    const double lbj = __longlong_as_double((long long)(kj & ~0xffull));
+                    double cost = __builtin_huge_val();
+                    if ((lbj <= bc || bc != bc) && lbj < __builtin_huge_val()) {
+                        const double k0 = slot[4 * j], dk = slot[4 * j + 1], L = slot[4 * j + 2];
+                        const StationResult sr = station_loop<false, F1P_GEN_CLOTHOID>(k0, dk, L, (const F1P_LDS(EgoParams)*)egp,
+                                                                                     (const F1P_LDS(uint32_t)*)tile, nullptr, nullptr, 0);
+                        cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
+                        cost += cfg.w_length * (1.0 / sr.len);
+                        cost += cfg.w_max_kappa * sr.maxk;
+                        cost += cfg.w_mean_kappa * (sr.sumk / (double)S);
+                        cost += cfg.w_similarity * sr.sim;
+                        if (sr.hit != 0) cost = __builtin_huge_val();
+                    }
+                    double wc = cost; int wi = cb + j;
+                    wave_argmin(wc, wi);
+                    if (lane == 0 && wc != __builtin_huge_val() && argmin_better(wc, wi, bc, bi)) {
+                        *bb_cost = wc; *bb_idx = wi;
+                        const int jw = wi - cb;
+                        win[0] = slot[4 * jw]; win[1] = slot[4 * jw + 1]; win[2] = slot[4 * jw + 2]; win[3] = slot[4 * jw + 3];
+                    }
+                }
+                __syncthreads();
+                bc = *bb_cost; bi = *bb_idx;
+            }
+            __syncthreads();                                      // slot / bb_key are rewritten by the next batch
+        }
+        if (bi == 0x7fffffff) bi = c0;                            // nothing feasible: the exhaustive loop's answer (first candidate, +inf)
+        if (tid == 0) {
+            if (a.best_idx) a.best_idx[e] = bi;
+            if (a.best_cost) a.best_cost[e] = bc;
+            if (a.near_idx) a.near_idx[e] = ni;
+        }
+        if (a.mode == LATTICE_EVAL) return;
+    } else if (a.mode != LATTICE_EMIT) {
         // ---- 4. candidates: fit, sample, check, cost -------------------------------------------------
         const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
         bc = __builtin_huge_val(); bi = 0x7fffffff;
@@ -820,11 +919,18 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     a.stage_offset = (int)lds;
     if (d_all_traj) lds += 16 * 4 * 64 * F1P_STAGE_PITCH;
     const bool cubic = cfg->generator == F1P_GEN_CUBIC;
+    // branch and bound needs every cost term >= 0 and only the winner as output
+    const bool weights_ok = cfg->w_length >= 0.0 && cfg->w_max_kappa >= 0.0 && cfg->w_mean_kappa >= 0.0 && cfg->w_similarity >= 0.0 &&
+                            cfg->w_length < HUGE_VAL && cfg->w_max_kappa < HUGE_VAL && cfg->w_mean_kappa < HUGE_VAL && cfg->w_similarity < HUGE_VAL;
+    const bool prune = cfg->prune != 0 && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_ok;
+    a.bb_offset = (int)lds;
+    if (prune) lds += 8 * 256 + 16;
     if (d_all_traj) {
         if (cubic) hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CUBIC>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
         else hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CLOTHOID>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
     } else {
         if (cubic) hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CUBIC>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+        else if (prune) hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CLOTHOID, true>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
         else hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CLOTHOID>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
     }
     return check_hip(ctx, hipGetLastError(), "k_lattice launch");

@@ -199,7 +199,8 @@ class LatticePlanner():
                                 n_shift=self.n_shift, n_cull=self.n_cull,
                                 check_collision=self.check_collision and self._map is not None,
                                 track_lookahead=self.track_lookahead, wheelbase=self.tracker.wheelbase,
-                                max_reacquire=self.tracker.max_reacquire, generator=self.generator)
+                                max_reacquire=self.tracker.max_reacquire, generator=self.generator,
+                                prune=True)   # branch and bound: same outputs, fewer station loops
 
     def plan(self, pose_x, pose_y, pose_theta, velocity, waypoints=None, cost_weights=None):
         """

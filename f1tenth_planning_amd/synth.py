@@ -119,7 +119,7 @@ def make_controls(E, T, R, seed=3, sigma_a=1.5, sigma_d=0.15, max_accel=3.0, max
     return c
 
 
-def bench_lattice_cfg(n_cand=256, n_stations=50, generator="clothoid"):
+def bench_lattice_cfg(n_cand=256, n_stations=50, generator="clothoid", prune=False):
     """The BASELINE.json lattice workload: look-aheads linspace(0.6, 3.0, 16) x widths linspace(-1, 1, C/16),
     S = 50 stations, equal weights on the four cost terms, collision check on."""
     from ._abi import lattice_cfg
@@ -129,4 +129,4 @@ def bench_lattice_cfg(n_cand=256, n_stations=50, generator="clothoid"):
         raise ValueError("n_cand must be a multiple of 16")
     return lattice_cfg(lookaheads=np.linspace(0.6, 3.0, n_l), widths=np.linspace(-1.0, 1.0, n_w),
                        n_stations=n_stations, weights=(0.25, 0.25, 0.25, 0.25), n_shift=1, n_cull=1,
-                       check_collision=True, generator=generator)
+                       check_collision=True, generator=generator, prune=prune)

@@ -73,7 +73,9 @@ typedef struct f1p_lattice_cfg {
     int32_t cand_begin;      /* candidate shard [cand_begin, cand_begin + cand_count) evaluated by this     */
     int32_t cand_count;      /*   call; 0 count = all C (used when one ego's candidates span ranks)         */
     int32_t generator;       /* F1P_GEN_CLOTHOID (the reference's G1 clothoid, :196) or F1P_GEN_CUBIC             */
-    int32_t reserved0;       /* keeps the doubles 8-byte aligned; must be 0                                  */
+    int32_t prune;           /* 1: branch and bound over the candidates (clothoid generator, winner-only outputs):
+                              * candidates whose cost lower bound exceeds the best cost found so far skip the
+                              * station loop; every output is bit-identical to prune = 0                         */
     double lookahead[F1P_MAX_LOOKAHEADS]; /* metres, circle radii for intersect_point                       */
     double width[F1P_MAX_WIDTHS];         /* metres, lateral offsets along the path normal                  */
     double w_length;         /* weight of 1/L                 (get_length_cost     :268-271)                */

@@ -216,3 +216,48 @@ def test_pinned_pipelined_batch_equals_plain_batch(ctx, scene):
         b = ctx.lattice_plan(poses, cfg, prev_theta=prev, reuse_outputs=True)
         for k in a:
             np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=k)
+
+
+def _same(a, b):
+    for k in a:
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+
+
+def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
+    """cfg.prune = 1 skips the station loop of candidates whose cost lower bound exceeds the best cost so far; index, cost,
+    status, steering, speed and trajectory must not change in any bit -- with collisions, with the similarity term, with more
+    than 256 candidates, on a candidate shard, with blocked egos, host goals, NaN goals and a NaN previous trajectory."""
+    rl, img, origin = scene
+    import copy
+    for n_cand, E, seed, sig in ((256, 1024, 5, 0.3), (512, 256, 6, 0.3), (256, 512, 7, 0.9), (48, 128, 8, 0.3)):
+        poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sig, yaw_sigma=0.3)
+        poses[:4, :2] += 300.0                                        # off the map: every candidate blocked
+        full = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=50)
+        bb = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=50, prune=True)
+        a = ctx.lattice_plan(poses, full)
+        b = ctx.lattice_plan(poses, bb)
+        _same(a, b)
+        assert (a["status"][:4] == _abi.ST_ALL_BLOCKED).all() and (a["status"] == 0).mean() > 0.5
+        prev = a["best_traj"][:, :, 2] + np.random.default_rng(seed).normal(0, 0.05, (E, 50))
+        _same(ctx.lattice_plan(poses, full, prev_theta=prev), ctx.lattice_plan(poses, bb, prev_theta=prev))
+        prev[5, 7] = np.nan                                           # NaN similarity: np.argmin takes the first NaN cost
+        _same(ctx.lattice_plan(poses, full, prev_theta=prev), ctx.lattice_plan(poses, bb, prev_theta=prev))
+        # candidate shard (the multi-GPU split): same range, same answer
+        for lo, cnt in ((0, n_cand // 2), (n_cand // 2, n_cand - n_cand // 2), (7, 13)):
+            f2, b2 = copy.copy(full), copy.copy(bb)
+            f2.cand_begin = b2.cand_begin = lo; f2.cand_count = b2.cand_count = cnt
+            _same(ctx.lattice_plan(poses[:64], f2), ctx.lattice_plan(poses[:64], b2))
+    # host goals incl. NaN rows; weights that stress the bound (only max-kappa; only length; zero weights)
+    rng = np.random.default_rng(3)
+    E, C = 96, 64
+    poses = synth.make_egos(rl, E, seed=9)
+    goals = np.stack([np.column_stack([rng.uniform(0.5, 3.0, C), rng.uniform(-1.0, 1.0, C), rng.uniform(-0.6, 0.6, C)]) for _ in range(E)])
+    goals[:, 5] = np.nan; goals[3] = np.nan
+    for w in ((0.25, 0.25, 0.25, 0.25), (0.0, 1.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 1.0, 0.0)):
+        kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=37, weights=w, n_shift=1, n_cull=1, check_collision=True)
+        a = ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals)
+        b = ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals)
+        _same(a, b)
+    # a negative weight disables the bound (falls back to the exhaustive kernel): still the same answer
+    kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=37, weights=(1.5, -0.5, 0.0, 0.0), check_collision=True)
+    _same(ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals), ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals))
