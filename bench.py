@@ -171,10 +171,14 @@ def main():
         p50, p95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
         q50, q95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True))
         r50, r95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=False, reuse_outputs=True))
+        import copy
+        cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
+        b50, b95 = percentiles(lambda: ctx.lattice_plan(poses, cfg_bb, want_traj=True, reuse_outputs=True))
         lat = {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
                "includes": "H2D poses + kernel + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays",
                "pageable_host_arrays": {"p50_ms": q50, "p95_ms": q95},
-               "without_best_traj": {"p50_ms": r50, "p95_ms": r95}}
+               "without_best_traj": {"p50_ms": r50, "p95_ms": r95},
+               "branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 (the planner classes' default): bit-identical outputs"}}
 
     # parity gate that travels with every measurement: a seeded subset against the oracle (rank 0)
     steer = d_steer.download(np.float64, (E,))

@@ -41,6 +41,10 @@ struct f1p_ctx {
     float* d_dbg_cost32 = nullptr;     // [E][R] filter costs of the next launch (test hook), or null
     int32_t* d_dbg_nref = nullptr;     // [E] size of the refined set (-1 = fp64 fallback), or null
 
+    // two-kernel branch and bound of the lattice planner: bounds and clothoids handed from the fit kernel to the evaluation kernel
+    char* d_bb_scratch = nullptr;
+    size_t bb_scratch_bytes = 0;
+
     // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

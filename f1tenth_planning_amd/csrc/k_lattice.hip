@@ -267,6 +267,9 @@ __device__ F1P_FIT_INLINE Clothoid g1_fit(double x1, double y1, double th1) {
 // instructions) instead of a sincos (~45).  Rounding drift is bounded by re-anchoring E and R with exact sincos every
 // F1P_K3_ANCHOR pieces (8: drift < 1e-14 rad); the anchors depend only on the piece index, so any piece's state can be
 // rebuilt from its anchor and the winner re-emission stays bit-identical to the evaluation loop.
+#ifndef F1P_BB_SPLIT_MIN_EGOS
+#define F1P_BB_SPLIT_MIN_EGOS 256   // below this one kernel per plan wins (launch latency)
+#endif
 #ifndef F1P_K3_ANCHOR
 #define F1P_K3_ANCHOR 8
 #endif
@@ -513,6 +516,12 @@ struct LatticeArgs {
     int tile_rows, tile_words;  // LDS occupancy tile: rows x (32-cell words)
     int stage_offset;           // byte offset of the staging tiles in dynamic LDS (materialised mode)
     int bb_offset;              // byte offset of the branch-and-bound sort keys in dynamic LDS (PRUNE instantiation)
+    // two-kernel branch and bound: k_lattice<PRUNE> with fit_only hands the sorted bounds to k_lattice_eval through HBM
+    int fit_only;
+    unsigned long long* bb_keys;   // [E][256] sorted (bound | slot) keys
+    double* bb_cloth;              // [E][256][4] clothoid of every slot (k0, dk, L, ok)
+    int32_t* bb_ni;                // [E] nearest raceline segment
+    int wave_lds_bytes;            // k_lattice_eval: LDS bytes per wave
 };
 
 // goal of candidate c in the ego frame; false when it has no goal (look-ahead circle missed the raceline)
@@ -539,6 +548,72 @@ __device__ __forceinline__ bool candidate_goal(const LatticeArgs& a, const f1p_l
     gy = -st * dx + ct * dy;
     gth = remainder_2pi(psi - ep->theta);
     return true;
+}
+
+// Steps 6-7 for ONE wave: re-emit the winner (every interval is independent -> one lane per interval, bit-identical to the
+// evaluation loop) into best_traj and the wave's LDS arrays tr_x / tr_y, then track it with pure pursuit in the ego frame.
+template <int GEN>
+__device__ __forceinline__ void emit_and_track(const LatticeArgs& a, const f1p_lattice_cfg& cfg, int e, int lane, int ni, int den,
+                                               const Clothoid& cl, double bc, double* tr_x, double* tr_y, double* inc_x, double* inc_y) {
+    const int S = cfg.n_stations;
+    double* bt = a.best_traj ? a.best_traj + (size_t)e * S * 4 : nullptr;
+    if (GEN == F1P_GEN_CUBIC) {
+        const Cubic cq = cubic_setup(cl.k0, cl.dk, cl.L);
+        for (int i = lane; i < S; i += 64) {             // closed form per station: nothing to accumulate
+            double x = 0.0, y = 0.0, th = 0.0, ak = 0.0;
+            if (cl.ok) cubic_row(cq, (double)i / (double)den, x, y, th, ak);
+            tr_x[i] = x; tr_y[i] = y;
+            if (bt) {
+                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
+                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+            }
+        }
+    } else {
+        const double ds = cl.ok ? cl.L / (double)den : 0.0;
+        IntervalCoef ic;
+        if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
+        for (int i = lane; i < S - 1; i += 64) {
+            double dx = 0.0, dy = 0.0;
+            if (cl.ok) {
+                PieceState st = piece_state_at(cl.k0, cl.dk, ds, i, ic);
+                interval_increment(cl.k0, cl.dk, (double)i * ds, i * ic.nsub, ic, st, dx, dy);
+            }
+            inc_x[i] = dx; inc_y[i] = dy;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < S; i += 64) {
+            double x = 0.0, y = 0.0;
+            for (int j = 0; j < i; ++j) { x += inc_x[j]; y += inc_y[j]; }   // same order as the evaluation loop
+            tr_x[i] = x; tr_y[i] = y;
+            if (bt) {
+                const double s = (double)i * ds;
+                const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
+                const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
+                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
+                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 7. track the winner: PurePursuitPlanner.plan(0, 0, 0, L, best_traj) in the ego frame ----------
+    Track o;
+    o.steer = 0.0; o.speed = 0.0; o.la_idx = F1P_LA_NONE; o.status = F1P_ST_ALL_BLOCKED;
+    if (cl.ok && bc < __builtin_huge_val()) {
+        double td; int ti;
+        nearest_scan(0.0, 0.0, tr_x, tr_y, S, lane, 64, td, ti);
+        wave_argmin(td, ti);
+        const SegProj ts = seg_project(0.0, 0.0, tr_x[ti], tr_y[ti], tr_x[ti + 1], tr_y[ti + 1]);
+        o = wave_pursuit(0.0, 0.0, 0.0, cfg.track_lookahead, cfg.wheelbase, cfg.max_reacquire, tr_x, tr_y, nullptr,
+                         a.wv[ni], S, ti, ts.t, ts.d);
+    }
+    if (lane == 0) {
+        a.steer[e] = o.steer;
+        a.speed[e] = o.speed;
+        if (a.status) a.status[e] = o.status;
+    }
 }
 
 // STAGING = materialised mode (all_traj requested): a second instantiation, so the fused kernel keeps its register budget
@@ -592,7 +667,7 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
     }
 
     // ---- 3. occupancy tile around the ego -> LDS ------------------------------------------------------
-    const bool collide_on = cfg.check_collision && a.has_grid;
+    const bool collide_on = cfg.check_collision && a.has_grid && !(PRUNE && a.fit_only);
     int tile_gx0 = 0, tile_gy0 = 0;   // cell coordinates of tile word 0 / row 0 (gx0 is a multiple of 32)
     if (collide_on) {
         const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
@@ -688,6 +763,13 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
                     const bool other_less = other < key;
                     key = (take_min == other_less) ? other : key;
                 }
+            }
+            if (a.fit_only) {                                     // single batch (launcher): the station rounds run in k_lattice_eval
+                a.bb_keys[(size_t)e * 256 + tid] = key;
+                reinterpret_cast<double2*>(a.bb_cloth)[((size_t)e * 256 + tid) * 2] = make_double2(cl.k0, cl.dk);
+                reinterpret_cast<double2*>(a.bb_cloth)[((size_t)e * 256 + tid) * 2 + 1] = make_double2(cl.L, cl.ok ? 1.0 : 0.0);
+                if (tid == 0) a.bb_ni[e] = ni;
+                return;
             }
             __syncthreads();
             bb_key[tid] = key;
@@ -810,64 +892,104 @@ __global__ __launch_bounds__(256, STAGING ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES) v
             else cl = g1_fit(gx, gy, gth);
         }
     }
-    double* bt = a.best_traj ? a.best_traj + (size_t)e * S * 4 : nullptr;
-    if (GEN == F1P_GEN_CUBIC) {
-        const Cubic cq = cubic_setup(cl.k0, cl.dk, cl.L);
-        for (int i = lane; i < S; i += 64) {             // closed form per station: nothing to accumulate
-            double x = 0.0, y = 0.0, th = 0.0, ak = 0.0;
-            if (cl.ok) cubic_row(cq, (double)i / (double)den, x, y, th, ak);
-            tr_x[i] = x; tr_y[i] = y;
-            if (bt) {
-                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
-                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
-            }
-        }
-    } else {
-        const double ds = cl.ok ? cl.L / (double)den : 0.0;
-        IntervalCoef ic;
-        if (cl.ok) ic = interval_setup(cl.k0, cl.dk, cl.L, ds);
-        for (int i = lane; i < S - 1; i += 64) {
-            double dx = 0.0, dy = 0.0;
-            if (cl.ok) {
-                PieceState st = piece_state_at(cl.k0, cl.dk, ds, i, ic);
-                interval_increment(cl.k0, cl.dk, (double)i * ds, i * ic.nsub, ic, st, dx, dy);
-            }
-            inc_x[i] = dx; inc_y[i] = dy;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (single wave, no barrier)
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < S; i += 64) {
-            double x = 0.0, y = 0.0;
-            for (int j = 0; j < i; ++j) { x += inc_x[j]; y += inc_y[j]; }   // same order as the evaluation loop
-            tr_x[i] = x; tr_y[i] = y;
-            if (bt) {
-                const double s = (double)i * ds;
-                const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
-                const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
-                reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
-                reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
-            }
+    emit_and_track<GEN>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
+}
+
+// Second kernel of the two-kernel branch and bound: ONE WAVE PER EGO (4 egos per workgroup, no workgroup barriers) runs the
+// station rounds over the bounds sorted by k_lattice<PRUNE>(fit_only), selects, re-emits and tracks.  In the single-kernel
+// variant three of a workgroup's four waves wait while one evaluates; here every resident wave works.
+// Per-wave LDS: EgoParams | tr_x, tr_y, inc_x, inc_y [S] | occupancy tile.
+__global__ __launch_bounds__(256, 3) void k_lattice_eval(LatticeArgs a, f1p_lattice_cfg cfg) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= a.E) return;                                    // wave-uniform
+    const int S = cfg.n_stations;
+    unsigned char* base = lds_raw + (size_t)wave * a.wave_lds_bytes;
+    EgoParams* egp = reinterpret_cast<EgoParams*>(base);
+    double* tr_x = reinterpret_cast<double*>(egp + 1);
+    double* tr_y = tr_x + S;
+    double* inc_x = tr_y + S;
+    double* inc_y = inc_x + S;
+    uint32_t* tile = reinterpret_cast<uint32_t*>(inc_y + S);
+    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
+    const int ni = a.bb_ni[e];
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    int tile_gx0 = 0, tile_gy0 = 0;
+    if (collide_on) {                                        // the same tile as k_lattice step 3, staged by one wave
+        const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
+        const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
+        const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+        const int half = a.tile_rows / 2;
+        tile_gx0 = ((egx - half) >> 5) << 5;
+        tile_gy0 = egy - half;
+        const int nwords = a.tile_rows * a.tile_words;
+        for (int q = lane; q < nwords; q += 64) {
+            const int r = q / a.tile_words, j = q - r * a.tile_words;
+            const int gy = tile_gy0 + r, gw = (tile_gx0 >> 5) + j;
+            uint32_t v = 0xffffffffu;
+            if (gy >= 0 && gy < a.grid.h && gw >= 0 && gw < a.grid.wwords) v = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
+            tile[q] = v;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    double sn_t, cs_t;
+    sincos(theta, &sn_t, &cs_t);
+    const double ct = cs_t, st = sn_t;
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    if (lane == 0) {
+        EgoParams q;
+        q.txx = ct * a.grid.inv_res; q.txy = -st * a.grid.inv_res; q.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
+        q.tyx = st * a.grid.inv_res; q.tyy = ct * a.grid.inv_res; q.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+        q.tile_w = (double)(a.tile_words * 32); q.tile_h = (double)a.tile_rows;
+        q.tile_gx0 = (double)tile_gx0; q.tile_gy0 = (double)tile_gy0; q.grid_w = (double)a.grid.w; q.grid_h = (double)a.grid.h;
+        q.px = px; q.py = py; q.theta = theta; q.ct = ct; q.st = st;
+        q.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr; q.bits = a.grid.bits;
+        q.tile_words = a.tile_words; q.wwords = a.grid.wwords; q.S = S; q.den = den; q.sim_m = S - cfg.n_shift - cfg.n_cull;
+        q.n_shift = cfg.n_shift; q.collide = collide_on ? 1 : 0; q.pad = 0;
+        *egp = q;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
 
-    // ---- 7. track the winner: PurePursuitPlanner.plan(0, 0, 0, L, best_traj) in the ego frame ----------
-    Track o;
-    o.steer = 0.0; o.speed = 0.0; o.la_idx = F1P_LA_NONE; o.status = F1P_ST_ALL_BLOCKED;
-    if (cl.ok && bc < __builtin_huge_val()) {
-        double td; int ti;
-        nearest_scan(0.0, 0.0, tr_x, tr_y, S, lane, 64, td, ti);
-        wave_argmin(td, ti);
-        const SegProj ts = seg_project(0.0, 0.0, tr_x[ti], tr_y[ti], tr_x[ti + 1], tr_y[ti + 1]);
-        o = wave_pursuit(0.0, 0.0, 0.0, cfg.track_lookahead, cfg.wheelbase, cfg.max_reacquire, tr_x, tr_y, nullptr,
-                         a.wv[ni], S, ti, ts.t, ts.d);
+    const unsigned long long* keys = a.bb_keys + (size_t)e * 256;
+    const double* cloth = a.bb_cloth + (size_t)e * 256 * 4;
+    const int c0 = cfg.cand_begin;
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long kj = keys[64 * r + lane];
+        const unsigned long long k_first = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(kj >> 32)) << 32) |
+                                           (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)kj);
+        const double lb_first = __longlong_as_double((long long)(k_first & ~0xffull));
+        if (!(lb_first <= bc || bc != bc) || !(lb_first < __builtin_huge_val())) break;      // wave-uniform
+        const int j = (int)(kj & 0xffull);
+        const double lbj = __longlong_as_double((long long)(kj & ~0xffull));
+        double cost = __builtin_huge_val();
+        if ((lbj <= bc || bc != bc) && lbj < __builtin_huge_val()) {
+            const double k0 = cloth[4 * j], dk = cloth[4 * j + 1], L = cloth[4 * j + 2];
+            const StationResult sr = station_loop<false, F1P_GEN_CLOTHOID>(k0, dk, L, (const F1P_LDS(EgoParams)*)egp,
+                                                                         (const F1P_LDS(uint32_t)*)tile, nullptr, nullptr, 0);
+            cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
+            cost += cfg.w_length * (1.0 / sr.len);
+            cost += cfg.w_max_kappa * sr.maxk;
+            cost += cfg.w_mean_kappa * (sr.sumk / (double)S);
+            cost += cfg.w_similarity * sr.sim;
+            if (sr.hit != 0) cost = __builtin_huge_val();
+        }
+        double wc = cost; int wi = c0 + j;
+        wave_argmin(wc, wi);
+        if (wc != __builtin_huge_val() && argmin_better(wc, wi, bc, bi)) { bc = wc; bi = wi; }
     }
+    if (bi == 0x7fffffff) bi = c0;                            // nothing feasible: the exhaustive loop's answer (first candidate, +inf)
     if (lane == 0) {
-        a.steer[e] = o.steer;
-        a.speed[e] = o.speed;
-        if (a.status) a.status[e] = o.status;
+        if (a.best_idx) a.best_idx[e] = bi;
+        if (a.best_cost) a.best_cost[e] = bc;
+        if (a.near_idx) a.near_idx[e] = ni;
     }
+    if (a.mode == LATTICE_EVAL) return;
+    const int jw = bi - c0;
+    Clothoid cl;
+    cl.k0 = cloth[4 * jw]; cl.dk = cloth[4 * jw + 1]; cl.L = cloth[4 * jw + 2]; cl.ok = cloth[4 * jw + 3] != 0.0;
+    emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
 }
 
 __global__ __launch_bounds__(256) void k_clothoid_g1(const double* __restrict__ goals, int n, double* __restrict__ k0,
@@ -925,6 +1047,33 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     const bool prune = cfg->prune != 0 && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_ok;
     a.bb_offset = (int)lds;
     if (prune) lds += 8 * 256 + 16;
+    a.fit_only = 0; a.bb_keys = nullptr; a.bb_cloth = nullptr; a.bb_ni = nullptr; a.wave_lds_bytes = 0;
+    const int n_cand = cfg->cand_count > 0 ? cfg->cand_count : cfg->n_lookahead * cfg->n_width;
+    if (prune && n_cand <= 256 && E >= F1P_BB_SPLIT_MIN_EGOS) {
+        // two kernels: fit + bound + sort with every wave busy, then one wave per ego for the station rounds
+        const size_t need = (size_t)E * (256 * 8 + 256 * 32 + 4) + 64;
+        if (need > ctx->bb_scratch_bytes) {
+            F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_bb_scratch) (void)hipFree(ctx->d_bb_scratch);
+            ctx->d_bb_scratch = nullptr; ctx->bb_scratch_bytes = 0;
+            F1P_HIP(ctx, hipMalloc((void**)&ctx->d_bb_scratch, need));
+            ctx->bb_scratch_bytes = need;
+        }
+        a.bb_cloth = reinterpret_cast<double*>(ctx->d_bb_scratch);
+        a.bb_keys = reinterpret_cast<unsigned long long*>(ctx->d_bb_scratch + (size_t)E * 256 * 32);
+        a.bb_ni = reinterpret_cast<int32_t*>(ctx->d_bb_scratch + (size_t)E * 256 * 40);
+        a.fit_only = 1;
+        const size_t lds_fit = lds - sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;   // no occupancy tile in the fit kernel (offsets unchanged)
+        (void)lds_fit;
+        hipLaunchKernelGGL((k_lattice<false, F1P_GEN_CLOTHOID, true>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
+        int rc = check_hip(ctx, hipGetLastError(), "k_lattice (fit) launch");
+        if (rc) return rc;
+        size_t wl = sizeof(EgoParams) + sizeof(double) * 4 * (size_t)S + sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
+        wl = (wl + 15) & ~(size_t)15;
+        a.wave_lds_bytes = (int)wl;
+        hipLaunchKernelGGL(k_lattice_eval, dim3((E + 3) / 4), dim3(256), 4 * wl, ctx->stream, a, *cfg);
+        return check_hip(ctx, hipGetLastError(), "k_lattice_eval launch");
+    }
     if (d_all_traj) {
         if (cubic) hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CUBIC>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
         else hipLaunchKernelGGL((k_lattice<true, F1P_GEN_CLOTHOID>), dim3(E), dim3(256), lds, ctx->stream, a, *cfg);
