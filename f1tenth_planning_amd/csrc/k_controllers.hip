@@ -3,8 +3,10 @@
 // Replaces StanleyPlanner.calc_theta_and_ef / controller / plan (control/stanley/stanley.py:57-139) and
 // LQRPlanner.calc_control_points / controller / plan (control/lqr/lqr.py:60-210) with solve_lqr / update_matrix
 // (utils/utils.py:167-239).  Both are nearest_point on the front-axle position plus an O(1) epilogue per ego, so the
-// mapping is K1's: one 256-thread workgroup per ego scans the raceline, then lane 0 runs the epilogue (for LQR a
-// 4x4 discrete Riccati iteration of at most `max_iter` steps, all in registers).  fp64 throughout.
+// mapping is K1's: one wave64 per ego runs the chunk-pruned nearest scan.  Stanley's epilogue is a handful of operations on
+// lane 0; LQR's is a 4x4 discrete Riccati iteration of up to `max_iter` steps (~15k fp64 instructions), so there a workgroup
+// first resolves the front-axle errors of its 256 egos wave by wave into LDS and then iterates with ONE THREAD PER EGO, all
+// lanes busy, everything in registers.  fp64 throughout.
 #include "f1p_internal.h"
 
 namespace f1p {
@@ -14,13 +16,13 @@ struct FrontErr { double theta_e, ef; int idx; };
 // front-axle point -> nearest raceline segment -> cross-track and heading error (stanley.py:57-88 == lqr.py:60-103)
 __device__ __forceinline__ FrontErr front_axle_errors(double x, double y, double theta, double wheelbase,
                                                       const double* __restrict__ wx, const double* __restrict__ wy,
-                                                      const double* __restrict__ wpsi, const double* __restrict__ wbox, int n,
-                                                      double* sd, int* si) {
+                                                      const double* __restrict__ wpsi, const double* __restrict__ wbox, int n) {
+    // executed by ONE wave: all 64 lanes call it with the same arguments and get the same result
     const double fx = x + wheelbase * cos(theta);            // stanley.py:66
     const double fy = y + wheelbase * sin(theta);            // :67
     double bd; int bi;
-    nearest_scan_boxed(fx, fy, wx, wy, wbox, n, threadIdx.x, blockDim.x, bd, bi);   // :69
-    block_argmin(bd, bi, sd, si);
+    nearest_scan_boxed(fx, fy, wx, wy, wbox, n, threadIdx.x & 63, 64, bd, bi);   // :69
+    wave_argmin(bd, bi);
     const SegProj s = seg_project(fx, fy, wx[bi], wy[bi], wx[bi + 1], wy[bi + 1]);
     const double vx = fx - s.qx, vy = fy - s.qy;             // :70
     FrontErr r;
@@ -38,12 +40,10 @@ __global__ __launch_bounds__(256) void k_stanley(const double* __restrict__ stat
                                                  const double* __restrict__ wv, const double* __restrict__ wpsi,
                                                  const double* __restrict__ wbox, int n, double* __restrict__ steer, double* __restrict__ speed,
                                                  int32_t* __restrict__ near_idx) {
-    __shared__ double sd[4];
-    __shared__ int si[4];
-    const int e = blockIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per ego
     if (e >= E) return;
-    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, wbox, n, sd, si);
-    if (threadIdx.x == 0) {
+    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], wheelbase, wx, wy, wpsi, wbox, n);
+    if ((threadIdx.x & 63) == 0) {
         const double cte_front = atan2(k_path * fe.ef, states[4 * e + 3]);   // stanley.py:110
         steer[e] = cte_front + fe.theta_e;                                   // :111
         speed[e] = wv[fe.idx];
@@ -149,12 +149,20 @@ __global__ __launch_bounds__(256) void k_lqr(const double* __restrict__ states, 
                                              const double* __restrict__ wkappa, const double* __restrict__ wbox, int n,
                                              double* __restrict__ steer,
                                              double* __restrict__ speed, int32_t* __restrict__ near_idx) {
-    __shared__ double sd[4];
-    __shared__ int si[4];
-    const int e = blockIdx.x;
-    if (e >= E) return;
-    const FrontErr fe = front_axle_errors(states[4 * e], states[4 * e + 1], states[4 * e + 2], p.wheelbase, wx, wy, wpsi, wbox, n, sd, si);
-    if (threadIdx.x == 0) {
+    __shared__ double s_ef[256], s_te[256];
+    __shared__ int s_idx[256];
+    const int e_base = blockIdx.x * 256, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = 0; q < 64; ++q) {                           // phase 1: each wave resolves 64 egos, one after the other
+        const int k = wave * 64 + q, eq = e_base + k;
+        if (eq >= E) break;                                  // wave-uniform
+        const FrontErr f = front_axle_errors(states[4 * eq], states[4 * eq + 1], states[4 * eq + 2], p.wheelbase, wx, wy, wpsi, wbox, n);
+        if (lane == 0) { s_ef[k] = f.ef; s_te[k] = f.theta_e; s_idx[k] = f.idx; }
+    }
+    __syncthreads();
+    const int e = e_base + threadIdx.x;                      // phase 2: one thread per ego
+    if (e < E) {
+        FrontErr fe;
+        fe.ef = s_ef[threadIdx.x]; fe.theta_e = s_te[threadIdx.x]; fe.idx = s_idx[threadIdx.x];
         const double v = states[4 * e + 3];
         const double e_old = err[2 * e], th_old = err[2 * e + 1];                               // lqr.py:136-137
         const double A[16] = {1.0, p.ts, 0, 0, 0, 0, v, 0, 0, 0, 1.0, p.ts, 0, 0, 0, 0};      // update_matrix utils.py:227-233
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_lqr(const double* __restrict__ states, 
 int launch_stanley(f1p_ctx* ctx, const double* d_states, int E, double wheelbase, double k_path, double* d_steer,
                    double* d_speed, int32_t* d_near) {
     if (E <= 0) return F1P_OK;
-    hipLaunchKernelGGL(k_stanley, dim3(E), dim3(256), 0, ctx->stream, d_states, E, wheelbase, k_path, ctx->d_wx, ctx->d_wy,
+    hipLaunchKernelGGL(k_stanley, dim3((E + 3) / 4), dim3(256), 0, ctx->stream, d_states, E, wheelbase, k_path, ctx->d_wx, ctx->d_wy,
                        ctx->d_wv, ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, d_steer, d_speed, d_near);
     return check_hip(ctx, hipGetLastError(), "k_stanley launch");
 }
@@ -184,7 +192,7 @@ int launch_lqr(f1p_ctx* ctx, const double* d_states, double* d_err, int E, doubl
     LqrParams p;
     p.wheelbase = wheelbase; p.ts = ts; p.r = r; p.eps = eps; p.max_iter = max_iter;
     for (int i = 0; i < 4; ++i) p.q[i] = q[i];
-    hipLaunchKernelGGL(k_lqr, dim3(E), dim3(256), 0, ctx->stream, d_states, d_err, E, p, ctx->d_wx, ctx->d_wy, ctx->d_wv,
+    hipLaunchKernelGGL(k_lqr, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_states, d_err, E, p, ctx->d_wx, ctx->d_wy, ctx->d_wv,
                        ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->n_wp, d_steer, d_speed, d_near);
     return check_hip(ctx, hipGetLastError(), "k_lqr launch");
 }
