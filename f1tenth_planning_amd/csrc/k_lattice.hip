@@ -270,6 +270,9 @@ __device__ F1P_FIT_INLINE Clothoid g1_fit(double x1, double y1, double th1) {
 #ifndef F1P_BB_SPLIT_MIN_EGOS
 #define F1P_BB_SPLIT_MIN_EGOS 256   // below this one kernel per plan wins (launch latency)
 #endif
+#ifndef F1P_K3_FMAX
+#define F1P_K3_FMAX 1
+#endif
 #ifndef F1P_K3_ANCHOR
 #define F1P_K3_ANCHOR 8
 #endif
@@ -438,7 +441,7 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
         double s = 0.0, th, ak;
         if (GEN == F1P_GEN_CLOTHOID) {
             s = (double)i * ds;
-            th = s * (k0 + 0.5 * s * dk);
+            th = (STAGING || prev) ? s * (k0 + 0.5 * s * dk) : 0.0;   // only the similarity term and the materialised rows read it
             ak = fabs(k0 + dk * s);
         } else {
             if (cq.ok) cubic_row(cq, (double)i / inv_den, x, y, th, ak);
@@ -446,7 +449,7 @@ __device__ F1P_STATION_INLINE StationResult station_loop(double k0, double dk, d
             if (i > 0) { const double ddx = x - xp, ddy = y - yp; len += __builtin_sqrt(ddx * ddx + ddy * ddy); }
             xp = x; yp = y;
         }
-        if (ak > maxk) maxk = ak;
+        maxk = F1P_K3_FMAX ? __builtin_fmax(maxk, ak) : (ak > maxk ? ak : maxk);   // ak is never NaN for a fitted candidate
         sumk += ak;
         if (prev && i < sim_m) { const double d = th - prev[i + n_shift]; sim += d * d; }
         if (collide && !(F1P_K3_ABLATE & 2)) {
