@@ -57,6 +57,48 @@ __global__ __launch_bounds__(256) void kC(const float4* __restrict__ c, size_t n
     if (s == 12345.678f) out[0] = s;
 }
 
+// D: linear float4 fill (write bandwidth reference).  E: the materialised-lattice store pattern: a wave writes, for 64 candidates,
+// 128-byte chunks (8 lanes x 16 B) at a stride of S*32 bytes between candidates, 4 stations at a time.
+__global__ __launch_bounds__(256) void kD(float4* __restrict__ c, size_t n4) {
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) c[i] = v;
+}
+__global__ __launch_bounds__(256) void kE(float4* __restrict__ c, int C, int S) {
+    // block = one ego (C candidates); wave w covers candidates 64 w .. 64 w + 63; rows of 32 B = 2 float4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* ego = c + (size_t)blockIdx.x * C * S * 2;
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (int cb = wave * 64; cb < C; cb += 256)
+        for (int i0 = 0; i0 < S; i0 += 4) {
+            const int n_units = 2 * (S - i0 < 4 ? S - i0 : 4);
+            const int unit = lane % 8, sub = lane / 8;
+            for (int g = 0; g < 8; ++g) {
+                const int cand = cb + g * 8 + sub;
+                if (cand < C && unit < n_units) ego[(size_t)cand * S * 2 + (size_t)i0 * 2 + unit] = v;
+            }
+        }
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void kDnt(v4f* __restrict__ c, size_t n4) {
+    const v4f v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, &c[i]);
+}
+__global__ __launch_bounds__(256) void kEnt(v4f* __restrict__ c, int C, int S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v4f* ego = c + (size_t)blockIdx.x * C * S * 2;
+    const v4f v = {1.f, 2.f, 3.f, 4.f};
+    for (int cb = wave * 64; cb < C; cb += 256)
+        for (int i0 = 0; i0 < S; i0 += 4) {
+            const int n_units = 2 * (S - i0 < 4 ? S - i0 : 4);
+            const int unit = lane % 8, sub = lane / 8;
+            for (int g = 0; g < 8; ++g) {
+                const int cand = cb + g * 8 + sub;
+                if (cand < C && unit < n_units) __builtin_nontemporal_store(v, &ego[(size_t)cand * S * 2 + (size_t)i0 * 2 + unit]);
+            }
+        }
+}
+
 int main(int argc, char** argv) {
     const int E = argc > 1 ? atoi(argv[1]) : 8192, T = 30, R = 512;
     const size_t n = (size_t)E * T * 2 * R;
@@ -78,6 +120,27 @@ int main(int argc, char** argv) {
         }
         const char* names[] = {"A dword, 256 thr/ego", "B dwordx4, 128 thr/ego", "C linear float4, 2048 wg", "C linear float4, 8192 wg"};
         printf("%-28s %8.4f ms  %7.0f GB/s\n", names[which], best, n * 4 / (best * 1e-3) / 1e9);
+    }
+    {   // write patterns on a 4096 x 256 x 50 x 32 B = 1.68 GB tensor
+        const int Eg = 4096, C = 256, S = 50;
+        const size_t n4 = (size_t)Eg * C * S * 2;
+        float4* w;
+        CHK(hipMalloc(&w, n4 * 16));
+        for (int which = 0; which < 4; ++which) {
+            float best = 1e9f;
+            for (int it = 0; it < 6; ++it) {
+                CHK(hipEventRecord(e0));
+                if (which == 0) hipLaunchKernelGGL(kD, dim3(256 * 16), dim3(256), 0, 0, w, n4);
+                if (which == 1) hipLaunchKernelGGL(kE, dim3(Eg), dim3(256), 0, 0, w, C, S);
+                if (which == 2) hipLaunchKernelGGL(kDnt, dim3(256 * 16), dim3(256), 0, 0, (v4f*)w, n4);
+                if (which == 3) hipLaunchKernelGGL(kEnt, dim3(Eg), dim3(256), 0, 0, (v4f*)w, C, S);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (it > 0 && ms < best) best = ms;
+            }
+            const char* names[] = {"D linear float4 fill", "E 128-B chunks, stride S*32 B", "D nontemporal", "E nontemporal"};
+            printf("%-28s %8.4f ms  %7.0f GB/s\n", names[which], best, n4 * 16 / (best * 1e-3) / 1e9);
+        }
     }
     return 0;
 }
