@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=200, help="host-boundary plan() calls for p50/p95 (0 = skip)")
-    ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc", "pursuit"], default="lattice",
+    ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc", "stmpc", "pursuit"], default="lattice",
                     help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
     ap.add_argument("--generator", choices=["clothoid", "cubic"], default="clothoid",
                     help="candidate generator: clothoid = the reference's (headline); cubic = cubic Hermite spline (secondary line)")
@@ -79,6 +79,8 @@ def main():
         return main_kmpc(args)
     if args.workload == "pursuit":
         return main_pursuit(args)
+    if args.workload == "stmpc":
+        return main_stmpc(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,6 +289,61 @@ def main_pursuit(args):
                                "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_pure_pursuit_batch"}
         out["parity"] = {"egos_checked": int(n_cpu), "near_idx_mismatches": int((near != want["near_idx"]).sum()),
                          "max_abs_steer_diff": float(np.abs(steer - want["steer"]).max())}
+    print(json.dumps(out))
+    ctx.close()
+
+
+def main_stmpc(args):
+    """Secondary line: random shooting on the dynamic single-track model: E egos x 512 rollouts x 40 steps
+    of 0.025 s, fp64, controls (steering speed, acceleration) streamed from HBM as f32 [E][T][2][R]."""
+    E = args.egos if args.egos != 4096 else 1024
+    T, R = (args.horizon if args.horizon != 30 else 40), args.rollouts
+    cfg = _abi.stmpc_cfg(horizon=T, n_rollouts=R)
+    cl = synth.make_centerline(seed=2)
+    rng = np.random.default_rng(12)
+    k = rng.integers(0, len(cl) - 1, E)
+    v = rng.uniform(2.5, 5.5, E)
+    x0 = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.normal(0, 0.05, E), v,
+                          cl[k, 3] + rng.normal(0, 0.1, E), rng.normal(0, 0.2, E), rng.normal(0, 0.02, E)])
+    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) % max(1, _abi.load_library().f1p_device_count()))
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    ref = ctx.stmpc_ref(x0[:, [0, 1, 3, 4]], T)
+    ctrl = np.empty((E, T, 2, R), dtype=np.float32)
+    ctrl[:, :, 0, :] = np.clip(rng.normal(0, 1.5, (E, T, R)), -3.2, 3.2)
+    ctrl[:, :, 1, :] = np.clip(rng.normal(0, 1.5, (E, T, R)), -3.0, 3.0)
+    d_x0, d_ref, d_ctrl = ctx.to_device(x0), ctx.to_device(ref), ctx.to_device(ctrl)
+    d_steer, d_speed, d_bi, d_bc = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E)
+
+    def step():
+        ctx.stmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc)
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_end() / args.steps
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    abytes = E * R * T * 8 + E * (T + 1) * 56 + E * 56 + E * 28
+    out = {"metric": "rollout-steps/sec (dynamic single-track random shooting)", "value": float(E) * R * T * args.steps / elapsed,
+           "unit": "rollout-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 on f32 controls", "data": "synthetic",
+           "config": {"workload": f"stmpc shooting: {E} egos x {R} rollouts x {T} steps (SURVEY.md 8f rank 2)"},
+           "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_stmpc_shoot", "kernel_ms": kernel_ms}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        nthr = oracle.max_threads()
+        n_cpu = min(E, max(nthr, 256))
+        t1 = time.perf_counter()
+        want = oracle.stmpc_shoot_batch(x0[:n_cpu], ref[:n_cpu], ctrl[:n_cpu], cfg, nthreads=nthr)
+        cpu_s = time.perf_counter() - t1
+        bi = d_bi.download(np.int32, (E,))[:n_cpu]
+        out["cpu_baseline"] = {"value": float(n_cpu) * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
+                               "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_stmpc_shoot_batch"}
+        out["parity"] = {"egos_checked": int(n_cpu), "best_idx_mismatches": int((bi != want["best_idx"]).sum())}
     print(json.dumps(out))
     ctx.close()
 

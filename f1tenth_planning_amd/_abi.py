@@ -77,7 +77,8 @@ def stmpc_cfg(horizon=40, n_rollouts=512, dt=0.025, wheelbase=0.33, max_steer=0.
 def lattice_cfg(lookaheads=(0.4, 0.6, 0.8, 1.0), widths=None, n_stations=100, weights=(1.0, 0.0, 0.0, 0.0),
                 n_shift=1, n_cull=1, check_collision=True, track_lookahead=0.8, wheelbase=0.33,
                 max_reacquire=20.0, cand_begin=0, cand_count=0, generator="clothoid", prune=False):
-    """Build a LatticeCfg.  prune: branch and bound over the candidates (bit-identical outputs, fewer station loops).  Defaults are the reference's: look-aheads [0.4, 0.6, 0.8, 1.0] and
+    """Build a LatticeCfg.  prune: branch and bound over the candidates (bit-identical outputs, fewer station
+    loops).  Defaults are the reference's: look-aheads [0.4, 0.6, 0.8, 1.0] and
     widths linspace(-1, 1, 7) (lattice_planner.py:228-229), 100 stations (:197), tracker look-ahead 0.8
     (:211), tracker wheelbase 0.33 (:55), only the length cost runnable (:268-271)."""
     import numpy as np

@@ -26,7 +26,11 @@ __device__ __forceinline__ DynConst dyn_const(const f1p_stmpc_cfg& c) {
     return k;
 }
 
-// update_state :317-404, operation order kept
+// update_state :317-404, operation order kept.
+// FAST: the range-reduced sincos core for cos/sin(yaw + beta) and tan(delta) = sin / cos (valid while the arguments stay below
+// 1e5 in magnitude, which the shooting kernel checks once per ego; delta is clamped to +-max_steer); otherwise the device
+// library's full-range functions.  Same split as kmpc_step.
+template <bool FAST>
 __device__ __forceinline__ void dyn_step(DynState& s, double a, double delta_v, const f1p_stmpc_cfg& c, const DynConst& k) {
     if (delta_v >= c.max_steer_v) delta_v = c.max_steer_v;             // :330-333
     else if (delta_v <= -c.max_steer_v) delta_v = -c.max_steer_v;
@@ -40,13 +44,21 @@ __device__ __forceinline__ void dyn_step(DynState& s, double a, double delta_v, 
     const double A4 = k.M * T;
     const double A5 = k.N * V + k.M * T;
     const double A6 = k.N * V * k.l_r - k.M * T * k.l_f;
-    double sn, cs;
-    sincos(s.yaw + s.beta, &sn, &cs);
+    double sn, cs, tn;
+    if (FAST) {
+        double sd, cd;
+        sincos_fast(s.yaw + s.beta, &sn, &cs);      // guarded: beta can run away when a rollout brakes to v ~ 0
+        sincos_core(s.delta, &sd, &cd);
+        tn = sd / cd;
+    } else {
+        sincos(s.yaw + s.beta, &sn, &cs);
+        tn = tan(s.delta);
+    }
     const double x_new = s.x + s.v * cs * c.dt;                        // :358
     const double y_new = s.y + s.v * sn * c.dt;                        // :359
     double delta_new = s.delta + delta_v * c.dt;                       // :360
     double v_new = s.v + a * c.dt;                                     // :361
-    const double yaw_new = s.yaw + s.v / c.wheelbase * tan(s.delta) * c.dt;   // :362-365
+    const double yaw_new = s.yaw + s.v / c.wheelbase * tn * c.dt;             // :362-365
     const double yr_new = s.yr + (A1 * s.delta + A2 * s.beta - A3 * (s.yr / s.v)) * c.dt;                             // :367-371
     const double beta_new = s.beta + (A4 * (s.delta / s.v) - A5 * (s.beta / s.v) + A6 * (s.yr / (s.v * s.v)) - s.yr) * c.dt;   // :372-381
     if (v_new > c.max_speed) v_new = c.max_speed;                      // :393-396
@@ -71,9 +83,40 @@ __global__ __launch_bounds__(256) void k_stmpc_predict(const double* __restrict_
     s.yr = x0[7 * e + 5]; s.beta = x0[7 * e + 6];
     double* p = path + (size_t)e * 7 * (T + 1);
     for (int t = 0; t <= T; ++t) {
-        if (t > 0) dyn_step(s, oa[(size_t)e * T + t - 1], od[(size_t)e * T + t - 1], cfg, k);
+        if (t > 0) dyn_step<false>(s, oa[(size_t)e * T + t - 1], od[(size_t)e * T + t - 1], cfg, k);
         p[t] = s.x; p[(T + 1) + t] = s.y; p[2 * (T + 1) + t] = s.delta; p[3 * (T + 1) + t] = s.v; p[4 * (T + 1) + t] = s.yaw;
         p[5 * (T + 1) + t] = s.yr; p[6 * (T + 1) + t] = s.beta;
+    }
+}
+
+// all rollouts of this thread, first-minimum argmin (objective :616-622, bounds :685-706 as a projection)
+template <bool FAST>
+__device__ __forceinline__ void stmpc_rollouts(const float* __restrict__ ce, const double* sref, const f1p_stmpc_cfg& cfg, const DynConst& k,
+                                               const DynState& s0, int tid, double& bc, int& bi) {
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    for (int r = tid; r < R; r += blockDim.x) {
+        DynState s = s0;
+        double cost = 0.0, pdv = 0.0, pa = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double dv = clampd2((double)ce[((size_t)t * 2 + 0) * R + r], -cfg.max_steer_v, cfg.max_steer_v);   // :701-703
+            double a = clampd2((double)ce[((size_t)t * 2 + 1) * R + r], -cfg.max_accel, cfg.max_accel);        // :704-706
+            if (t > 0) dv = clampd2(dv, pdv - cfg.max_steer_v, pdv + cfg.max_steer_v);                         // :685
+            const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + t]; q += cfg.q[j] * er * er; }   // :619
+            cost += q;
+            cost += cfg.r[0] * dv * dv + cfg.r[1] * a * a;                                                       // :616
+            if (t > 0) { const double d0 = dv - pdv, d1 = a - pa; cost += cfg.rd[0] * d0 * d0 + cfg.rd[1] * d1 * d1; }   // :622
+            dyn_step<FAST>(s, a, dv, cfg, k);
+            pdv = dv; pa = a;
+        }
+        const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + T]; q += cfg.qf[j] * er * er; }
+        cost += q;
+        if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
     }
 }
 
@@ -97,30 +140,8 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
     s0.yr = x0[7 * e + 5]; s0.beta = x0[7 * e + 6];
     const float* ce = controls + (size_t)e * T * 2 * R;
     double bc = __builtin_huge_val(); int bi = 0x7fffffff;
-    for (int r = tid; r < R; r += blockDim.x) {
-        DynState s = s0;
-        double cost = 0.0, pdv = 0.0, pa = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double dv = clampd2((double)ce[((size_t)t * 2 + 0) * R + r], -cfg.max_steer_v, cfg.max_steer_v);   // :701-703
-            double a = clampd2((double)ce[((size_t)t * 2 + 1) * R + r], -cfg.max_accel, cfg.max_accel);        // :704-706
-            if (t > 0) dv = clampd2(dv, pdv - cfg.max_steer_v, pdv + cfg.max_steer_v);                         // :685
-            const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
-            double q = 0.0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + t]; q += cfg.q[j] * er * er; }   // :619
-            cost += q;
-            cost += cfg.r[0] * dv * dv + cfg.r[1] * a * a;                                                       // :616
-            if (t > 0) { const double d0 = dv - pdv, d1 = a - pa; cost += cfg.rd[0] * d0 * d0 + cfg.rd[1] * d1 * d1; }   // :622
-            dyn_step(s, a, dv, cfg, k);
-            pdv = dv; pa = a;
-        }
-        const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
-        double q = 0.0;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + T]; q += cfg.qf[j] * er * er; }
-        cost += q;
-        if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
-    }
+    if (fabs(cfg.max_steer) <= 1.0e4) stmpc_rollouts<true>(ce, sref, cfg, k, s0, tid, bc, bi);     // workgroup-uniform
+    else stmpc_rollouts<false>(ce, sref, cfg, k, s0, tid, bc, bi);
     block_argmin(bc, bi, red_d, red_i);
     if (tid == 0) {
         double pdv = 0.0;

@@ -362,6 +362,12 @@ class Context:
         self._check(self.lib.f1p_stmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
         return ref
 
+    def stmpc_shoot_dev(self, d_x0, d_ref, d_controls, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost=None, d_best_seq=None):
+        """Asynchronous launch on HBM-resident buffers: x0 [E][7], ref [E][7][T+1], controls f32 [E][T][2][R]."""
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_stmpc_shoot_dev(self.h, p(d_x0), p(d_ref), p(d_controls), int(E), C.byref(cfg), p(d_steer), p(d_speed),
+                                                 p(d_best_idx), p(d_best_cost), p(d_best_seq)))
+
     def stmpc_shoot(self, x0, ref, controls, cfg, want_seq=True):
         x0 = _f64(x0, (-1, 7)); E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
         ref = _f64(ref, (E, 7, T + 1))
