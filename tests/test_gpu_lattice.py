@@ -258,6 +258,20 @@ def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
         a = ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals)
         b = ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals)
         _same(a, b)
+    # the two-kernel schedule (>= 256 egos) with host goals, a candidate shard and a ragged candidate count
+    E2 = 320
+    poses2 = synth.make_egos(rl, E2, seed=10, pos_sigma=0.5)
+    goals2 = np.stack([np.column_stack([rng.uniform(0.5, 3.0, C), rng.uniform(-1.0, 1.0, C), rng.uniform(-0.6, 0.6, C)]) for _ in range(E2)])
+    goals2[:, 9] = np.nan; goals2[7] = np.nan
+    kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=50, weights=(0.25, 0.25, 0.25, 0.25), check_collision=True)
+    _same(ctx.lattice_plan(poses2, _abi.lattice_cfg(**kw), goals=goals2), ctx.lattice_plan(poses2, _abi.lattice_cfg(prune=True, **kw), goals=goals2))
+    for lo, cnt in ((0, 100), (100, 156), (250, 6)):
+        f2, b2 = synth.bench_lattice_cfg(n_cand=256), synth.bench_lattice_cfg(n_cand=256, prune=True)
+        f2.cand_begin = b2.cand_begin = lo; f2.cand_count = b2.cand_count = cnt
+        _same(ctx.lattice_plan(poses2, f2), ctx.lattice_plan(poses2, b2))
+    f3 = _abi.lattice_cfg(lookaheads=np.linspace(0.6, 3.0, 7), widths=np.linspace(-1, 1, 9), n_stations=23, weights=(0.4, 0.2, 0.2, 0.2), check_collision=True)
+    b3 = _abi.lattice_cfg(lookaheads=np.linspace(0.6, 3.0, 7), widths=np.linspace(-1, 1, 9), n_stations=23, weights=(0.4, 0.2, 0.2, 0.2), check_collision=True, prune=True)
+    _same(ctx.lattice_plan(poses2, f3), ctx.lattice_plan(poses2, b3))
     # a negative weight disables the bound (falls back to the exhaustive kernel): still the same answer
     kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=37, weights=(1.5, -0.5, 0.0, 0.0), check_collision=True)
     _same(ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals), ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals))
