@@ -99,67 +99,12 @@ __device__ __forceinline__ void kmpc_rollouts(const float* __restrict__ ce, cons
 // ---------------------------------------------------------------------------------------------------
 struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; };
 
-// The controls of F1P_K4_CHUNK time steps are requested up front (2 x CHUNK independent 256-byte wave loads in flight) and
-// consumed afterwards: with one load pair per step the kernel is bound by HBM latency (~1 TB/s), not bandwidth.
-#ifndef F1P_K4_CHUNK
-#define F1P_K4_CHUNK 10
-#endif
-#ifndef F1P_K4_PACKED
-#define F1P_K4_PACKED 1
-#endif
 #ifndef F1P_K4_WAVES_FILTER
 #define F1P_K4_WAVES_FILTER 4
 #endif
 #ifndef F1P_K4_CHUNK2
 #define F1P_K4_CHUNK2 5   // time steps per register buffer of the packed filter (4 x CHUNK2 VGPRs)
 #endif
-__device__ __forceinline__ float kmpc_rollout_cost_f32(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R, int r) {
-    float x = 0.f, y = 0.f, v = k.v0, yaw = 0.f, cost = 0.f, pa = 0.f, pd = 0.f;
-    for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK) {
-        float av[F1P_K4_CHUNK], dv[F1P_K4_CHUNK];
-#pragma unroll
-        for (int j = 0; j < F1P_K4_CHUNK; ++j) {
-            const int t = t0 + j < T ? t0 + j : T - 1;                 // clamp: the tail re-reads the last step (unused)
-            av[j] = ce[((size_t)t * 2 + 0) * R + r];
-            dv[j] = ce[((size_t)t * 2 + 1) * R + r];
-        }
-#pragma unroll
-        for (int j = 0; j < F1P_K4_CHUNK; ++j) {
-            const int t = t0 + j;
-            if (t < T) {
-                float a = fminf(fmaxf(av[j], -k.max_accel), k.max_accel);
-                float d = fminf(fmaxf(dv[j], -k.max_steer), k.max_steer);
-                if (t > 0) d = fminf(fmaxf(d, pd - k.dmax), pd + k.dmax);
-                const float e0 = x - sref32[0 * (T + 1) + t], e1 = y - sref32[1 * (T + 1) + t];
-                const float e2 = v - sref32[2 * (T + 1) + t], e3 = yaw - sref32[3 * (T + 1) + t];
-                cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
-                if (t > 0) { const float da = a - pa, dd = d - pd; cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
-                float sn, cs;
-                __sincosf(yaw, &sn, &cs);
-                const float cy = k.c0 * cs - k.s0 * sn, sy = k.s0 * cs + k.c0 * sn;     // cos / sin of the absolute heading
-                const float vdt = v * k.dt;
-                x += vdt * cy;
-                y += vdt * sy;
-                // tan(d) for the clamped steering angle: odd Taylor polynomial to d^11 (relative error < 1e-7 for |d| <= 0.6, no
-                // transcendental issue slots); larger steering limits take the intrinsic
-                float tn;
-                if (k.max_steer <= 0.6f) {
-                    const float d2 = d * d;
-                    tn = d * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
-                } else {
-                    tn = __tanf(d);
-                }
-                yaw += v * k.inv_wb_dt * tn;
-                v = fminf(fmaxf(v + a * k.dt, k.min_speed), k.max_speed);
-                pa = a; pd = d;
-            }
-        }
-    }
-    const float e0 = x - sref32[0 * (T + 1) + T], e1 = y - sref32[1 * (T + 1) + T];
-    const float e2 = v - sref32[2 * (T + 1) + T], e3 = yaw - sref32[3 * (T + 1) + T];
-    cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3;
-    return cost;
-}
 
 // Two rollouts per thread in the lanes of packed-f32 instructions: plain f32 VALU ops issue 16 lanes per clock on CDNA4 and
 // only v_pk_{fma,mul,add}_f32 reach the 32-lane f32 rate, so the filter -- which is VALU-bound once the control stream is
@@ -373,7 +318,6 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
 
     // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
     float fmin_ = __builtin_huge_valf();
-#if F1P_K4_PACKED
     // polynomial phasor / tan only inside their proven ranges (workgroup-uniform): |steer| <= 0.6 rad and a heading increment
     // per step of at most 0.85 rad at the speed limits
     const float vmax = fmaxf(fabsf(k.max_speed), fmaxf(fabsf(k.min_speed), fabsf(k.v0)));
@@ -390,14 +334,6 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
             fmin_ = fminf(fmin_, c.y);
         }
     }
-#else
-    for (int r = tid; r < R; r += blockDim.x) {
-        const float c = kmpc_rollout_cost_f32(ce, sref32, k, T, R, r);
-        c32[r] = c;
-        if (cost32_out) cost32_out[(size_t)e * R + r] = c;
-        fmin_ = fminf(fmin_, c);
-    }
-#endif
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
     if (lane == 0) red_f[wave] = fmin_;
