@@ -116,11 +116,7 @@ __device__ __forceinline__ f1p_f2 med3x2(f1p_f2 x, float lo, float hi) {
     r.y = __builtin_amdgcn_fmed3f(x.y, lo, hi);
     return r;
 }
-// POLY: the heading phasor (cos yaw, sin yaw) is carried along and rotated by the step's heading increment with degree-8 / 9
-// Taylor polynomials (|increment| <= 0.85 rad, checked by the caller) -- packed FMAs instead of four quarter-rate
-// v_sin / v_cos per step; tan of the clamped steering angle likewise (|d| <= 0.6).  Contraction is on in here: this is the
-// filter, its error budget is the refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
-struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd, hc, hs; };
+struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd; };
 
 __device__ __forceinline__ void kmpc_load_chunk2(const float* __restrict__ ce, int T, int R, int r0, int r1, int t0,
                                                  f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
@@ -153,9 +149,8 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             s.cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
             if (t > 0) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
             f1p_f2 cy, sy;                                             // cos / sin of the absolute heading
-            if (POLY) {
-                cy = s.hc; sy = s.hs;
-            } else {
+            {   // hardware sin / cos of the relative heading (the transcendental unit runs beside the packed FMAs: a polynomial
+                // phasor recurrence measured 4 % slower), rotated by the start heading
                 float sn0, cs0, sn1, cs1;
                 __sincosf(s.yaw.x, &sn0, &cs0);
                 __sincosf(s.yaw.y, &sn1, &cs1);
@@ -167,7 +162,7 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             s.x += vdt * cy;
             s.y += vdt * sy;
             f1p_f2 tn;
-            if (POLY) {                                                // odd Taylor polynomial to d^11: relative error < 1e-7 for |d| <= 0.6
+            if (POLY) {                                                // odd Taylor polynomial to d^11: next term 0.0036 d^12 < 2.5e-7 for |d| <= 0.45
                 const f1p_f2 d2 = d * d;
                 tn = d * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
             } else {
@@ -175,30 +170,21 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             }
             const f1p_f2 dyaw = s.v * k.inv_wb_dt * tn;
             s.yaw += dyaw;
-            if (POLY) {
-                const f1p_f2 z = dyaw * dyaw;
-                const f1p_f2 sd = dyaw * (1.0f + z * (-0.16666667f + z * (8.3333333e-3f + z * (-1.9841270e-4f + z * 2.7557319e-6f))));
-                const f1p_f2 cd = 1.0f + z * (-0.5f + z * (4.1666667e-2f + z * (-1.3888889e-3f + z * 2.4801587e-5f)));
-                const f1p_f2 nc = s.hc * cd - s.hs * sd;
-                s.hs = s.hs * cd + s.hc * sd;
-                s.hc = nc;
-            }
             s.v = med3x2(s.v + a * k.dt, k.min_speed, k.max_speed);
             s.pa = a; s.pd = d;
         }
     }
 }
 
-// POLY: the heading phasor (cos yaw, sin yaw) is carried along and rotated by the step's heading increment with degree-8 / 9
-// Taylor polynomials (|increment| <= 0.85 rad, checked by the caller) -- packed FMAs instead of four quarter-rate
-// v_sin / v_cos per step; tan of the clamped steering angle likewise (|d| <= 0.6).  Contraction is on in the step function:
-// this is the filter, its error budget is the refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
+// POLY: tan of the clamped steering angle by its Taylor polynomial (|d| <= 0.45, checked by the caller) instead of the
+// sin / cos / rcp sequence of __tanf.  Contraction is on in the step function: this is the filter, its error budget is the
+// refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
 // The controls of F1P_K4_CHUNK2 time steps are requested up front (4 x CHUNK2 independent 256-byte wave loads in flight).
 template <bool POLY>
 __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R,
                                                          int r0, int r1) {
     KmpcState2 s;
-    s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f; s.hc = k.c0; s.hs = k.s0;
+    s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f;
     for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK2) {
         f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
         kmpc_load_chunk2(ce, T, R, r0, r1, t0, a0, d0);
@@ -318,10 +304,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
 
     // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
     float fmin_ = __builtin_huge_valf();
-    // polynomial phasor / tan only inside their proven ranges (workgroup-uniform): |steer| <= 0.6 rad and a heading increment
-    // per step of at most 0.85 rad at the speed limits
-    const float vmax = fmaxf(fabsf(k.max_speed), fmaxf(fabsf(k.min_speed), fabsf(k.v0)));
-    const bool poly = k.max_steer <= 0.6f && vmax * fabsf(k.inv_wb_dt) * 0.6841368f <= 0.85f;     // tan(0.6) = 0.68413...
+    const bool poly = k.max_steer <= 0.45f;               // polynomial tan inside its accuracy range (the reference's MAX_STEER is 0.4189)
     for (int r = tid; r < R; r += 2 * blockDim.x) {                    // rollouts r and r + 256 share the packed lanes
         const int r1 = r + (int)blockDim.x < R ? r + (int)blockDim.x : r;
         const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(ce, sref32, k, T, R, r, r1) : kmpc_rollout_cost_f32x2<false>(ce, sref32, k, T, R, r, r1);
