@@ -35,11 +35,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # fp64 vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s of FMA)
 FP64_VALU_PEAK_TLANES = 39.3
 # VALU wave-instructions per candidate of k_lattice, from the latest committed PMC profile (SQ_INSTS_VALU / candidates)
-VALU_INSTR_PER_CANDIDATE = {"value": 7184.0, "source": "profiles/r01_k_lattice_v4_summary.md (SQ_INSTS_VALU 1.177e8 / 16384 waves)"}
+VALU_INSTR_PER_CANDIDATE = {"value": 6946.0, "source": "profiles/r01_k_lattice_v5_summary.md (SQ_INSTS_VALU 1.138e8 / 16384 waves)"}
 # HBM-side bytes per k_lattice launch at the headline config, from the separate --pmc passes of the same command:
-# FETCH_SIZE 2772 KiB (x2: the gfx950 wide-read correction of MI355X_MICROARCH.md) + WRITE_SIZE 8192 KiB
-PMC_TRAFFIC = {"bytes": (2772 * 2 + 8192) * 1024, "fetch_kib": 2772, "write_kib": 8192, "egos": 4096, "cands": 256, "stations": 50,
-               "source": "profiles/r01_k_lattice_v4_summary.md"}
+# FETCH_SIZE 2855 KiB (x2: the gfx950 wide-read correction of MI355X_MICROARCH.md) + WRITE_SIZE 8192 KiB
+PMC_TRAFFIC = {"bytes": (2855 * 2 + 8192) * 1024, "fetch_kib": 2855, "write_kib": 8192, "egos": 4096, "cands": 256, "stations": 50,
+               "source": "profiles/r01_k_lattice_v5_summary.md"}
 
 
 def algorithmic_bytes_lattice(E, C, S, n_wp, grid_w, grid_h, device_goals=True):
