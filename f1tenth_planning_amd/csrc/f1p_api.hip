@@ -52,6 +52,13 @@ GridDev grid_dev(const f1p_ctx* ctx) {
     return g;
 }
 
+#define F1P_SMALL_D2H_BYTES ((size_t)64 * 1024)
+static int ensure_bounce(f1p_ctx* ctx) {
+    if (ctx->h_bounce) return F1P_OK;
+    F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_bounce, F1P_SMALL_D2H_BYTES, hipHostMallocDefault));
+    return F1P_OK;
+}
+
 // staged host<->device transfer plan for the *_batch wrappers
 struct Stage {
     f1p_ctx* ctx;
@@ -76,6 +83,20 @@ struct Stage {
         return d;
     }
     int finish() {
+        // Small results (a single vehicle, a few hundred egos): the outputs sit back to back in the arena, so ONE copy into the
+        // context's page-locked bounce buffer and a host-side scatter replace one hipMemcpyAsync per array (~10 us each --
+        // the bulk of a single-vehicle plan()'s latency).
+        if (outs.size() > 1) {
+            char* lo = (char*)outs.front().dev;
+            char* hi = (char*)outs.back().dev + outs.back().bytes;
+            const size_t span = (size_t)(hi - lo);
+            if (span <= F1P_SMALL_D2H_BYTES && ensure_bounce(ctx) == F1P_OK) {
+                F1P_HIP(ctx, hipMemcpyAsync(ctx->h_bounce, lo, span, hipMemcpyDeviceToHost, ctx->stream));
+                F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                for (auto& o : outs) memcpy(o.host, ctx->h_bounce + ((char*)o.dev - lo), o.bytes);
+                return F1P_OK;
+            }
+        }
         for (auto& o : outs) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return F1P_OK;
@@ -227,6 +248,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto& ev : ctx->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

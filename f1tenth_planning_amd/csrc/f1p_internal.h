@@ -35,6 +35,7 @@ struct f1p_ctx {
     // scratch arena for the host-pointer (*_batch) wrappers
     char* d_arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
+    char* h_bounce = nullptr;          // page-locked 64 KB: small results come back in one copy
 
     // shooting-MPC evaluation mode: f32 filter + fp64 refinement (default) or plain fp64; diagnostics of the filter
     bool kmpc_mixed = true;
