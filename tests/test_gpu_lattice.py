@@ -275,3 +275,33 @@ def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
     # a negative weight disables the bound (falls back to the exhaustive kernel): still the same answer
     kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=37, weights=(1.5, -0.5, 0.0, 0.0), check_collision=True)
     _same(ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals), ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals))
+
+
+def test_clothoid_class_and_sample_traj_on_the_gpu(orc):
+    """The pyclothoids stand-in: G1Hermite from an arbitrary start pose, accessors, and sample_traj through the planning kernel
+    against the oracle's fit + evaluation (utils/utils.py:286-295 layout)."""
+    from f1tenth_planning_amd.utils.clothoid import Clothoid
+    from f1tenth_planning_amd.utils.utils import sample_traj
+    rng = np.random.default_rng(4)
+    for _ in range(12):
+        x0, y0, th0 = rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-3, 3)
+        gx, gy, gth = rng.uniform(0.6, 3.0), rng.uniform(-1.0, 1.0), rng.uniform(-0.6, 0.6)
+        c, s = np.cos(th0), np.sin(th0)
+        cl = Clothoid.G1Hermite(x0, y0, th0, x0 + c * gx - s * gy, y0 + s * gx + c * gy, th0 + gth)
+        ok, k0, dk, L = orc.clothoid_g1(gx, gy, gth)
+        assert ok and abs(cl.kappa0 - k0) < 1e-9 and abs(cl.dk - dk) < 1e-9 and abs(cl.length - L) < 1e-10
+        assert abs(cl.X(cl.length) - (x0 + c * gx - s * gy)) < 1e-9 and abs(cl.Y(cl.length) - (y0 + s * gx + c * gy)) < 1e-9
+        assert abs(cl.ThetaEnd - (th0 + gth)) < 1e-9
+        rows = sample_traj(cl, 100)                                   # the reference's npts (lattice_planner.py:197)
+        assert rows.shape == (100, 4)
+        want = orc.sample_traj(k0, dk, L, 100)                        # start frame
+        np.testing.assert_allclose(rows[:, 0], x0 + c * want[:, 0] - s * want[:, 1], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(rows[:, 1], y0 + s * want[:, 0] + c * want[:, 1], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(rows[:, 2], th0 + want[:, 2], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(rows[:, 3], want[:, 3], rtol=0, atol=1e-9)
+        for si in (0.0, 0.37 * cl.length, cl.length):                 # scalar accessors agree with the sampled rows' model
+            assert abs(np.hypot(cl.XDD(si), cl.YDD(si)) - abs(cl.kappa0 + cl.dk * si)) < 1e-12
+    xs, ys = Clothoid.G1Hermite(0, 0, 0, 1, 1, 0).SampleXY(50)
+    assert len(xs) == 50 and abs(xs[-1] - 1.0) < 1e-9 and abs(ys[-1] - 1.0) < 1e-9
+    with pytest.raises(ValueError):
+        Clothoid.G1Hermite(0, 0, 0, 0, 0, 0.3)

@@ -401,6 +401,27 @@ def main():
     g["dyn_Q"] = np.asarray(c7.Q.diagonal()); g["dyn_Qf"] = np.asarray(c7.Qf.diagonal())
     g["dyn_R"] = np.asarray(c7.R.diagonal()); g["dyn_Rd"] = np.asarray(c7.Rd.diagonal()); g["dyn_params"] = vp
     np.savez_compressed(os.path.join(OUT, "g12_dynamic_model.npz"), **g)
+
+    # ---- G13: host helpers of utils.py: solve_lqr, update_matrix (:167-239), quat_2_rpy (:246-269), sample_traj (:286-295) ----
+    rng = np.random.default_rng(13)
+    speeds = rng.uniform(0.3, 8.0, 12)
+    Ks, As, Bs = [], [], []
+    for v in speeds:
+        A, b = U.update_matrix(np.array([0.0, 0.0, 0.0, v]), 4, 0.01, 0.33)
+        Ks.append(U.solve_lqr(A, b, np.diag([0.999, 0.0, 0.0066, 0.0]), np.array([[0.75]]), 0.001, 50))
+        As.append(A); Bs.append(b)
+    quats = rng.normal(0, 1, (16, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    rpy = np.array([U.quat_2_rpy(*q) for q in quats])
+
+    class Arc:   # duck-typed analytic clothoid (circular arc of radius 2 from the origin): sample_traj only calls methods
+        length = 1.5
+        def X(self, s): return 2.0 * np.sin(0.5 * s)
+        def Y(self, s): return 2.0 * (1.0 - np.cos(0.5 * s))
+        def Theta(self, s): return 0.5 * s
+        def XDD(self, s): return -0.5 * np.sin(0.5 * s)
+        def YDD(self, s): return 0.5 * np.cos(0.5 * s)
+    np.savez_compressed(os.path.join(OUT, "g13_utils_host.npz"), speeds=speeds, A=np.array(As), B=np.array(Bs), K=np.array(Ks),
+                        quats=quats, rpy=rpy, arc_traj7=U.sample_traj(Arc(), 7), arc_traj1=U.sample_traj(Arc(), 1))
     print("golden vectors written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))
