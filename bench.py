@@ -34,6 +34,8 @@ from f1tenth_planning_amd.runtime import Context  # noqa: E402  (loads libf1p.so
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # fp64 vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s of FMA)
 FP64_VALU_PEAK_TLANES = 39.3
+# what a pure v_fma_f64 loop sustains on this chip (tools/microbench/valu.hip: 28.5-29.7 T lane-instr/s = 57-59 TFLOP/s)
+FP64_VALU_SUSTAINED_TLANES = 29.7
 # VALU wave-instructions per candidate of k_lattice, from the latest committed PMC profile (SQ_INSTS_VALU / candidates)
 VALU_INSTR_PER_CANDIDATE = {"value": 6946.0, "source": "profiles/r01_k_lattice_v5_summary.md (SQ_INSTS_VALU 1.138e8 / 16384 waves)"}
 # HBM-side bytes per k_lattice launch at the headline config, from the separate --pmc passes of the same command:
@@ -219,6 +221,7 @@ def main():
                          "note": "fused kernel is fp64-VALU/transcendental bound by construction; HBM fraction is tiny",
                          "valu_fp64": {"achieved": valu_tlanes, "peak": FP64_VALU_PEAK_TLANES, "unit": "T lane-instr/s",
                                        "frac": valu_tlanes / FP64_VALU_PEAK_TLANES,
+                                       "sustained_peak": FP64_VALU_SUSTAINED_TLANES, "frac_of_sustained": valu_tlanes / FP64_VALU_SUSTAINED_TLANES,
                                        "valu_instr_per_candidate": VALU_INSTR_PER_CANDIDATE}},
             "blocked_egos": int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
