@@ -1,0 +1,102 @@
+"""Randomised configurations of the lattice planner against the oracle, exhaustive and branch-and-bound schedules alike: station
+counts 2..120, ragged goal grids (1..40 look-aheads x 1..40 widths, more than 256 candidates included), random weights, shifts,
+tracker parameters, maps with different resolutions, inflation, previous trajectories, both generators.  Indices and status exact,
+steering / trajectory within the north_star tolerances; the two schedules bit-identical to each other."""
+import os
+
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from f1tenth_planning_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("F1P_FUZZ_SEEDS", "12"))))   # F1P_FUZZ_SEEDS=200 for a long hunt
+def test_random_lattice_configurations(ctx, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_pts = int(rng.integers(300, 1500))
+    rl = synth.make_raceline(seed=seed, n_pts=n_pts, spacing=float(rng.uniform(0.08, 0.35)))
+    res = float(rng.uniform(0.04, 0.12))
+    side = int(np.ceil((np.ptp(rl[:, 0]) + 8.0) / res)), int(np.ceil((np.ptp(rl[:, 1]) + 8.0) / res))
+    img, origin = synth.make_grid(rl[:, :2], size=(min(side[1], 2600), min(side[0], 2600)), resolution=res,
+                                  half_width=float(rng.uniform(0.8, 1.5)))
+    ctx.set_waypoints(rl)
+    ctx.set_grid(img, res, origin, 206)
+    E = int(rng.integers(3, 70)) if seed % 3 else int(rng.integers(256, 400))     # both branch-and-bound schedules
+    poses = synth.make_egos(rl, E, seed=seed, pos_sigma=float(rng.uniform(0.1, 0.7)), yaw_sigma=float(rng.uniform(0.05, 0.5)))
+    n_l, n_w = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+    if seed % 4 == 0:
+        n_l, n_w = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    S = int(rng.choice([2, 3, 5, 17, 50, 64, 65, 100, 120]))
+    w = rng.uniform(0, 1, 4); w[rng.integers(0, 4)] = 0.0
+    n_shift = int(rng.integers(0, 3)); n_cull = int(rng.integers(0, 3))
+    kw = dict(lookaheads=np.sort(rng.uniform(0.4, 3.5, n_l)), widths=np.sort(rng.uniform(-1.2, 1.2, n_w)), n_stations=S,
+              weights=tuple(w), n_shift=n_shift, n_cull=n_cull, check_collision=bool(seed % 5), track_lookahead=float(rng.uniform(0.3, 1.5)),
+              wheelbase=float(rng.uniform(0.25, 0.4)), generator="cubic" if seed % 6 == 5 else "clothoid")
+    full, bb = _abi.lattice_cfg(**kw), _abi.lattice_cfg(prune=True, **kw)
+    if seed % 2:
+        ctx.inflate_grid(float(rng.uniform(0.05, 0.3)))
+    prev = None
+    if seed % 3 == 1 and S - n_shift - n_cull > 0:
+        prev = rng.normal(0, 0.3, (E, S))
+    a = ctx.lattice_plan(poses, full, prev_theta=prev)
+    b = ctx.lattice_plan(poses, bb, prev_theta=prev)
+    for k in a:
+        np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=f"schedules differ in {k}")
+    if seed % 2:                                               # the oracle sees the un-inflated image: compare without inflation
+        ctx.inflate_grid(0.0)
+        a = ctx.lattice_plan(poses, full, prev_theta=prev)
+    want = orc.lattice_plan_batch(poses, rl, full, grid=(img, res, origin[0], origin[1], 206), prev_theta=prev, nthreads=8)
+    np.testing.assert_array_equal(a["near_idx"], want["near_idx"])
+    np.testing.assert_array_equal(a["status"], want["status"])
+    np.testing.assert_array_equal(a["best_idx"], want["best_idx"])
+    fin = np.isfinite(want["best_cost"])
+    np.testing.assert_allclose(a["best_cost"][fin], want["best_cost"][fin], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(a["steer"], want["steer"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(a["speed"], want["speed"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(a["best_traj"], want["best_traj"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("F1P_FUZZ_SEEDS", "12"))))
+def test_random_kmpc_configurations(ctx, orc, seed):
+    """Random horizons, rollout counts (not multiples of the workgroup), weights and bounds (steering limits on both sides of the
+    polynomial-tan range): the mixed-precision schedule is bit-identical to the all-fp64 kernel and both match the oracle's index."""
+    rng = np.random.default_rng(5000 + seed)
+    cl = synth.make_centerline(seed=2 + seed % 3)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    E = int(rng.integers(1, 90))
+    T = int(rng.choice([1, 2, 5, 8, 30, 31, 64, 65, 70]))
+    R = int(rng.choice([1, 2, 7, 64, 255, 256, 257, 512, 513, 1000]))
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1] + rng.normal(0, 0.2, E), cl[k, 2] + rng.normal(0, 0.2, E), rng.uniform(0.0, 6.5, E),
+                              cl[k, 3] + rng.normal(0, 0.3, E) + 2 * np.pi * rng.integers(-3, 4, E)])
+    max_steer = float(rng.choice([0.2, 0.4189, 0.44, 0.5, 0.9]))
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R, dt=float(rng.choice([0.05, 0.1, 0.2])), max_steer=max_steer,
+                        max_dsteer=float(rng.uniform(0.5, 4.0)), max_speed=float(rng.uniform(3.0, 8.0)), min_speed=float(rng.choice([0.0, -1.0])),
+                        max_accel=float(rng.uniform(1.0, 5.0)), q=tuple(rng.uniform(0, 20, 4)), qf=tuple(rng.uniform(0, 20, 4)),
+                        r=tuple(rng.uniform(0, 50, 2)), rd=tuple(rng.uniform(0, 50, 2)))
+    ref = ctx.kmpc_ref(states, T, cfg.dt, 0.03)
+    ctrl = synth.make_controls(E, T, R, seed=seed, sigma_a=float(rng.uniform(0.5, 4.0)), sigma_d=float(rng.uniform(0.05, 0.6)),
+                               max_accel=10.0, max_steer=2.0)          # beyond the bounds: the projection has work to do
+    try:
+        ctx.kmpc_set_mode(True)
+        mixed = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+        ctx.kmpc_set_mode(False)
+        plain = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+    finally:
+        ctx.kmpc_set_mode(True)
+    for key in ("best_idx", "best_cost", "steer", "speed", "best_seq"):
+        np.testing.assert_array_equal(mixed[key], plain[key], err_msg=key)
+    want = orc.kmpc_shoot_batch(states, ref, ctrl, cfg, nthreads=8)
+    np.testing.assert_array_equal(mixed["best_idx"], want["best_idx"])
+    np.testing.assert_allclose(mixed["steer"], want["steer"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mixed["speed"], want["speed"], rtol=0, atol=1e-12)
