@@ -35,7 +35,7 @@ int main() {
     double* o64; float* o32;
     CHK(hipMalloc(&o64, 8)); CHK(hipMalloc(&o32, 4));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    const int blocks = 256 * 4, iters = 20000;      // 4 workgroups of 4 waves per CU = 4 waves per SIMD
+    const int blocks = 256 * 4, iters = 200000;      // ~14 ms per launch: long enough for the clocks to settle      // 4 workgroups of 4 waves per CU = 4 waves per SIMD
     for (int which = 0; which < 2; ++which) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {

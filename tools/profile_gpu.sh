@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --latency-iters 0 $*"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --latency-iters 0 $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
