@@ -107,6 +107,7 @@ struct Stage {
 #define F1P_PLAN_CHUNKS 2
 #endif
 #define F1P_PLAN_CHUNK_MIN_EGOS 2048
+#define F1P_PLAN_CHUNKS_MAX 8          // = number of slice events in f1p_ctx
 
 static bool is_pinned_host(const void* p) {
     hipPointerAttribute_t a;
@@ -624,7 +625,9 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
     // second stream while slice k + 1 is being planned, so only the last slice's D2H is exposed in the call's latency.
     // Only when the trajectories go to PAGE-LOCKED host memory (f1p_host_alloc / hipHostRegister): copies into pageable
     // memory block the calling thread and would serialise the slices (measured: 0.58 -> 0.72 ms at 4096 egos).
-    const int K = (!all_cost && !all_traj && best_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS && is_pinned_host(best_traj)) ? F1P_PLAN_CHUNKS : 1;
+    // Two slices up to 8191 egos (a slice of 2048 is two full waves of workgroups over the chip), slices of >= 4096 egos beyond.
+    const int k_big = E >= 8192 ? (E / 4096 < F1P_PLAN_CHUNKS_MAX ? E / 4096 : F1P_PLAN_CHUNKS_MAX) : F1P_PLAN_CHUNKS;
+    const int K = (!all_cost && !all_traj && best_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS && is_pinned_host(best_traj)) ? k_big : 1;
     if (K > 1 && (rc = ensure_copy_stream(ctx))) return rc;
     if (K == 1) {
         if ((rc = f1p_lattice_plan_dev(ctx, d_poses, d_goals, d_prev, E, cfg, d_steer, d_speed, d_bi, d_bc, d_st, d_ni, d_bt, d_ac, d_at))) return rc;

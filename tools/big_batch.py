@@ -13,4 +13,8 @@ for prune in (False, True):
     t = time.perf_counter(); out = ctx.lattice_plan(poses, cfg); dt = time.perf_counter() - t
     print("prune", prune, "E", E, "%.2f ms" % (1e3 * dt), "%.3g candidate-steps/s incl. PCIe" % (E * 256 * 50 / dt), "ok frac", (out["status"] == 0).mean())
     if prune: assert (out["best_idx"] == ref["best_idx"]).all() and (out["steer"] == ref["steer"]).all()
-    ref = out
+    ref = {k: np.array(v) for k, v in out.items()}
+    ctx.lattice_plan(poses, cfg, reuse_outputs=True)
+    t = time.perf_counter(); pin = ctx.lattice_plan(poses, cfg, reuse_outputs=True); dt = time.perf_counter() - t
+    print("   page-locked result arrays, sliced plan / D2H pipeline: %.2f ms" % (1e3 * dt), "%.3g candidate-steps/s incl. PCIe" % (E * 256 * 50 / dt))
+    assert all((np.asarray(pin[k]) == ref[k]).all() for k in ("best_idx", "steer", "best_traj"))
