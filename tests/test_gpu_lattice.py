@@ -205,7 +205,7 @@ def test_pinned_pipelined_batch_equals_plain_batch(ctx, scene):
     (f1p_lattice_plan_batch); every output must be bit-identical to the single-launch path, also for an odd split."""
     rl, img, origin = scene
     cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50)
-    for E in (2049, 4096):
+    for E in (2049, 4096, 12289):                      # two slices, two slices, three slices with an odd split
         poses = synth.make_egos(rl, E, seed=77)
         plain = ctx.lattice_plan(poses, cfg)
         pinned = ctx.lattice_plan(poses, cfg, reuse_outputs=True)
