@@ -65,8 +65,18 @@ class PurePursuitPlanner():
             return 0.0, 0.0
         return float(out["steer"][0]), float(out["speed"][0])
 
-    def plan_batch(self, poses, lookahead_distance, waypoints=None):
+    def plan_batch(self, poses, lookahead_distance, waypoints=None, devices=None):
         """poses [E, 3] = (x, y, theta) -> dict(steer [E], speed [E], near_idx, la_idx, status).  Egos without a
-        look-ahead point get (0.0, 0.0) and status 2 instead of a warning per ego."""
+        look-ahead point get (0.0, 0.0) and status 2 instead of a warning per ego.
+        devices: GPU indices (or "all"): contiguous ego ranges, one context and one host thread per GPU, no collective."""
         ctx = self._bind_waypoints(waypoints)
+        if devices is not None:
+            from ...runtime import MultiContext
+            key = "all" if isinstance(devices, str) else tuple(int(d) for d in devices)
+            if getattr(self, "_mc_key", None) != key:
+                if getattr(self, "_mc", None) is not None:
+                    self._mc.close()
+                self._mc, self._mc_key = MultiContext(None if key == "all" else key), key
+            self._mc.set_waypoints_cached(self.waypoints)
+            return self._mc.pure_pursuit(poses, lookahead_distance, self.wheelbase, self.max_reacquire)
         return ctx.pure_pursuit(poses, lookahead_distance, self.wheelbase, self.max_reacquire)

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "f1p_internal.h"
 
 static thread_local std::string g_create_error;
@@ -153,15 +155,17 @@ static int validate_kmpc(f1p_ctx* ctx, const f1p_kmpc_cfg* cfg, int E) {
 using namespace f1p;
 
 // ---------------------------------------------------------------------------------------------------
-// RCCL, loaded with dlopen so libf1p.so itself has no link-time dependency on it.
+// RCCL, loaded with dlopen so libf1p.so itself has no link-time dependency on it.  Types and enum values come
+// from <rccl/rccl.h> (ncclUint64, ncclInt32, ncclMin ...); only the entry points are resolved at run time.
 // ---------------------------------------------------------------------------------------------------
-typedef struct { char internal[F1P_COMM_ID_BYTES]; } rccl_unique_id;
-typedef int (*pfn_ncclGetUniqueId)(rccl_unique_id*);
-typedef int (*pfn_ncclCommInitRank)(void**, int, rccl_unique_id, int);
-typedef int (*pfn_ncclCommDestroy)(void*);
-typedef int (*pfn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef const char* (*pfn_ncclGetErrorString)(int);
-enum { RCCL_INT32 = 2, RCCL_FLOAT64 = 8, RCCL_MIN = 3 };   // ncclInt32, ncclFloat64, ncclMin (nccl.h enums)
+static_assert(NCCL_UNIQUE_ID_BYTES == F1P_COMM_ID_BYTES, "f1p.h must carry RCCL's unique-id size");
+typedef ncclResult_t (*pfn_ncclGetUniqueId)(ncclUniqueId*);
+typedef ncclResult_t (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+typedef ncclResult_t (*pfn_ncclCommDestroy)(ncclComm_t);
+typedef ncclResult_t (*pfn_ncclCommCount)(const ncclComm_t, int*);
+typedef ncclResult_t (*pfn_ncclCommUserRank)(const ncclComm_t, int*);
+typedef ncclResult_t (*pfn_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+typedef const char* (*pfn_ncclGetErrorString)(ncclResult_t);
 
 static int rccl_open(f1p_ctx* ctx) {
     if (ctx->rccl_lib) return F1P_OK;
@@ -245,7 +249,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_cost, ctx->d_comm_idx};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -746,14 +750,19 @@ int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, con
     return launch_kmpc_sample(ctx, d_controls, E, cfg, seed, sigma_accel, sigma_steer);
 }
 
+static std::string rccl_err(f1p_ctx* ctx, const char* what, ncclResult_t r) {
+    auto es = rccl_sym<pfn_ncclGetErrorString>(ctx, "ncclGetErrorString");
+    return std::string(what) + " failed: " + (es ? es(r) : "?") + " (code " + std::to_string((int)r) + ")";
+}
+
 int f1p_comm_unique_id(f1p_ctx* ctx, uint8_t id[F1P_COMM_ID_BYTES]) {
     F1P_ENTER(ctx);
     int rc = rccl_open(ctx); if (rc) return rc;
     auto fn = rccl_sym<pfn_ncclGetUniqueId>(ctx, "ncclGetUniqueId");
     if (!fn) return set_error(ctx, F1P_ECOMM, "ncclGetUniqueId not found");
-    rccl_unique_id uid;
-    int r = fn(&uid);
-    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclGetUniqueId failed");
+    ncclUniqueId uid;
+    const ncclResult_t r = fn(&uid);
+    if (r != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclGetUniqueId", r));
     memcpy(id, uid.internal, F1P_COMM_ID_BYTES);
     return F1P_OK;
 }
@@ -765,11 +774,28 @@ int f1p_comm_init(f1p_ctx* ctx, const uint8_t id[F1P_COMM_ID_BYTES], int32_t nra
     if (ctx->comm) f1p_comm_destroy(ctx);
     auto fn = rccl_sym<pfn_ncclCommInitRank>(ctx, "ncclCommInitRank");
     if (!fn) return set_error(ctx, F1P_ECOMM, "ncclCommInitRank not found");
-    rccl_unique_id uid;
+    ncclUniqueId uid;
     memcpy(uid.internal, id, F1P_COMM_ID_BYTES);
-    int r = fn(&ctx->comm, nranks, uid, rank);
-    if (r != 0) { ctx->comm = nullptr; return set_error(ctx, F1P_ECOMM, "ncclCommInitRank failed with code " + std::to_string(r)); }
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = fn(&comm, nranks, uid, rank);
+    if (r != ncclSuccess) { ctx->comm = nullptr; return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclCommInitRank", r)); }
+    ctx->comm = comm;
     ctx->comm_rank = rank; ctx->comm_nranks = nranks;
+    return F1P_OK;
+}
+
+int f1p_comm_info(f1p_ctx* ctx, int32_t* nranks, int32_t* rank) {
+    F1P_ENTER(ctx);
+    if (!ctx->comm) return set_error(ctx, F1P_ESTATE, "communicator not initialised: call f1p_comm_init");
+    auto cnt = rccl_sym<pfn_ncclCommCount>(ctx, "ncclCommCount");
+    auto ur = rccl_sym<pfn_ncclCommUserRank>(ctx, "ncclCommUserRank");
+    if (!cnt || !ur) return set_error(ctx, F1P_ECOMM, "ncclCommCount / ncclCommUserRank not found");
+    int n = 0, r = 0;
+    ncclResult_t e = cnt((ncclComm_t)ctx->comm, &n);
+    if (e == ncclSuccess) e = ur((ncclComm_t)ctx->comm, &r);
+    if (e != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclCommCount", e));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
     return F1P_OK;
 }
 
@@ -777,12 +803,18 @@ int f1p_comm_destroy(f1p_ctx* ctx) {
     if (!ctx) return F1P_EINVAL;
     if (ctx->comm && ctx->rccl_lib) {
         auto fn = rccl_sym<pfn_ncclCommDestroy>(ctx, "ncclCommDestroy");
-        if (fn) (void)fn(ctx->comm);
+        if (fn) (void)fn((ncclComm_t)ctx->comm);
     }
     ctx->comm = nullptr;
     return F1P_OK;
 }
 
+// Cross-rank argmin with np.argmin's rules (first minimum; a NaN cost is "smaller" than any number, lattice_planner.py:159-172,
+// f1p::argmin_better).  ncclMin on floating point leaves NaN handling unspecified, so the cost travels as a monotone
+// unsigned 64-bit key (k_argmin_key: NaN -> 0, otherwise the IEEE bits made order-preserving) and both reductions are
+// integer minima: all-reduce(min, u64) on the key, then all-reduce(min, i32) on the index among the ranks holding that key.
+// The key map is a bijection on non-NaN doubles (-0.0 is folded into +0.0, which np.argmin also treats as equal), so the
+// cost that comes back is bit-identical to the single-GPU result.
 int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E) {
     F1P_ENTER(ctx);
     if (!ctx->comm) return set_error(ctx, F1P_ESTATE, "communicator not initialised: call f1p_comm_init");
@@ -790,25 +822,58 @@ int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E)
     if (E == 0) return F1P_OK;
     if (E > ctx->comm_cap) {
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_comm_cost) (void)hipFree(ctx->d_comm_cost);
+        if (ctx->d_comm_key) (void)hipFree(ctx->d_comm_key);
         if (ctx->d_comm_idx) (void)hipFree(ctx->d_comm_idx);
-        ctx->d_comm_cost = nullptr; ctx->d_comm_idx = nullptr; ctx->comm_cap = 0;
-        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_cost, sizeof(double) * (size_t)E));
+        ctx->d_comm_key = nullptr; ctx->d_comm_idx = nullptr; ctx->comm_cap = 0;
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_key, sizeof(uint64_t) * 2 * (size_t)E));   // [own keys | reduced keys]
         F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_idx, sizeof(int32_t) * (size_t)E));
         ctx->comm_cap = E;
     }
     auto ar = rccl_sym<pfn_ncclAllReduce>(ctx, "ncclAllReduce");
     if (!ar) return set_error(ctx, F1P_ECOMM, "ncclAllReduce not found");
-    // 1. global minimum cost per ego
-    int r = ar(d_cost, ctx->d_comm_cost, (size_t)E, RCCL_FLOAT64, RCCL_MIN, ctx->comm, ctx->stream);
-    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclAllReduce(min, f64) failed with code " + std::to_string(r));
-    // 2. ranks that hold that cost keep their index, the others contribute INT32_MAX
-    int rc = launch_mask_idx(ctx, d_cost, ctx->d_comm_cost, d_idx, ctx->d_comm_idx, E); if (rc) return rc;
+    uint64_t* own = ctx->d_comm_key;
+    uint64_t* red = ctx->d_comm_key + E;
+    int rc = launch_argmin_key(ctx, d_cost, own, E); if (rc) return rc;
+    // 1. global minimum key per ego
+    ncclResult_t r = ar(own, red, (size_t)E, ncclUint64, ncclMin, (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclAllReduce(min, u64)", r));
+    // 2. ranks that hold that key keep their index, the others contribute INT32_MAX; the winning cost is decoded in place
+    rc = launch_argmin_mask(ctx, own, red, d_idx, ctx->d_comm_idx, d_cost, E); if (rc) return rc;
     // 3. lowest index among the holders (np.argmin first-minimum rule)
-    r = ar(ctx->d_comm_idx, d_idx, (size_t)E, RCCL_INT32, RCCL_MIN, ctx->comm, ctx->stream);
-    if (r != 0) return set_error(ctx, F1P_ECOMM, "ncclAllReduce(min, i32) failed with code " + std::to_string(r));
-    F1P_HIP(ctx, hipMemcpyAsync(d_cost, ctx->d_comm_cost, sizeof(double) * (size_t)E, hipMemcpyDeviceToDevice, ctx->stream));
+    r = ar(ctx->d_comm_idx, d_idx, (size_t)E, ncclInt32, ncclMin, (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclAllReduce(min, i32)", r));
     return F1P_OK;
+}
+
+// the two local kernels of the exchange on host arrays (the collective replaced by the caller): lets a single-GPU box check
+// the key map against np.argmin for NaN / inf / signed-zero costs.  keys_out [E] <- key(cost[e]);
+int f1p_argmin_key_batch(f1p_ctx* ctx, const double* cost, int32_t E, uint64_t* keys_out) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!cost || !keys_out))) return set_error(ctx, F1P_EINVAL, "bad cost / keys / E");
+    Stage s(ctx);
+    s.need(8 * (size_t)E); s.need(8 * (size_t)E);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_c;
+    if ((rc = s.in(cost, (size_t)E, &d_c))) return rc;
+    uint64_t* d_k = s.out(keys_out, (size_t)E);
+    if ((rc = launch_argmin_key(ctx, d_c, d_k, E))) return rc;
+    return s.finish();
+}
+// own_keys / min_keys / idx [E] -> masked_idx [E] (idx where own == min, else INT32_MAX), cost_out [E] = decoded min key
+int f1p_argmin_mask_batch(f1p_ctx* ctx, const uint64_t* own_keys, const uint64_t* min_keys, const int32_t* idx, int32_t E,
+                          int32_t* masked_idx, double* cost_out) {
+    F1P_ENTER(ctx);
+    if (E < 0 || (E > 0 && (!own_keys || !min_keys || !idx || !masked_idx || !cost_out))) return set_error(ctx, F1P_EINVAL, "NULL argument");
+    Stage s(ctx);
+    s.need(8 * (size_t)E); s.need(8 * (size_t)E); s.need(4 * (size_t)E); s.need(4 * (size_t)E); s.need(8 * (size_t)E);
+    int rc = s.begin(); if (rc) return rc;
+    const uint64_t *d_o, *d_m; const int32_t* d_i;
+    if ((rc = s.in(own_keys, (size_t)E, &d_o))) return rc;
+    if ((rc = s.in(min_keys, (size_t)E, &d_m))) return rc;
+    if ((rc = s.in(idx, (size_t)E, &d_i))) return rc;
+    int32_t* d_mi = s.out(masked_idx, (size_t)E); double* d_c = s.out(cost_out, (size_t)E);
+    if ((rc = launch_argmin_mask(ctx, d_o, d_m, d_i, d_mi, d_c, E))) return rc;
+    return s.finish();
 }
 
 // ---------------------------------------------------------------------------------------------------

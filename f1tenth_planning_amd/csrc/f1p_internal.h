@@ -50,7 +50,7 @@ struct f1p_ctx {
     void* rccl_lib = nullptr;
     void* comm = nullptr;
     int comm_rank = 0, comm_nranks = 0;
-    double* d_comm_cost = nullptr;
+    uint64_t* d_comm_key = nullptr;    // [2][comm_cap]: own keys | reduced keys of the argmin exchange
     int32_t* d_comm_idx = nullptr;
     int comm_cap = 0;
 };
@@ -105,6 +105,8 @@ int launch_stmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, c
 int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E, const f1p_stmpc_cfg* cfg,
                        double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, double* d_best_seq);
 int launch_stmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);
-int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E);
+int launch_argmin_key(f1p_ctx* ctx, const double* d_cost, uint64_t* d_key, int E);
+int launch_argmin_mask(f1p_ctx* ctx, const uint64_t* d_own, const uint64_t* d_min, const int32_t* d_idx, int32_t* d_masked,
+                       double* d_cost_out, int E);
 
 }  // namespace f1p

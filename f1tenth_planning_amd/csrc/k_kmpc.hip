@@ -449,11 +449,25 @@ __global__ __launch_bounds__(256) void k_kmpc_sample(float* __restrict__ control
     controls[(et * 2 + 1) * R + r] = d;
 }
 
-__global__ void k_mask_idx(const double* __restrict__ cost, const double* __restrict__ gmin, const int32_t* __restrict__ idx,
-                           int32_t* __restrict__ masked, int E) {
+// ---- the two local kernels of the cross-rank argmin (f1p_comm_argmin_dev) ---------------------------------------------
+// cost -> unsigned key whose integer order is np.argmin's order on costs: NaN first (key 0), then -inf ... +inf.
+__global__ void k_argmin_key(const double* __restrict__ cost, uint64_t* __restrict__ key, int E) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    masked[e] = (cost[e] == gmin[e]) ? idx[e] : 0x7fffffff;
+    double c = cost[e];
+    if (c != c) { key[e] = 0ull; return; }
+    if (c == 0.0) c = 0.0;                                            // -0.0 == +0.0 for np.argmin: one key
+    const uint64_t b = (uint64_t)__double_as_longlong(c);
+    key[e] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);           // negative: reversed; positive: above every negative
+}
+__global__ void k_argmin_mask(const uint64_t* __restrict__ own, const uint64_t* __restrict__ gmin, const int32_t* __restrict__ idx,
+                              int32_t* __restrict__ masked, double* __restrict__ cost_out, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t k = gmin[e];
+    masked[e] = (own[e] == k) ? idx[e] : 0x7fffffff;
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    cost_out[e] = k == 0ull ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double((long long)b);
 }
 
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
@@ -504,10 +518,17 @@ int launch_kmpc_sample(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cf
     return check_hip(ctx, hipGetLastError(), "k_kmpc_sample launch");
 }
 
-int launch_mask_idx(f1p_ctx* ctx, const double* d_cost, const double* d_gmin, const int32_t* d_idx, int32_t* d_masked, int E) {
+int launch_argmin_key(f1p_ctx* ctx, const double* d_cost, uint64_t* d_key, int E) {
     if (E <= 0) return F1P_OK;
-    hipLaunchKernelGGL(k_mask_idx, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_cost, d_gmin, d_idx, d_masked, E);
-    return check_hip(ctx, hipGetLastError(), "k_mask_idx launch");
+    hipLaunchKernelGGL(k_argmin_key, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_cost, d_key, E);
+    return check_hip(ctx, hipGetLastError(), "k_argmin_key launch");
+}
+
+int launch_argmin_mask(f1p_ctx* ctx, const uint64_t* d_own, const uint64_t* d_min, const int32_t* d_idx, int32_t* d_masked,
+                       double* d_cost_out, int E) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_argmin_mask, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_own, d_min, d_idx, d_masked, d_cost_out, E);
+    return check_hip(ctx, hipGetLastError(), "k_argmin_mask launch");
 }
 
 }  // namespace f1p

@@ -31,18 +31,41 @@ def candidate_shard_cfg(cfg, rank, world):
     return sh
 
 
+def cost_key(cost):
+    """np.argmin's order on fp64 costs as an unsigned 64-bit key: NaN -> 0 (a NaN wins np.argmin), then -inf ... +inf by
+    the order-preserving map of the IEEE bits; -0.0 and +0.0 share a key.  Host mirror of k_argmin_key (csrc/k_kmpc.hip)."""
+    c = np.array(cost, dtype=np.float64, copy=True).reshape(-1)
+    c[c == 0.0] = 0.0
+    b = c.view(np.uint64)
+    key = np.where((b >> np.uint64(63)).astype(bool), ~b, b | np.uint64(1 << 63))
+    key[np.isnan(c)] = 0
+    return key
+
+
+def key_cost(key):
+    """inverse of cost_key (key 0 -> NaN)"""
+    k = np.ascontiguousarray(key, dtype=np.uint64)
+    b = np.where((k >> np.uint64(63)).astype(bool), k & np.uint64((1 << 63) - 1), ~k)
+    c = b.view(np.float64).copy()
+    c[k == 0] = np.nan
+    return c
+
+
 def argmin_allreduce(cost, idx, group=None):
-    """Global (cost, idx) argmin over ranks on host arrays: all-reduce(min) of cost, then all-reduce(min) of the index
-    among the holders of the minimum.  Works on any torch.distributed backend."""
+    """Global (cost, idx) argmin over ranks on host arrays with np.argmin's rules (first minimum, NaN first): all-reduce(min)
+    of the cost key, then all-reduce(min) of the index among the holders of the minimum -- the algorithm of
+    f1p_comm_argmin_dev on any torch.distributed backend."""
     import torch
     import torch.distributed as dist
-    c = torch.from_numpy(np.ascontiguousarray(cost, dtype=np.float64).copy())
-    gmin = c.clone()
+    own = cost_key(cost)
+    k = torch.from_numpy((own ^ np.uint64(1 << 63)).view(np.int64).copy())     # gloo has no u64: order-preserving shift to i64
+    gmin = k.clone()
     dist.all_reduce(gmin, op=dist.ReduceOp.MIN, group=group)
     i = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64).copy())
-    masked = torch.where(c == gmin, i, torch.full_like(i, np.iinfo(np.int32).max))
+    masked = torch.where(k == gmin, i, torch.full_like(i, np.iinfo(np.int32).max))
     dist.all_reduce(masked, op=dist.ReduceOp.MIN, group=group)
-    return gmin.numpy(), masked.numpy().astype(np.int32)
+    gkey = gmin.numpy().view(np.uint64) ^ np.uint64(1 << 63)
+    return key_cost(gkey), masked.numpy().astype(np.int32)
 
 
 def init_rccl(ctx, rank, world, group=None):

@@ -263,11 +263,33 @@ class LatticePlanner():
                     b.free()
         return steer, speed, status, traj
 
-    def plan_batch(self, poses, waypoints=None, prev_theta=None, want_traj=True):
+    def plan_batch(self, poses, waypoints=None, prev_theta=None, want_traj=True, devices=None):
         """poses [E, 4] = (x, y, theta, velocity) -> dict(steer, speed, best_idx, best_cost, status, near_idx[, best_traj]).
-        Fused device path only (Python callables cannot run per ego on the GPU)."""
+        Fused device path only (Python callables cannot run per ego on the GPU).
+        devices: list of GPU indices (or "all") -- the egos are cut into contiguous ranges, one per GPU, each planned by its own
+        context on its own host thread (runtime.MultiContext; egos are independent, so there is no collective and the result
+        is identical to the single-GPU plan)."""
         ctx = self._bind(waypoints)
-        return ctx.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj)
+        if devices is None:
+            return ctx.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj)
+        mc = self._multi(devices)
+        mc.set_waypoints_cached(self.waypoints)
+        return mc.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj)
+
+    def _multi(self, devices):
+        from ...runtime import MultiContext
+        key = "all" if isinstance(devices, str) else tuple(int(d) for d in devices)
+        if getattr(self, "_mc_key", None) != key:
+            if getattr(self, "_mc", None) is not None:
+                self._mc.close()
+            self._mc = MultiContext(None if key == "all" else key)
+            self._mc_key, self._mc_map = key, None
+        if self._map is not None and self._mc_map != (id(self._map), self._inflate):
+            self._mc.set_grid(*self._map)
+            if self._inflate > 0.0:
+                self._mc.inflate_grid(self._inflate)
+            self._mc_map = (id(self._map), self._inflate)
+        return self._mc
 
 
 # ---- working versions of the reference's example plug-ins (its own do not run, SURVEY.md section 0) ---------------

@@ -392,8 +392,124 @@ class Context:
         buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(uid)
         self._check(self.lib.f1p_comm_init(self.h, buf, int(nranks), int(rank)))
 
+    def comm_info(self):
+        """(nranks, rank) as the RCCL communicator reports them."""
+        n = C.c_int32(); r = C.c_int32()
+        self._check(self.lib.f1p_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def comm_argmin_dev(self, d_cost, d_idx, E):
         self._check(self.lib.f1p_comm_argmin_dev(self.h, d_cost.ptr, d_idx.ptr, int(E)))
+
+    def argmin_key(self, cost):
+        """the cost -> u64 key map of the cross-rank argmin (np.argmin order, NaN first)"""
+        cost = _f64(cost).reshape(-1); E = cost.shape[0]
+        keys = np.empty(E, np.uint64)
+        self._check(self.lib.f1p_argmin_key_batch(self.h, _ptr(cost), E, _ptr(keys)))
+        return keys
+
+    def argmin_mask(self, own_keys, min_keys, idx):
+        own = np.ascontiguousarray(own_keys, np.uint64); mn = np.ascontiguousarray(min_keys, np.uint64)
+        idx = np.ascontiguousarray(idx, np.int32); E = own.shape[0]
+        masked = np.empty(E, np.int32); cost = np.empty(E)
+        self._check(self.lib.f1p_argmin_mask_batch(self.h, _ptr(own), _ptr(mn), _ptr(idx), E, _ptr(masked), _ptr(cost)))
+        return masked, cost
+
+
+class MultiContext:
+    """One process, several GPUs (SURVEY.md 8b "Threading"): one Context per device, each driven by its own host thread
+    (ctypes releases the GIL for the duration of a C call, and distinct f1p_ctx are thread-safe).  Egos are independent, so a
+    batch is cut into contiguous ego ranges -- GPU g gets egos [g E/G, (g+1) E/G) -- with NO collective; the scene (waypoints,
+    grid) is replicated.  Results are concatenated in ego order, so the output is identical to one Context planning the whole
+    batch.  `devices` may repeat an index (two contexts, two streams on one GPU): that is how a single-GPU box tests this path.
+    """
+
+    def __init__(self, devices=None):
+        from concurrent.futures import ThreadPoolExecutor
+        if devices is None:
+            n = _abi.load_library().f1p_device_count()
+            if n <= 0:
+                raise F1PError(_abi.F1P_ENODEV, "no HIP device visible -- the HIP path is mandatory, there is no CPU fallback")
+            devices = range(n)
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("devices must name at least one GPU")
+        self.ctxs = [Context(d) for d in self.devices]
+        self._pool = ThreadPoolExecutor(max_workers=len(self.ctxs), thread_name_prefix="f1p-gpu")
+
+    def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        for c in getattr(self, "ctxs", []):
+            c.close()
+        self.ctxs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _each(self, fn):
+        """run fn(ctx, g) on every context's thread; re-raises the first failure"""
+        return [f.result() for f in [self._pool.submit(fn, c, g) for g, c in enumerate(self.ctxs)]]
+
+    # ---- scene: replicated ---------------------------------------------------------------------------------------
+    def set_waypoints(self, waypoints, cols=None):
+        self._each(lambda c, g: c.set_waypoints(waypoints, cols))
+
+    def set_waypoints_cached(self, waypoints, cols=None):
+        self._each(lambda c, g: c.set_waypoints_cached(waypoints, cols))
+
+    def set_grid(self, img, resolution, origin, occupied_below):
+        self._each(lambda c, g: c.set_grid(img, resolution, origin, occupied_below))
+
+    def inflate_grid(self, radius):
+        self._each(lambda c, g: c.inflate_grid(radius))
+
+    def sync(self):
+        self._each(lambda c, g: c.sync())
+
+    # ---- batched planners: ego-sharded -----------------------------------------------------------------------------
+    def _sharded(self, n_items, call):
+        """call(ctx, lo, hi) -> dict of arrays with leading dimension hi - lo; concatenated over the ego ranges"""
+        from .dist import shard_range
+        G = len(self.ctxs)
+        ranges = [shard_range(n_items, g, G) for g in range(G)]
+
+        def run(c, g):
+            lo, hi = ranges[g]
+            return call(c, lo, hi) if hi > lo else None
+        parts = [p for p in self._each(run) if p is not None]
+        if not parts:
+            return call(self.ctxs[0], 0, 0)
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+    def lattice_plan(self, poses, cfg, goals=None, prev_theta=None, want_traj=True):
+        poses = _f64(poses, (-1, 4)); E = poses.shape[0]
+        g = None if goals is None else _f64(goals, (E, cfg.n_cand, 3))
+        pt = None if prev_theta is None else _f64(prev_theta, (E, cfg.n_stations))
+        return self._sharded(E, lambda c, lo, hi: c.lattice_plan(poses[lo:hi], cfg, None if g is None else g[lo:hi],
+                                                                   None if pt is None else pt[lo:hi], want_traj=want_traj))
+
+    def pure_pursuit(self, poses, lookahead, wheelbase=0.33, max_reacquire=20.0):
+        poses = _f64(poses, (-1, 3))
+        return self._sharded(poses.shape[0], lambda c, lo, hi: c.pure_pursuit(poses[lo:hi], lookahead, wheelbase, max_reacquire))
+
+    def kmpc_ref(self, states, horizon, dt=0.1, dl=0.03):
+        st = _f64(states, (-1, 4))
+        return self._sharded(st.shape[0], lambda c, lo, hi: dict(ref=c.kmpc_ref(st[lo:hi], horizon, dt, dl)))["ref"]
+
+    def kmpc_shoot(self, x0, ref, controls, cfg, want_seq=True):
+        x0 = _f64(x0, (-1, 4))
+        return self._sharded(x0.shape[0], lambda c, lo, hi: c.kmpc_shoot(x0[lo:hi], ref[lo:hi], controls[lo:hi], cfg, want_seq))
 
 
 _default_ctx = None

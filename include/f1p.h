@@ -338,14 +338,24 @@ int f1p_stmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, c
  * Multi-GPU: egos shard with no communication (one ctx per rank).  Only when ONE ego's candidate set is
  * split over ranks is there an exchange step: all-reduce(min) of the per-ego best cost, then
  * all-reduce(min) of the candidate index among the ranks that hold that cost (np.argmin first-minimum
- * rule, lattice_planner.py:170), both RCCL collectives enqueued on the ctx stream.
+ * rule, lattice_planner.py:159-172), both RCCL collectives enqueued on the ctx stream.
  * ---------------------------------------------------------------------------------------------- */
 #define F1P_COMM_ID_BYTES 128
 int f1p_comm_unique_id(f1p_ctx* ctx, uint8_t id[F1P_COMM_ID_BYTES]);              /* rank 0, then broadcast */
 int f1p_comm_init(f1p_ctx* ctx, const uint8_t id[F1P_COMM_ID_BYTES], int32_t nranks, int32_t rank);
 int f1p_comm_destroy(f1p_ctx* ctx);
-/* in place on device buffers: d_cost [E] fp64 <- global min; d_idx [E] int32 <- lowest index with that cost */
+/* number of ranks / this rank as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank) */
+int f1p_comm_info(f1p_ctx* ctx, int32_t* nranks, int32_t* rank);
+/* in place on device buffers: d_cost [E] fp64 <- global min; d_idx [E] int32 <- lowest index with that cost.
+ * np.argmin's ordering including its NaN rule (a NaN cost wins, the first one by index): the cost is reduced as a
+ * monotone unsigned 64-bit key (NaN -> 0), so both collectives are integer all-reduce(min) and every rank agrees. */
 int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E);
+/* The two local steps of that exchange on host arrays (the collective in between is the caller's), so the key map can be
+ * checked against np.argmin on a single GPU:  keys [E] <- key(cost);  masked_idx [E] <- idx where own_keys == min_keys
+ * else INT32_MAX, cost_out [E] <- the cost min_keys encodes. */
+int f1p_argmin_key_batch(f1p_ctx* ctx, const double* cost, int32_t E, uint64_t* keys);
+int f1p_argmin_mask_batch(f1p_ctx* ctx, const uint64_t* own_keys, const uint64_t* min_keys, const int32_t* idx, int32_t E,
+                          int32_t* masked_idx, double* cost_out);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,13 @@ part = oracle.lattice_plan_batch(poses, rl, sh)
 cost, idx = argmin_allreduce(part["best_cost"], part["best_idx"])
 # ties: rank 1 holds the same cost at a higher index, rank 0 must win (first-minimum rule)
 tc, ti = argmin_allreduce(np.array([1.0, 2.0 - rank, np.inf]), np.array([5 + 10 * rank, 7 + rank, 3 - rank]))
+# np.argmin's NaN rule across ranks: a NaN cost wins (the first one by index), -inf beats numbers, -0.0 ties with +0.0
+nan = float("nan")
+nc, ni = argmin_allreduce(np.array([nan if rank == 1 else -5.0, nan, -np.inf if rank == 0 else -1e300, 0.0 if rank == 1 else -0.0]),
+                          np.array([40 + rank, 9 - 2 * rank, 3 + rank, 8 - 4 * rank]))
 out = dict(rank=rank, lo=lo, hi=hi, ego_best=mine["best_idx"].tolist(), cand_cost=cost.tolist(), cand_idx=idx.tolist(),
-           tie_cost=tc.tolist(), tie_idx=ti.tolist(), shard=[sh.cand_begin, sh.cand_count])
+           tie_cost=tc.tolist(), tie_idx=ti.tolist(), shard=[sh.cand_begin, sh.cand_count],
+           nan_isnan=np.isnan(nc).tolist(), nan_cost=np.nan_to_num(nc, nan=0.0, neginf=-1e308).tolist(), nan_idx=ni.tolist())
 dist.barrier()
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
@@ -84,3 +89,37 @@ def test_world2_gloo_ego_and_candidate_sharding(tmp_path):
         assert o["cand_idx"] == full["best_idx"].tolist()
         np.testing.assert_array_equal(np.array(o["cand_cost"]), full["best_cost"])
         assert o["tie_idx"] == [5, 8, 2] and o["tie_cost"][:2] == [1.0, 1.0] and np.isinf(o["tie_cost"][2])
+        # NaN on rank 1 only -> its index; NaN on both -> the lower index; -inf beats -1e300; signed zeros tie -> lower index
+        assert o["nan_isnan"] == [True, True, False, False]
+        assert o["nan_idx"] == [41, 7, 3, 4] and o["nan_cost"][2] == -1e308 and o["nan_cost"][3] == 0.0
+
+
+def test_cost_key_is_np_argmin_order():
+    """the host mirror of k_argmin_key: integer order of the keys == np.argmin's order on the costs (NaN first)"""
+    from f1tenth_planning_amd.dist import cost_key, key_cost
+    rng = np.random.default_rng(5)
+    base = np.concatenate([rng.normal(0, 1, 200) * np.exp(rng.uniform(-700, 700, 200)),
+                           [np.nan, np.inf, -np.inf, 0.0, -0.0, 5e-324, -5e-324, 1.0, 1.0]])
+    for _ in range(200):
+        c = rng.choice(base, 7)
+        k = cost_key(c)
+        assert int(np.argmin(k)) == int(np.argmin(c)), (c, k)        # first minimum, NaN first
+    r = base[~np.isnan(base)]
+    back = key_cost(cost_key(r))
+    assert np.array_equal(back, r) and np.isnan(key_cost(cost_key([np.nan]))[0])        # -0.0 == 0.0 under array_equal
+
+
+def test_bench_self_launch_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher starts the ranks itself (the parent never touches the GPU); on a box with
+    fewer devices every path ends in a non-zero exit and a message, never in a silent 1-GPU run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    from f1tenth_planning_amd import _abi
+    n = _abi.load_library().f1p_device_count()
+    if n >= 2:
+        assert p.returncode == 0 and '"n_gpus": 2' in p.stdout, p.stdout[-2000:]
+    else:
+        assert p.returncode != 0, p.stdout[-2000:]
+        assert "f1p_device_count()" in p.stdout or "GPU(s) are visible" in p.stdout, p.stdout[-2000:]
+        assert '"n_gpus"' not in p.stdout

@@ -1,33 +1,132 @@
-"""The RCCL exchange step of the candidate-sharded mode on the one GPU a test box has: a 1-rank communicator runs the
-same f1p_comm_argmin_dev + emit path the 8-GPU job runs, and must reproduce the unsharded plan bit for bit."""
+"""Multi-GPU paths on whatever the test box has.
+
+* world in {2, 4, 8} with REAL RCCL ranks: `bench.py --gpus N --shard candidates` (self-launched children, one rank per GPU)
+  must report N ranks as seen by the communicator, a plan bit-identical to the unsharded one on every rank and the
+  exchange self-test (NaN / inf / ties against np.argmin) green; skipped when the box has fewer devices.  RCCL refuses two
+  ranks on one device, so a single-GPU box covers the same code with
+* a 1-rank communicator (f1p_comm_argmin_dev + emit == the unsharded plan, NaN costs included),
+* the two local kernels of the exchange against np.argmin over emulated ranks (host min in place of the collective),
+* the single-process multi-context plan_batch (two contexts / two host threads on device 0).
+"""
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from f1tenth_planning_amd import synth
-from f1tenth_planning_amd.dist import lattice_plan_candidate_sharded
+from f1tenth_planning_amd import _abi, synth
+from f1tenth_planning_amd.dist import candidate_shard_cfg, cost_key, lattice_plan_candidate_sharded
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(ctx):
+    rl = synth.make_raceline(seed=0)
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+    ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+    return rl
 
 
 def test_candidate_sharded_one_rank_rccl():
     from f1tenth_planning_amd.runtime import Context
-    rl = synth.make_raceline(seed=0)
-    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
     cfg = synth.bench_lattice_cfg(n_cand=512, n_stations=50)       # BASELINE config 1 candidate set
-    poses = synth.make_egos(rl, 33, seed=41)
     with Context(0) as ctx:
-        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        rl = _scene(ctx)
+        poses = synth.make_egos(rl, 33, seed=41)
         full = ctx.lattice_plan(poses, cfg)
         ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        assert ctx.comm_info() == (1, 0)
         got = lattice_plan_candidate_sharded(ctx, poses, cfg, rank=0, world=1, use_rccl=True)
         for k in ("steer", "speed", "best_idx", "best_cost", "status", "near_idx", "best_traj"):
             np.testing.assert_array_equal(got[k], full[k])
-        # emulate 4 ranks on one device: evaluate 4 slices, reduce on the host exactly like the collective does
-        from f1tenth_planning_amd.dist import candidate_shard_cfg
-        bc = np.full(33, np.inf); bi = np.full(33, 2 ** 31 - 1, np.int64)
-        for r in range(4):
-            o = ctx.lattice_plan(poses, candidate_shard_cfg(cfg, r, 4), want_traj=False)
-            gmin = np.minimum(bc, o["best_cost"])
-            bi = np.minimum(np.where(bc == gmin, bi, 2 ** 31 - 1), np.where(o["best_cost"] == gmin, o["best_idx"], 2 ** 31 - 1))
-            bc = gmin
-        np.testing.assert_array_equal(bi, full["best_idx"]); np.testing.assert_array_equal(bc, full["best_cost"])
+        # emulate 4 ranks on one device: evaluate 4 slices, reduce with the exchange's own kernels (host min = the collective)
+        parts = [ctx.lattice_plan(poses, candidate_shard_cfg(cfg, r, 4), want_traj=False) for r in range(4)]
+        keys = [ctx.argmin_key(p["best_cost"]) for p in parts]
+        gmin = np.minimum.reduce(keys)
+        masked = [ctx.argmin_mask(k, gmin, p["best_idx"]) for k, p in zip(keys, parts)]
+        bi = np.minimum.reduce([m[0] for m in masked])
+        np.testing.assert_array_equal(bi, full["best_idx"]); np.testing.assert_array_equal(masked[0][1], full["best_cost"])
+
+
+def test_exchange_kernels_follow_np_argmin_with_nan_inf_and_ties():
+    from f1tenth_planning_amd.runtime import Context
+    rng = np.random.default_rng(17)
+    W, E = 8, 4096
+    cost = rng.normal(0, 1, (W, E))
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1.0, 1.0, -1.0, 5e-324, -5e-324])
+    pick = rng.integers(0, 30, (W, E))
+    cost = np.where(pick < len(special), special[np.minimum(pick, len(special) - 1)], cost)
+    idx = (np.arange(W)[:, None] * 64 + rng.integers(0, 64, (W, E))).astype(np.int32)
+    with Context(0) as ctx:
+        keys = np.stack([ctx.argmin_key(cost[r]) for r in range(W)])
+        np.testing.assert_array_equal(keys, np.stack([cost_key(cost[r]) for r in range(W)]))      # device == host mirror
+        gmin = keys.min(axis=0)
+        res = [ctx.argmin_mask(keys[r], gmin, idx[r]) for r in range(W)]
+        got_i = np.minimum.reduce([m for m, _ in res]); got_c = res[0][1]
+        # 1-rank communicator: the collective path itself with NaN / inf costs (identity on one rank)
+        ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        d_c, d_i = ctx.to_device(cost[3]), ctx.to_device(idx[3])
+        ctx.comm_argmin_dev(d_c, d_i, E)
+        one_c = d_c.download(np.float64, (E,)); one_i = d_i.download(np.int32, (E,))
+    np.testing.assert_array_equal(one_i, idx[3])
+    assert np.array_equal(one_c, cost[3], equal_nan=True)
+    for e in range(E):                                        # np.argmin over all ranks' candidates in index order
+        order = np.argsort(idx[:, e], kind="stable")
+        j = order[int(np.argmin(cost[order, e]))]
+        assert got_i[e] == idx[j, e], e
+        assert (np.isnan(got_c[e]) and np.isnan(cost[j, e])) or got_c[e] == cost[j, e], e
+
+
+def test_multicontext_plan_batch_equals_single_context():
+    """SURVEY 8b threading: one process, one ctx per GPU, one host thread each.  Two contexts on device 0 stand in for two GPUs."""
+    from f1tenth_planning_amd.runtime import Context, MultiContext
+    n_dev = _abi.load_library().f1p_device_count()
+    devices = list(range(n_dev)) if n_dev >= 2 else [0, 0]
+    cfg = synth.bench_lattice_cfg(n_cand=64, n_stations=30)
+    with Context(0) as ctx, MultiContext(devices) as mc:
+        rl = _scene(ctx)
+        img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+        mc.set_waypoints(rl); mc.set_grid(img, 0.058, origin, 206)
+        for E in (1, 2, 301):                                # fewer egos than contexts, odd split
+            poses = synth.make_egos(rl, E, seed=90 + E)
+            one = ctx.lattice_plan(poses, cfg)
+            many = mc.lattice_plan(poses, cfg)
+            assert sorted(one) == sorted(many)
+            for k in one:
+                np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+        pp1 = ctx.pure_pursuit(poses[:, :3], 0.8); pp2 = mc.pure_pursuit(poses[:, :3], 0.8)
+        for k in pp1:
+            np.testing.assert_array_equal(pp1[k], pp2[k], err_msg=k)
+
+
+def test_planner_classes_accept_devices():
+    from f1tenth_planning_amd.planning.lattice_planner.lattice_planner import LatticePlanner
+    n_dev = _abi.load_library().f1p_device_count()
+    devices = list(range(n_dev)) if n_dev >= 2 else [0, 0]
+    rl = synth.make_raceline(seed=0)
+    poses = synth.make_egos(rl, 130, seed=5)
+    pl = LatticePlanner(waypoints=rl)
+    one = pl.plan_batch(poses)
+    many = pl.plan_batch(poses, devices=devices)
+    for k in one:
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_real_rccl_ranks(world):
+    if _abi.load_library().f1p_device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for shard in ("candidates", "egos"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shard", shard, "--steps", "5",
+                            "--warmup", "2", "--egos", "512", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        assert line["n_gpus"] == world
+        cs = line["candidate_sharded"]
+        assert cs["rccl_ranks"] == world and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
+        assert line["exchange_selftest"]["matches_np_argmin_on_every_rank"] is True and line["exchange_selftest"]["nan_costs"] > 0

@@ -4,6 +4,11 @@
     rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_X -o run -- python3 bench.py ...
     rocprofv3 --pmc FETCH_SIZE -f csv -d gpurun_out/pmc_fetch_X -o run -- python3 bench.py ...
     python tools/prof_summary.py gpurun_out/prof_X [gpurun_out/pmc_fetch_X ...] > profiles/rNN_name.md
+    python tools/prof_summary.py --json profiles/rNN_name_pmc.json --headline 'k_lattice<false, 0, false>' \
+           --config '{"egos": 4096, ...}' gpurun_out/prof_X gpurun_out/pmc_* > profiles/rNN_name.md
+
+--json writes the machine-readable file bench.py parses at run time (roofline.traffic, roofline.valu_fp64): per kernel the
+mean counter values per dispatch, the average duration, and `headline: true` on the kernel the timed step launches.
 
 Kernel-trace directories give per-kernel call count / average / min / max duration; PMC directories give per-kernel
 mean counter values per dispatch.  FETCH_SIZE / WRITE_SIZE are reported in the counter's own unit (KiB per the
@@ -50,10 +55,44 @@ def pmc(d):
     return agg
 
 
+def write_json(path, dirs, headline, config):
+    import json
+    kernels = {}
+    for d in dirs:
+        kt = kernel_trace(d)
+        if kt and not pmc(d):                      # durations from the plain trace only (PMC passes perturb them)
+            for name, v in kt[0].items():
+                kernels.setdefault(name, {})["avg_us"] = sum(v) / len(v)
+                kernels[name]["calls"] = len(v)
+        for name, cs in pmc(d).items():
+            for cname, v in cs.items():
+                key = {"FETCH_SIZE": "FETCH_SIZE_KiB", "WRITE_SIZE": "WRITE_SIZE_KiB", "SQ_WAVES": "waves"}.get(cname, cname)
+                kernels.setdefault(name, {})[key] = sum(v) / len(v)
+    out = {"config": config, "dirs": dirs,
+           "kernels": [dict(kernel=n, headline=bool(headline and headline in n), **v) for n, v in sorted(kernels.items())]}
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 def main():
+    import json
     dirs = sys.argv[1:]
+    jpath = headline = None
+    config = None
+    while dirs and dirs[0].startswith("--"):
+        opt = dirs.pop(0)
+        if opt == "--json":
+            jpath = dirs.pop(0)
+        elif opt == "--headline":
+            headline = dirs.pop(0)
+        elif opt == "--config":
+            config = json.loads(dirs.pop(0))
+        else:
+            raise SystemExit(f"unknown option {opt}")
     if not dirs:
         raise SystemExit(__doc__)
+    if jpath:
+        write_json(jpath, dirs, headline, config)
     print("# rocprofv3 summary\n")
     for d in dirs:
         kt = kernel_trace(d)
