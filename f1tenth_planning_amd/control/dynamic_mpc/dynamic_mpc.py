@@ -131,7 +131,9 @@ class STMPCPlanner:
         if st[3] <= c.V_KS:                                      # kinematic branch (:168-180)
             cfg = self._kin_cfg()
             x0 = np.array([[st[0], st[1], st[3], st[4]]])
-            ref = ctx.kmpc_ref(x0, c.TK, c.DTK, c.dlk)
+            # STMPCPlanner's own calc_ref_trajectory_kinematic (dynamic_mpc.py:236-276): same gathers as the dynamic one with
+            # (TK, DTK, dlk) and ITS yaw fix-up threshold of 5 (:273-274) -- not KMPCPlanner's 4.5 (kinematic_mpc.py:198-203)
+            ref = np.ascontiguousarray(ctx.stmpc_ref(x0, c.TK, c.DTK, c.dlk)[:, [0, 1, 3, 4]])
             out = ctx.kmpc_shoot(x0, ref, self._sample(c.TK, c.N_ROLLOUTS, c.SIGMA_ACCEL, c.SIGMA_STEER, c.MAX_ACCEL, c.MAX_STEER), cfg)
             self.oa, self.odelta_v = out["best_seq"][0, :, 0], out["best_seq"][0, :, 1]
         else:                                                    # dynamic branch (:181-191)

@@ -610,12 +610,15 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
                            double* best_cost, int32_t* status, int32_t* near_idx, double* best_traj,
                            double* all_cost, double* all_traj) {
     F1P_ENTER(ctx);
-    int rc = validate_lattice(ctx, cfg, E, goals == nullptr, E == 0 || (poses && steer && speed && best_idx));
+    int rc = validate_lattice(ctx, cfg, E, goals == nullptr, E == 0 || (poses && best_idx && ((cfg && cfg->cand_count > 0) || (steer && speed))));
     if (rc) return rc;
+    if (cfg->cand_count > 0 && (steer || speed || status || best_traj))
+        return set_error(ctx, F1P_EINVAL, "a candidate shard (cfg.cand_count > 0) only evaluates: it produces best_idx, best_cost and near_idx; "
+                                          "pass NULL for steer / speed / status / best_traj and emit the global winner with f1p_lattice_emit_dev");
     const size_t C = (size_t)cfg->n_lookahead * cfg->n_width, S = cfg->n_stations, e = E;
     Stage s(ctx);
     s.need(8 * 4 * e); s.need(8 * e * C * 3, goals); s.need(8 * e * S, prev_theta);
-    s.need(8 * e); s.need(8 * e); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
+    s.need(8 * e, steer); s.need(8 * e, speed); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
     s.need(8 * e * S * 4, best_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
     if ((rc = s.begin())) return rc;
     const double *d_poses, *d_goals, *d_prev;
@@ -653,6 +656,20 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
     F1P_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return F1P_OK;
+}
+
+int f1p_clothoid_sample_batch(f1p_ctx* ctx, const double* params, int32_t n, int32_t npts, double* rows) {
+    F1P_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!params || !rows))) return set_error(ctx, F1P_EINVAL, "bad params / rows / n");
+    if (npts < 1 || npts > 65536) return set_error(ctx, F1P_EINVAL, "npts must be in [1, 65536]");
+    Stage s(ctx);
+    s.need(8 * 3 * (size_t)n); s.need(8 * 4 * (size_t)n * npts);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_p;
+    if ((rc = s.in(params, (size_t)3 * n, &d_p))) return rc;
+    double* d_rows = s.out(rows, (size_t)4 * n * npts);
+    if ((rc = launch_clothoid_sample(ctx, d_p, n, npts, d_rows))) return rc;
+    return s.finish();
 }
 
 int f1p_clothoid_g1_batch(f1p_ctx* ctx, const double* goals, int32_t n, double* kappa0, double* dkappa, double* length, int32_t* ok) {

@@ -87,6 +87,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
                    int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
                    double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
                    int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj);
+int launch_clothoid_sample(f1p_ctx* ctx, const double* d_params, int n, int S, double* d_rows);
 int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok);
 
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,

@@ -222,6 +222,13 @@ class Context:
         self._check(self.lib.f1p_clothoid_g1_batch(self.h, _ptr(g), n, _ptr(k0), _ptr(dk), _ptr(L), _ptr(ok)))
         return k0, dk, L, ok.astype(bool)
 
+    def clothoid_sample(self, params, npts):
+        """params [n, 3] = (kappa0, dkappa, length) -> rows [n, npts, 4] (x, y, theta, |kappa|) in each clothoid's start frame"""
+        p = _f64(params, (-1, 3)); n = p.shape[0]
+        rows = np.empty((n, int(npts), 4))
+        self._check(self.lib.f1p_clothoid_sample_batch(self.h, _ptr(p), n, int(npts), _ptr(rows)))
+        return rows
+
     # ---- pure pursuit ------------------------------------------------------------------------------------
     def pure_pursuit(self, poses, lookahead, wheelbase=0.33, max_reacquire=20.0):
         poses = _f64(poses, (-1, 3)); E = poses.shape[0]
@@ -280,9 +287,12 @@ class Context:
                 out["best_traj"] = np.empty((E, S, 4))
         if want_all:
             out["all_cost"] = np.empty((E, Cn)); out["all_traj"] = np.empty((E, Cn, S, 4))
+        if cfg.cand_count > 0:            # a candidate shard only evaluates: (best_idx, best_cost, near_idx)
+            for k in ("steer", "speed", "status", "best_traj"):
+                out.pop(k, None)
         self._check(self.lib.f1p_lattice_plan_batch(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
-                                                    _ptr(out["steer"]), _ptr(out["speed"]), _ptr(out["best_idx"]),
-                                                    _ptr(out["best_cost"]), _ptr(out["status"]), _ptr(out["near_idx"]),
+                                                    _ptr(out.get("steer")), _ptr(out.get("speed")), _ptr(out["best_idx"]),
+                                                    _ptr(out["best_cost"]), _ptr(out.get("status")), _ptr(out["near_idx"]),
                                                     _ptr(out.get("best_traj")), _ptr(out.get("all_cost")),
                                                     _ptr(out.get("all_traj"))))
         return out

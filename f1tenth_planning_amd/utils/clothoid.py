@@ -1,9 +1,8 @@
 """Stand-in for the part of `pyclothoids.Clothoid` the reference uses (lattice_planner.py:196, utils/utils.py:289-293,
 planning/lattice_planner/test_pyclothoids.py:14-26): G1 Hermite fit and evaluation of one clothoid.
 
-The fit runs on the GPU (f1p_clothoid_g1_batch, csrc/k_lattice.hip g1_fit); `SampleXY` / `sample` go through the lattice
-kernel's station loop (f1p_lattice_plan_batch with a single host goal and all_traj), i.e. the very rows the planner
-evaluates.  The scalar accessors X(s), Y(s), ... are host numpy (composite Gauss-Legendre): they exist for drop-in
+The fit runs on the GPU (f1p_clothoid_g1_batch, csrc/k_lattice.hip g1_fit); `SampleXY` / `sample` hand the stored parameters (kappa0, dkappa, length)
+to the lattice kernel's station arithmetic (f1p_clothoid_sample_batch), i.e. the very rows the planner evaluates.  The scalar accessors X(s), Y(s), ... are host numpy (composite Gauss-Legendre): they exist for drop-in
 compatibility, not for speed.  pyclothoids itself is not installable here, so parity of the curve family is pinned by the
 known answers of tests/test_oracle_clothoid.py, not by the third-party binary.
 """
@@ -89,16 +88,13 @@ class Clothoid:
     def sample(self, npts, ctx=None):
         """[npts, 4] rows (x, y, theta, |kappa|) at equal arc-length steps, first row the start, last row the end -- the
         layout of the reference's sample_traj (utils/utils.py:286-295), produced by the planning kernel's station loop."""
-        from .. import _abi
         from .utils import _plain_context
-        if not 2 <= npts <= 1024:
-            raise ValueError("between 2 and 1024 samples")
+        if not 1 <= npts <= 65536:
+            raise ValueError("between 1 and 65536 samples")
         ctx = ctx or _plain_context()
-        lx, ly = self._xy_local(self.length)
-        goal = np.array([[[lx, ly, self.Theta(self.length) - self.theta0]]])          # end pose in the start frame
-        cfg = _abi.lattice_cfg(lookaheads=[1.0], widths=[0.0], n_stations=int(npts), check_collision=False)
-        out = ctx.lattice_plan(np.zeros((1, 4)), cfg, goals=goal, want_all=True)
-        rows = out["all_traj"][0, 0].copy()
+        # the stored parameters go straight to the station loop (f1p_clothoid_sample_batch): no re-fit from the end pose, so a
+        # directly constructed or multi-turn clothoid samples ITS curve
+        rows = ctx.clothoid_sample(np.array([[self.kappa0, self.dk, self.length]]), int(npts))[0]
         c, s = np.cos(self.theta0), np.sin(self.theta0)
         x, y = rows[:, 0].copy(), rows[:, 1].copy()
         rows[:, 0] = self.x0 + c * x - s * y

@@ -252,7 +252,9 @@ int f1p_lqr_batch(f1p_ctx* ctx, const double* states, double* err, int32_t E, do
  *                           cfg.lookahead x cfg.width along the ctx waypoints
  *   prev_theta [E][S]       optional heading column of the previous plan's winner (similarity cost);
  *                           NULL = no previous path (term = 0)
- * Outputs (any may be NULL except steer/speed/best_idx):
+ * Outputs (any may be NULL except steer/speed/best_idx; a candidate shard, cfg.cand_count > 0, only EVALUATES: it writes
+ * best_idx, best_cost and near_idx, and the host-pointer wrapper rejects steer / speed / status / best_traj with F1P_EINVAL --
+ * the global winner is emitted with f1p_lattice_emit_dev after the cross-rank argmin):
  *   steer, speed [E]; best_idx [E] (global candidate index, np.argmin first-minimum rule);
  *   best_cost [E]; status [E]; near_idx [E] (nearest raceline segment);
  *   best_traj [E][S][4] rows (x, y, theta, |kappa|) in the ego frame -- the third return value of plan();
@@ -279,6 +281,11 @@ int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
  * goals [n][3] -> kappa0 [n], dkappa [n], length [n], ok [n] (0 = Newton did not converge / degenerate). */
 int f1p_clothoid_g1_batch(f1p_ctx* ctx, const double* goals, int32_t n, double* kappa0, double* dkappa,
                           double* length, int32_t* ok);
+
+/* sample_traj (utils/utils.py:286-295) for n clothoids given by their parameters: params [n][3] = (kappa0, dkappa, length) in
+ * each clothoid's own start frame (start pose (0, 0, 0)) -> rows [n][npts][4] = (X(s_i), Y(s_i), Theta(s_i), |kappa(s_i)|) at
+ * s_i = i * length / max(npts - 1, 1), the arithmetic of the planner's station loop. */
+int f1p_clothoid_sample_batch(f1p_ctx* ctx, const double* params, int32_t n, int32_t npts, double* rows);
 
 /* ------------------------------------------------------------------------------------------------
  * Kinematic MPC by random shooting for E egos: R open-loop rollouts of

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from f1tenth_planning_amd._abi import KmpcCfg, LatticeCfg  # noqa: E402  (struct layouts of include/f1p.h)
 
 LIB = os.path.join(HERE, "liborc.so")
+ASAN_LIB = os.environ.get("F1P_ORACLE_LIB")     # the sanitizer build (make -C oracle asan), CPU test leg only
 
 
 def build(force=False):
@@ -37,8 +38,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(LIB)
+        if ASAN_LIB:
+            _lib = C.CDLL(os.path.abspath(ASAN_LIB))
+        else:
+            build()
+            _lib = C.CDLL(LIB)
         _lib.orc_pi_2_pi.restype = C.c_double
         _lib.orc_pi_2_pi.argtypes = [C.c_double]
         _lib.orc_kmpc_rollout_cost.restype = C.c_double

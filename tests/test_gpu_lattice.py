@@ -305,3 +305,47 @@ def test_clothoid_class_and_sample_traj_on_the_gpu(orc):
     assert len(xs) == 50 and abs(xs[-1] - 1.0) < 1e-9 and abs(ys[-1] - 1.0) < 1e-9
     with pytest.raises(ValueError):
         Clothoid.G1Hermite(0, 0, 0, 0, 0, 0.3)
+
+
+def test_directly_constructed_and_multi_turn_clothoid_samples_its_own_curve(orc):
+    """Clothoid.sample hands the stored (kappa0, dkappa, length) to the station loop (f1p_clothoid_sample_batch): a clothoid that
+    was not produced by a G1 fit -- here 2.5 turns of a spiral -- samples ITS curve, not a re-fit through its end pose."""
+    from f1tenth_planning_amd.utils.clothoid import Clothoid
+    cl = Clothoid(1.0, -2.0, 0.7, 0.4, 0.9, 5.5)                      # heading change 0.4*5.5 + 0.45*5.5^2 = 15.8 rad
+    rows = cl.sample(200)
+    want = orc.sample_traj(0.4, 0.9, 5.5, 200)
+    c, s = np.cos(0.7), np.sin(0.7)
+    np.testing.assert_allclose(rows[:, 0], 1.0 + c * want[:, 0] - s * want[:, 1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rows[:, 1], -2.0 + s * want[:, 0] + c * want[:, 1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rows[:, 2], 0.7 + want[:, 2], rtol=0, atol=1e-9)
+    assert abs(rows[-1, 0] - cl.X(5.5)) < 1e-9 and abs(rows[-1, 1] - cl.Y(5.5)) < 1e-9
+    assert cl.sample(1).shape == (1, 4)
+
+
+def test_candidate_shard_through_the_host_wrapper_only_evaluates(ctx, scene):
+    """a shard cfg through f1p_lattice_plan_batch used to return uninitialised steer / speed / best_traj"""
+    import ctypes as C
+    rl, img, origin = scene
+    sh = synth.bench_lattice_cfg(n_cand=64, n_stations=50); sh.cand_begin, sh.cand_count = 16, 16
+    poses = synth.make_egos(rl, 9, seed=3)
+    out = ctx.lattice_plan(poses, sh)
+    assert sorted(out) == ["best_cost", "best_idx", "near_idx"] and ((out["best_idx"] >= 16) & (out["best_idx"] < 32)).all()
+    steer = np.empty(9); speed = np.empty(9); bidx = np.empty(9, np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)   # noqa: E731
+    rc = ctx.lib.f1p_lattice_plan_batch(ctx.h, p(np.ascontiguousarray(poses)), None, None, 9, C.byref(sh), p(steer), p(speed), p(bidx),
+                                        None, None, None, None, None, None)
+    assert rc == _abi.F1P_EINVAL and b"only evaluates" in ctx.lib.f1p_last_error(ctx.h)
+
+
+def test_long_station_counts_fit_the_lds_or_fail_cleanly(ctx, orc, scene):
+    """the two-kernel branch and bound asks for 4 per-wave LDS blocks; at S ~ 1000 that exceeds the CU's LDS and the plan
+    must fall back to the single-kernel schedule instead of failing at launch -- with the same outputs as the exhaustive kernel"""
+    rl, img, origin = scene
+    poses = synth.make_egos(rl, 260, seed=12)                           # >= 256 egos: the two-kernel schedule is the default
+    for S in (400, 1000):
+        full = synth.bench_lattice_cfg(n_cand=32, n_stations=S)
+        bb = synth.bench_lattice_cfg(n_cand=32, n_stations=S, prune=True)
+        _same(ctx.lattice_plan(poses, full), ctx.lattice_plan(poses, bb))
+    one = ctx.lattice_plan(poses[:3], synth.bench_lattice_cfg(n_cand=32, n_stations=1000), want_all=True)      # materialised rows at S = 1000
+    want = orc.lattice_plan_batch(poses[:3], rl, synth.bench_lattice_cfg(n_cand=32, n_stations=1000), grid=(img, 0.058, origin[0], origin[1], 206))
+    np.testing.assert_array_equal(one["best_idx"], want["best_idx"])

@@ -28,6 +28,11 @@ def test_dynamic_model_golden(ctx, golden, tracks):
     ctx.set_waypoints(tracks["levine"], cols=(1, 2, 5, 3))
     ref = ctx.stmpc_ref(g["dyn_ref_state"], cfg.horizon)
     np.testing.assert_array_equal(ref, g["dyn_ref_out"])
+    # the kinematic branch of STMPCPlanner uses ITS OWN reference extraction (dynamic_mpc.py:236-276, threshold 5)
+    TK, DTK, dlk = int(g["kin_cfg"][0]), float(g["kin_cfg"][1]), float(g["kin_cfg"][2])
+    refk = ctx.stmpc_ref(g["kin_ref_state"], TK, DTK, dlk)[:, [0, 1, 3, 4]]
+    np.testing.assert_array_equal(refk, g["kin_ref_out"])
+    assert not np.array_equal(ctx.kmpc_ref(g["kin_ref_state"], TK, DTK, dlk), g["kin_ref_out"])     # KMPCPlanner's 4.5 differs here
 
 
 def test_stmpc_shoot_vs_oracle(ctx, orc):

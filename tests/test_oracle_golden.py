@@ -184,3 +184,12 @@ def test_dynamic_model_golden(orc, golden, tracks):
     for j in range(len(g["dyn_ref_state"])):
         ref = orc.calc_ref_trajectory_dynamic(g["dyn_ref_state"][j], lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5], cfg.horizon)
         np.testing.assert_array_equal(ref, g["dyn_ref_out"][j])
+    # STMPCPlanner's own calc_ref_trajectory_kinematic (dynamic_mpc.py:236-276): yaw fix-up threshold 5, not KMPCPlanner's 4.5
+    TK, DTK, dlk = int(g["kin_cfg"][0]), float(g["kin_cfg"][1]), float(g["kin_cfg"][2])
+    differs = 0
+    for j in range(len(g["kin_ref_state"])):
+        ref = orc.calc_ref_trajectory_dynamic(g["kin_ref_state"][j], lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5], TK, dt=DTK, dl=dlk)
+        np.testing.assert_array_equal(ref[[0, 1, 3, 4]], g["kin_ref_out"][j])
+        r45, _ = orc.calc_ref_trajectory(g["kin_ref_state"][j], lev[:, 1], lev[:, 2], lev[:, 3], lev[:, 5], TK, dt=DTK, dl=dlk)
+        differs += int(not np.array_equal(r45, g["kin_ref_out"][j]))
+    assert differs >= 2          # the fixture does separate the two thresholds

@@ -396,6 +396,17 @@ def main():
         s_ = D.State(x=rs[j, 0], y=rs[j, 1], v=rs[j, 2], yaw=rs[j, 3])
         refs7[j] = dp.calc_ref_trajectory(s_, cx, cy, cyaw.copy(), sp)
     g["dyn_ref_state"] = rs; g["dyn_ref_out"] = refs7
+    # STMPCPlanner's OWN calc_ref_trajectory_kinematic (dynamic_mpc.py:236-276): the yaw fix-up threshold is 5 there, not the
+    # 4.5 of KMPCPlanner (kinematic_mpc.py:198-203).  Rows 4.. put cyaw - yaw between the two thresholds, on both sides.
+    rk = rs.copy()
+    rk[4, 3] = lev[kk[4], 3] - 4.75; rk[5, 3] = lev[kk[5], 3] + 4.75; rk[6, 3] = lev[kk[6], 3] - 5.25; rk[7, 3] = lev[kk[7], 3] + 5.25
+    rk[:, 2] = rng.uniform(0.2, 2.0, m)                        # the kinematic branch runs below V_KS = 2 m/s
+    TKk = dp.config.TK
+    refsk = np.zeros((m, 4, TKk + 1))
+    for j in range(m):
+        s_ = D.State(x=rk[j, 0], y=rk[j, 1], v=rk[j, 2], yaw=rk[j, 3])
+        refsk[j] = dp.calc_ref_trajectory_kinematic(s_, cx, cy, cyaw.copy(), sp)
+    g["kin_ref_state"] = rk; g["kin_ref_out"] = refsk; g["kin_cfg"] = np.array([TKk, dp.config.DTK, dp.config.dlk])
     c7 = dp.config
     g["dyn_cfg"] = np.array([c7.T, c7.DT, c7.dl, c7.WB, c7.MAX_STEER, c7.MAX_STEER_V, c7.MAX_SPEED, c7.MIN_SPEED, c7.MAX_ACCEL, c7.V_KS])
     g["dyn_Q"] = np.asarray(c7.Q.diagonal()); g["dyn_Qf"] = np.asarray(c7.Qf.diagonal())
