@@ -349,3 +349,18 @@ def test_long_station_counts_fit_the_lds_or_fail_cleanly(ctx, orc, scene):
     one = ctx.lattice_plan(poses[:3], synth.bench_lattice_cfg(n_cand=32, n_stations=1000), want_all=True)      # materialised rows at S = 1000
     want = orc.lattice_plan_batch(poses[:3], rl, synth.bench_lattice_cfg(n_cand=32, n_stations=1000), grid=(img, 0.058, origin[0], origin[1], 206))
     np.testing.assert_array_equal(one["best_idx"], want["best_idx"])
+
+
+def test_g1_fit_branch_against_the_independent_solver(ctx, golden):
+    """f1p_clothoid_g1_batch (the kernel's g1_fit) against tools/gen_clothoid_g14.py's fixture: 1704 goals incl. goals behind the
+    ego, |theta| up to pi and the normalisation seams; kappa0, kappa', L to 1e-9 relative, agreed failure set."""
+    g = golden("g14_clothoid_g1.npz")
+    G = g["goals"]
+    k0, dk, L, ok = ctx.clothoid_g1(G)
+    np.testing.assert_array_equal(ok.astype(np.int32), g["ok"])
+    sel = (g["ok"] == 1) & (g["ambiguous"] == 0)
+    for name, got in (("k0", k0), ("dk", dk), ("L", L)):
+        scale = np.maximum(1.0, np.abs(g[name][sel]))
+        assert (np.abs(got[sel] - g[name][sel]) / scale).max() < 1e-9, name
+    for i in np.nonzero(g["ambiguous"])[0]:
+        assert abs(L[i] - g["L"][i]) < 1e-9 and abs(abs(k0[i]) - abs(g["k0"][i])) < 1e-9

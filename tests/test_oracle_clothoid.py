@@ -94,3 +94,29 @@ def test_sample_traj_rows(orc):
 def test_degenerate_goal(orc):
     ok, *_ = orc.clothoid_g1(0.0, 0.0, 0.3)
     assert not ok
+
+
+def test_branch_pinned_by_the_independent_solver(orc):
+    """Row a7's branch, pinned without pyclothoids: tests/golden/g14_clothoid_g1.npz comes from tools/gen_clothoid_g14.py, a solver
+    that shares nothing with the oracle (Fresnel closed forms + QUADPACK + brentq over ALL roots on [-60, 60], selection = the
+    positive-length root of minimum |A|, i.e. Bertolazzi & Frego's principal branch).  1704 goals over x in [-1, 4], y in [-3, 3],
+    theta in (-pi, pi] incl. goals behind the ego and the seams phi0, phi1 -> +-pi.  The oracle (published initial guess +
+    Newton, what pyclothoids runs) must land on that root every time: kappa0, kappa', L to 1e-9, and the same failure set."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g14_clothoid_g1.npz"))
+    G = g["goals"]
+    res = np.array([orc.clothoid_g1(*G[i]) for i in range(len(G))], dtype=np.float64)
+    np.testing.assert_array_equal(res[:, 0].astype(np.int32), g["ok"])                  # agreed failure set (the two degenerate goals)
+    assert g["ok"].sum() == len(G) - 2 and g["n_roots"][g["ok"] == 1].min() >= 4          # a choice is really being made
+    sel = (g["ok"] == 1) & (g["ambiguous"] == 0)
+    assert sel.sum() >= 1690 and (G[sel, 0] < 0).sum() > 250 and (np.abs(G[sel, 2]) > 1.3).sum() > 700
+    for name, col in (("k0", 1), ("dk", 2), ("L", 3)):
+        scale = np.maximum(1.0, np.abs(g[name][sel]))
+        assert (np.abs(res[sel, col] - g[name][sel]) / scale).max() < 1e-9, name
+    # the straight-behind corner phi0 = phi1 = -pi has two mirror-image solutions of equal |A|: same length, opposite curvatures
+    amb = np.nonzero(g["ambiguous"])[0]
+    assert len(amb) == 2
+    for i in amb:
+        assert abs(res[i, 3] - g["L"][i]) < 1e-9 and abs(abs(res[i, 1]) - abs(g["k0"][i])) < 1e-9 and abs(abs(res[i, 2]) - abs(g["dk"][i])) < 1e-8
+    # "shortest curve" is a different (discontinuous) criterion on ~2 % of these goals: recorded, not pinned
+    assert 0 < (g["shortest_is_min_abs_a"][sel] == 0).sum() < 60
