@@ -1,0 +1,68 @@
+"""oracle/numpy_lattice.py -- the numpy-vectorised, single-core CPU baseline north_star asks for -- pinned to the reference's
+golden vectors for its leaf functions and to the C oracle for the whole plan (indices identical, floats to 1e-9)."""
+import numpy as np
+
+from f1tenth_planning_amd import synth
+from oracle import numpy_lattice as nl
+
+
+def test_nearest_and_intersect_match_the_reference_golden_vectors(golden, tracks):
+    g = golden("g1_g2_nearest_intersect.npz")
+    for name, cols in (("spielberg", (0, 1)), ("levine", (1, 2))):
+        wp = tracks[name][:, list(cols)]
+        wx, wy = np.ascontiguousarray(wp[:, 0]), np.ascontiguousarray(wp[:, 1])
+        pts = g[f"{name}_pts"]
+        proj, dist, t, idx = nl.nearest_point_batch(pts, wx, wy)
+        np.testing.assert_array_equal(idx, g[f"{name}_idx"])                       # bit-exact indices
+        np.testing.assert_array_equal(dist, g[f"{name}_dist"]); np.testing.assert_array_equal(t, g[f"{name}_t"])
+        np.testing.assert_array_equal(proj, g[f"{name}_proj"])
+        sel = g[f"{name}_int_sel"]; radii = g[f"{name}_int_radii"]
+        for b, r in enumerate(radii):
+            for c, wrap in enumerate((False, True)):
+                found, i2, t2 = nl.intersect_first_batch(pts[sel, 0].copy(), pts[sel, 1].copy(), np.full(len(sel), r), wx, wy,
+                                                         (g[f"{name}_idx"] + g[f"{name}_t"])[sel], wrap)
+                gi = g[f"{name}_int_i"][:, b, c]
+                np.testing.assert_array_equal(found, gi != -9999)
+                np.testing.assert_array_equal(i2[found], gi[found])
+                np.testing.assert_array_equal(t2[found], g[f"{name}_int_t"][:, b, c][found])
+        starts = g[f"{name}_int2_starts"]; n2 = g[f"{name}_int2_i"].shape[0]      # long scans, wrap, start past the end
+        for b, st in enumerate(starts):
+            found, i2, _ = nl.intersect_first_batch(pts[:n2, 0].copy(), pts[:n2, 1].copy(), np.full(n2, 0.8), wx, wy, np.full(n2, float(st)), True)
+            gi = g[f"{name}_int2_i"][:, b]
+            np.testing.assert_array_equal(found, gi != -9999); np.testing.assert_array_equal(i2[found], gi[found])
+        q = g[f"{name}_int3_pts"]                                                 # closing segment: first_i == -1
+        found, i2, _ = nl.intersect_first_batch(q[:, 0].copy(), q[:, 1].copy(), np.full(len(q), 0.8), wx, wy, np.full(len(q), len(wp) - 1.0), True)
+        gi = g[f"{name}_int3_i"]
+        np.testing.assert_array_equal(found, gi != -9999); np.testing.assert_array_equal(i2[found], gi[found])
+        assert (gi == -1).any()
+
+
+def test_numpy_plan_equals_the_c_oracle(orc):
+    rl = synth.make_raceline(seed=0)
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+    grid = (img, 0.058, origin[0], origin[1], 206)
+    for n_cand, S, seed, sigma in ((256, 50, 1, 0.3), (64, 30, 5, 0.9)):           # the second scene: many collisions / blocked egos
+        cfg = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=S)
+        poses = synth.make_egos(rl, 40, seed=seed, pos_sigma=sigma)
+        poses[0, :2] += 400.0                                                      # off the map: no look-ahead centres
+        poses[1, 2] += np.pi                                                       # facing backwards
+        a = nl.lattice_plan_batch(poses, rl, cfg, grid=grid)
+        b = orc.lattice_plan_batch(poses, rl, cfg, grid=grid, nthreads=4)
+        for k in ("near_idx", "best_idx", "status"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        fin = np.isfinite(b["best_cost"])
+        np.testing.assert_array_equal(np.isfinite(a["best_cost"]), fin)
+        assert np.abs(a["best_cost"][fin] - b["best_cost"][fin]).max() < 1e-12
+        assert np.abs(a["steer"] - b["steer"]).max() < 1e-9 and np.abs(a["speed"] - b["speed"]).max() < 1e-12
+        assert np.abs(a["best_traj"][fin] - b["best_traj"][fin]).max() < 1e-9
+        assert (b["status"] == 3).any()
+
+
+def test_numpy_clothoid_fit_matches_the_independent_solver(golden):
+    g = golden("g14_clothoid_g1.npz")
+    G = g["goals"]
+    ok, k0, dk, L = nl.clothoid_g1_batch(G[:, 0].copy(), G[:, 1].copy(), G[:, 2].copy())
+    np.testing.assert_array_equal(ok.astype(np.int32), g["ok"])
+    sel = (g["ok"] == 1) & (g["ambiguous"] == 0)
+    for name, got in (("k0", k0), ("dk", dk), ("L", L)):
+        assert (np.abs(got[sel] - g[name][sel]) / np.maximum(1.0, np.abs(g[name][sel]))).max() < 1e-9, name
