@@ -47,6 +47,18 @@ class KmpcCfg(C.Structure):
     ]
 
 
+class KmpcSampler(C.Structure):
+    """struct f1p_kmpc_sampler (include/f1p.h)"""
+    _fields_ = [("seed", C.c_uint64), ("call", C.c_uint32), ("use_warm", C.c_int32), ("sigma_accel", C.c_double), ("sigma_steer", C.c_double)]
+
+
+def kmpc_sampler(seed=0, call=0, use_warm=True, sigma_accel=1.5, sigma_steer=0.15):
+    s = KmpcSampler()
+    s.seed, s.call, s.use_warm = int(seed) & (2 ** 64 - 1), int(call) & 0xffffffff, 1 if use_warm else 0
+    s.sigma_accel, s.sigma_steer = float(sigma_accel), float(sigma_steer)
+    return s
+
+
 class StmpcCfg(C.Structure):
     """struct f1p_stmpc_cfg (include/f1p.h)"""
     _fields_ = [
@@ -179,6 +191,13 @@ PROTOTYPES = {
     "f1p_kmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(KmpcCfg), _P]),
     "f1p_kmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),
     "f1p_kmpc_sample_controls_dev": (C.c_int, [_P, _P, _I, C.POINTER(KmpcCfg), C.c_uint64, _D, _D]),
+    "f1p_kmpc_plan_batch": (C.c_int, [_P, _P, _I, C.POINTER(KmpcCfg), _D, C.POINTER(KmpcSampler), _P, _P, _P, _P, _P]),
+    "f1p_kmpc_plan_dev": (C.c_int, [_P, _P, _P, _I, C.POINTER(KmpcCfg), C.POINTER(KmpcSampler), _P, _P, _P, _P, _P]),
+    "f1p_kmpc_gen_controls_dev": (C.c_int, [_P, _P, _I, C.POINTER(KmpcCfg), C.POINTER(KmpcSampler)]),
+    "f1p_kmpc_warm_reset": (C.c_int, [_P]),
+    "f1p_kmpc_warm_get": (C.c_int, [_P, _P, _I, _I]),
+    "f1p_kmpc_warm_set": (C.c_int, [_P, _P, _I, _I]),
+    "f1p_kmpc_set_groups": (C.c_int, [_P, _I]),
     "f1p_stmpc_cfg_default": (None, [C.POINTER(StmpcCfg)]),
     "f1p_stmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P]),
     "f1p_stmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),

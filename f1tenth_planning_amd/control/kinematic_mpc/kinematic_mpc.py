@@ -6,7 +6,8 @@ examples/control/kinematic_mpc.py drives it unchanged.  What differs is the solv
 model and solves a QP with cvxpy/OSQP (:283-450, third-party, out of scope); here R candidate control sequences are
 rolled out through the reference's own nonlinear step (update_state_kinematic :223-243) on the GPU
 (csrc/k_kmpc.hip), scored with the reference's objective (:324-334) and bounds (:391-401), and the best one is
-applied (:506-508).  The reference trajectory extraction (calc_ref_trajectory_kinematic :162-206) also runs on the
+applied (:506-508).  The candidates are generated inside the kernel (counter-based Philox4x32-10, include/f1p.h
+f1p_kmpc_sampler) around a warm start that stays on the device; a plan uploads 32 bytes per vehicle.  The reference trajectory extraction (calc_ref_trajectory_kinematic :162-206) also runs on the
 GPU.
 """
 import os
@@ -107,23 +108,11 @@ class KMPCPlanner:
         ctx.set_waypoints_cached(np.column_stack([cx, cy, sp, cyaw]), cols=(0, 1, 2, 3))
         return ctx
 
-    def _controls(self, E, cfg, warm):
-        """Candidate sequences [E, T, 2, R] f32: Gaussian perturbations around the warm start (previous solution shifted
-        by one step, :491-498); rollout 0 is the unperturbed warm start, rollout 1 is all-zero."""
+    def _sampler(self):
         c = self.config
-        T, R = cfg.horizon, cfg.n_rollouts
-        rng = np.random.default_rng([c.SEED, self._calls])
-        ctrl = np.empty((E, T, 2, R), dtype=np.float32)
-        ctrl[:, :, 0, :] = rng.normal(0.0, c.SIGMA_ACCEL, (E, T, R))
-        ctrl[:, :, 1, :] = rng.normal(0.0, c.SIGMA_STEER, (E, T, R))
-        ctrl[:, :, :, 0] = 0.0
-        if warm is not None:
-            ctrl += warm[:, :, :, None].astype(np.float32)
-        if R > 1:
-            ctrl[:, :, :, 1] = 0.0
-        ctrl[:, :, 0, :] = np.clip(ctrl[:, :, 0, :], -c.MAX_ACCEL, c.MAX_ACCEL)
-        ctrl[:, :, 1, :] = np.clip(ctrl[:, :, 1, :], -c.MAX_STEER, c.MAX_STEER)
-        return ctrl
+        smp = _abi.kmpc_sampler(seed=c.SEED, call=self._calls, use_warm=True, sigma_accel=c.SIGMA_ACCEL, sigma_steer=c.SIGMA_STEER)
+        self._calls += 1
+        return smp
 
     def plan(self, states, waypoints=None):
         """
@@ -135,30 +124,32 @@ class KMPCPlanner:
                               beta=states[6])
         x0 = np.array([[vehicle_state.x, vehicle_state.y, vehicle_state.v, vehicle_state.yaw]], dtype=np.float64)   # :487
         out = self._shoot(ctx, x0)
-        self.oa = out["best_seq"][0, :, 0]
+        self.oa = out["best_seq"][0, :, 0]                 # the reference's attributes (:108-110); the warm start itself lives on the device
         self.odelta_v = out["best_seq"][0, :, 1]
         return float(out["steer"][0]), float(out["speed"][0])
 
-    def _shoot(self, ctx, x0):
+    def _shoot(self, ctx, x0, want_seq=True):
+        """One C call per plan (f1p_kmpc_plan_batch): reference extraction (:162-206), R candidate sequences generated IN THE
+        KERNEL around the context's device-resident warm start (previous solution shifted by one step, :491-498; rollout 0 is the
+        unperturbed warm start, rollout 1 all zero), rollouts, argmin, output map, new warm start.  Up: 32 B per ego.  Down: the
+        winners.  The warm start belongs to (context, batch size): switching between plan() and plan_batch() sizes restarts it."""
         c = self.config
-        cfg = _cfg_struct(c)
-        ref = ctx.kmpc_ref(x0, c.TK, c.DTK, c.dlk)
-        warm = None
-        if self.oa is not None and x0.shape[0] == 1:
-            warm = np.zeros((1, c.TK, 2))
-            warm[0, :-1, 0] = self.oa[1:]; warm[0, -1, 0] = self.oa[-1]
-            warm[0, :-1, 1] = self.odelta_v[1:]; warm[0, -1, 1] = self.odelta_v[-1]
-        ctrl = self._controls(x0.shape[0], cfg, warm)
-        self._calls += 1
-        return ctx.kmpc_shoot(x0, ref, ctrl, cfg)
+        return ctx.kmpc_plan(x0, _cfg_struct(c), self._sampler(), dl=c.dlk, want_seq=want_seq)
 
-    def plan_batch(self, x0, waypoints=None, controls=None):
-        """x0 [E, 4] = (x, y, v, yaw) -> dict(steer, speed, best_idx, best_cost, best_seq).  `controls`
-        (f32 [E, T, 2, R]) overrides the internal sampler."""
+    def reset(self):
+        """forget the warm start and restart the sampler's call counter (a new episode)"""
+        self._calls = 0
+        self.oa = self.odelta_v = None
+        if self._ctx is not None:
+            self._ctx.kmpc_warm_reset()
+
+    def plan_batch(self, x0, waypoints=None, controls=None, want_seq=True):
+        """x0 [E, 4] = (x, y, v, yaw) -> dict(steer, speed, best_idx, best_cost[, best_seq]).  `controls`
+        (f32 [E, T, 2, R]) overrides the in-kernel sampler with a caller-supplied candidate set (streamed from HBM)."""
         ctx = self._bind(waypoints)
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, 4)
         if controls is None:
-            return self._shoot(ctx, x0)
+            return self._shoot(ctx, x0, want_seq=want_seq)
         c = self.config
         cfg = _cfg_struct(c, n_rollouts=controls.shape[3])
         ref = ctx.kmpc_ref(x0, c.TK, c.DTK, c.dlk)

@@ -249,7 +249,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -770,6 +770,108 @@ int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, con
 static std::string rccl_err(f1p_ctx* ctx, const char* what, ncclResult_t r) {
     auto es = rccl_sym<pfn_ncclGetErrorString>(ctx, "ncclGetErrorString");
     return std::string(what) + " failed: " + (es ? es(r) : "?") + " (code " + std::to_string((int)r) + ")";
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shooting MPC with in-kernel control generation and a device-resident warm start
+// ---------------------------------------------------------------------------------------------------
+static int validate_sampler(f1p_ctx* ctx, const f1p_kmpc_sampler* smp) {
+    if (!smp) return set_error(ctx, F1P_EINVAL, "sampler is NULL");
+    if (!(smp->sigma_accel >= 0.0) || !(smp->sigma_steer >= 0.0) || !isfinite(smp->sigma_accel) || !isfinite(smp->sigma_steer))
+        return set_error(ctx, F1P_EINVAL, "sampler sigmas must be finite and >= 0");
+    return F1P_OK;
+}
+
+// the ctx's warm buffer for (E, T); a change of shape drops the old contents
+static int ensure_warm(f1p_ctx* ctx, int E, int T) {
+    if (ctx->d_kmpc_warm && ctx->kmpc_warm_E == E && ctx->kmpc_warm_T == T) return F1P_OK;
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_kmpc_warm) (void)hipFree(ctx->d_kmpc_warm);
+    ctx->d_kmpc_warm = nullptr; ctx->kmpc_warm_valid = false; ctx->kmpc_warm_E = ctx->kmpc_warm_T = 0;
+    F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_warm, sizeof(float) * 2 * (size_t)E * T));
+    ctx->kmpc_warm_E = E; ctx->kmpc_warm_T = T;
+    return F1P_OK;
+}
+
+int f1p_kmpc_plan_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, int32_t E, const f1p_kmpc_cfg* cfg,
+                      const f1p_kmpc_sampler* smp, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                      double* d_best_cost, double* d_best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if ((rc = validate_sampler(ctx, smp))) return rc;
+    if (E == 0) return F1P_OK;
+    if (!d_x0 || !d_ref || !d_steer || !d_speed || !d_best_idx) return set_error(ctx, F1P_EINVAL, "x0, ref, steer, speed and best_idx are required");
+    if (cfg->n_rollouts > 8192) return set_error(ctx, F1P_EINVAL, "at most 8192 rollouts per plan");
+    if ((rc = ensure_warm(ctx, E, cfg->horizon))) return rc;
+    const float* warm_in = (smp->use_warm && ctx->kmpc_warm_valid) ? ctx->d_kmpc_warm : nullptr;
+    rc = launch_kmpc_plan_gen(ctx, d_x0, d_ref, E, cfg, smp, warm_in, ctx->d_kmpc_warm, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
+    if (rc == F1P_OK) ctx->kmpc_warm_valid = true;
+    return rc;
+}
+
+int f1p_kmpc_plan_batch(f1p_ctx* ctx, const double* x0, int32_t E, const f1p_kmpc_cfg* cfg, double dl,
+                        const f1p_kmpc_sampler* smp, double* steer, double* speed, int32_t* best_idx, double* best_cost,
+                        double* best_seq) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if ((rc = validate_sampler(ctx, smp))) return rc;
+    if (E > 0 && (!x0 || !steer || !speed || !best_idx)) return set_error(ctx, F1P_EINVAL, "x0, steer, speed and best_idx are required");
+    if (!(dl > 0)) return set_error(ctx, F1P_EINVAL, "dl must be > 0");
+    if (ctx->n_wp < 2 || !ctx->has_psi) return set_error(ctx, F1P_ESTATE, "waypoints with a heading column are required");
+    const size_t T = cfg->horizon, e = E;
+    Stage s(ctx);
+    s.need(8 * 4 * e); s.need(8 * e * 4 * (T + 1));
+    s.need(8 * e); s.need(8 * e); s.need(4 * e); s.need(8 * e, best_cost); s.need(8 * e * T * 2, best_seq);
+    if ((rc = s.begin())) return rc;
+    const double* d_x0;
+    if ((rc = s.in(x0, 4 * e, &d_x0))) return rc;
+    double* d_ref = (double*)arena_take(ctx, 8 * e * 4 * (T + 1));
+    double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
+    double* d_bc = s.out(best_cost, e); double* d_bs = s.out(best_seq, e * T * 2);
+    if ((rc = launch_kmpc_ref(ctx, d_x0, E, cfg->horizon, cfg->dt, dl, d_ref))) return rc;            // calc_ref_trajectory_kinematic :162-206
+    if ((rc = f1p_kmpc_plan_dev(ctx, d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, d_bc, d_bs))) return rc;
+    return s.finish();
+}
+
+int f1p_kmpc_gen_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const f1p_kmpc_cfg* cfg, const f1p_kmpc_sampler* smp) {
+    F1P_ENTER(ctx);
+    int rc = validate_kmpc(ctx, cfg, E); if (rc) return rc;
+    if ((rc = validate_sampler(ctx, smp))) return rc;
+    if (E > 0 && !d_controls) return set_error(ctx, F1P_EINVAL, "controls is NULL");
+    const bool warm = smp->use_warm && ctx->kmpc_warm_valid && ctx->kmpc_warm_E == E && ctx->kmpc_warm_T == cfg->horizon;
+    return launch_kmpc_gen_controls(ctx, d_controls, E, cfg, smp, warm ? ctx->d_kmpc_warm : nullptr);
+}
+
+int f1p_kmpc_warm_reset(f1p_ctx* ctx) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->kmpc_warm_valid = false;
+    return F1P_OK;
+}
+
+int f1p_kmpc_warm_get(f1p_ctx* ctx, float* warm, int32_t E, int32_t T) {
+    F1P_ENTER(ctx);
+    if (!warm) return set_error(ctx, F1P_EINVAL, "warm is NULL");
+    if (!ctx->kmpc_warm_valid || ctx->kmpc_warm_E != E || ctx->kmpc_warm_T != T) return set_error(ctx, F1P_ESTATE, "no warm start of this shape is held");
+    F1P_HIP(ctx, hipMemcpyAsync(warm, ctx->d_kmpc_warm, sizeof(float) * 2 * (size_t)E * T, hipMemcpyDeviceToHost, ctx->stream));
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F1P_OK;
+}
+
+int f1p_kmpc_warm_set(f1p_ctx* ctx, const float* warm, int32_t E, int32_t T) {
+    F1P_ENTER(ctx);
+    if (!warm || E < 1 || T < 1) return set_error(ctx, F1P_EINVAL, "bad warm / E / T");
+    int rc = ensure_warm(ctx, E, T); if (rc) return rc;
+    F1P_HIP(ctx, hipMemcpyAsync(ctx->d_kmpc_warm, warm, sizeof(float) * 2 * (size_t)E * T, hipMemcpyHostToDevice, ctx->stream));
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->kmpc_warm_valid = true;
+    return F1P_OK;
+}
+
+int f1p_kmpc_set_groups(f1p_ctx* ctx, int32_t groups) {
+    if (!ctx) return F1P_EINVAL;
+    if (groups < 0 || groups > 64) return set_error(ctx, F1P_EINVAL, "groups must be in [0, 64]");
+    ctx->kmpc_groups = groups;
+    return F1P_OK;
 }
 
 int f1p_comm_unique_id(f1p_ctx* ctx, uint8_t id[F1P_COMM_ID_BYTES]) {

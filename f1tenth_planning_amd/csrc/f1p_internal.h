@@ -42,6 +42,15 @@ struct f1p_ctx {
     float* d_dbg_cost32 = nullptr;     // [E][R] filter costs of the next launch (test hook), or null
     int32_t* d_dbg_nref = nullptr;     // [E] size of the refined set (-1 = fp64 fallback), or null
 
+    // in-kernel control generation of the shooting MPC (f1p_kmpc_plan_*): the warm start lives here, on the device
+    float* d_kmpc_warm = nullptr;      // [E][T][2] f32: previous plan's applied winner shifted by one step
+    int kmpc_warm_E = 0, kmpc_warm_T = 0;
+    bool kmpc_warm_valid = false;
+    char* d_kmpc_scratch = nullptr;    // split-rollout mode: per-ego tickets + [E][R] filter costs
+    size_t kmpc_scratch_bytes = 0;
+    int kmpc_tickets_E = 0;
+    int kmpc_groups = 0;               // 0 = automatic number of workgroups per ego; > 0 forces it (tests, A/B runs)
+
     // two-kernel branch and bound of the lattice planner: bounds and clothoids handed from the fit kernel to the evaluation kernel
     char* d_bb_scratch = nullptr;
     size_t bb_scratch_bytes = 0;
@@ -93,6 +102,11 @@ int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0,
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                       double* d_best_cost, double* d_best_seq);
+int launch_kmpc_plan_gen(f1p_ctx* ctx, const double* d_x0, const double* d_ref, int E, const f1p_kmpc_cfg* cfg,
+                         const f1p_kmpc_sampler* smp, const float* d_warm_in, float* d_warm_out, double* d_steer, double* d_speed,
+                         int32_t* d_best_idx, double* d_best_cost, double* d_best_seq);
+int launch_kmpc_gen_controls(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, const f1p_kmpc_sampler* smp, const float* d_warm);
+int kmpc_plan_groups(const f1p_ctx* ctx, int E, int R);
 int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, const double* d_od, int E,
                         const f1p_kmpc_cfg* cfg, double* d_path);
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref);

@@ -48,17 +48,76 @@ __device__ __forceinline__ void kmpc_step(KmpcStep& s, double a, double delta, c
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
 
+// ---------------------------------------------------------------------------------------------------
+// Where a rollout's controls come from.
+//   SrcStream: the f32 buffer [t][accel|steer][rollout] of one ego in HBM (f1p_kmpc_shoot_*: parity tests, BASELINE configs[4]);
+//   SrcGen   : generated in registers from (seed, call, ego, rollout, t) around the ego's warm start (f1p_kmpc_plan_*): nothing
+//              per-rollout ever exists in memory.  Every consumer -- the f32 filter, the fp64 refinement, the winner's
+//              re-emission -- calls the same pure function, so they all see the same controls.
+// Generator: Philox4x32-10 (Salmon et al., SC'11; counter = (t, rollout, ego, call), key = seed) -> 128 bits per
+// (rollout, step); each control is a standardised Irwin-Hall sum of 8 of those bytes (v_sad_u8: integer, hence bit-identical
+// to the CPU restatement oracle/f1p_oracle.c orc_kmpc_gen_controls -- no transcendental whose last bit differs between
+// libraries), a bounded near-normal variate (+-4.9 sigma, excess kurtosis -0.15):
+//     z = (sum of 8 bytes - 1020) * (1 / 209.0215...);  accel = fma(sigma_a, z, warm_a[t]);  steer = fma(sigma_d, z', warm_d[t])
+// Rollout 0 is the unperturbed warm start (previous solution shifted by one step, kinematic_mpc.py:491-498), rollout 1 is all
+// zero.  The bounds (:391-401) are applied by the rollout's projection, exactly as for streamed controls.
+// ---------------------------------------------------------------------------------------------------
+struct SrcStream {
+    const float* __restrict__ ce;
+    int R;
+    __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
+        a = ce[((size_t)t * 2 + 0) * R + r];
+        d = ce[((size_t)t * 2 + 1) * R + r];
+    }
+};
+
+#define F1P_IH_MEAN 1020.0f                    // 8 bytes x 127.5
+#define F1P_IH_INV_STD 0.0047842013f           // 1 / sqrt(8 (256^2 - 1) / 12) = 1 / 209.02153, rounded to f32 (same literal in the oracle)
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+struct SrcGen {
+    uint32_t k0, k1, call, ego;
+    float sig_a, sig_d;
+    const float* warm;          // [T][2] (accel, steer) of this ego, LDS or global; nullptr = no warm start (zeros)
+    __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
+        uint32_t x0, x1, x2, x3;
+        philox4x32_10((uint32_t)t, (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
+        const uint32_t sa = __builtin_amdgcn_sad_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0u));   // sum of the 8 bytes of (x0, x1)
+        const uint32_t sd = __builtin_amdgcn_sad_u8(x3, 0u, __builtin_amdgcn_sad_u8(x2, 0u, 0u));
+        const float za = ((float)(int)sa - F1P_IH_MEAN) * F1P_IH_INV_STD;
+        const float zd = ((float)(int)sd - F1P_IH_MEAN) * F1P_IH_INV_STD;
+        const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
+        a = __builtin_fmaf(sig_a, za, wa);
+        d = __builtin_fmaf(sig_d, zd, wd);
+        if (r == 0) { a = wa; d = wd; }
+        else if (r == 1) { a = 0.0f; d = 0.0f; }
+    }
+};
+
 // fp64 cost of ONE rollout r: running sum in the reference's accumulation order
-template <bool FAST>
-__device__ __forceinline__ double kmpc_rollout_cost(const float* __restrict__ ce, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
+template <bool FAST, typename Src>
+__device__ __forceinline__ double kmpc_rollout_cost(const Src& src, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
                                                     double sy, double sv, double syaw, double dmax, int r) {
-    const int T = cfg.horizon, R = cfg.n_rollouts;
+    const int T = cfg.horizon;
     KmpcStep s;
     s.x = sx; s.y = sy; s.v = sv; s.yaw = syaw;
     double cost = 0.0, pa = 0.0, pd = 0.0;
     for (int t = 0; t < T; ++t) {
-        double a = (double)ce[((size_t)t * 2 + 0) * R + r];
-        double d = (double)ce[((size_t)t * 2 + 1) * R + r];
+        float af, df;
+        src.get(t, r, af, df);
+        double a = (double)af;
+        double d = (double)df;
         a = clampd(a, -cfg.max_accel, cfg.max_accel);             // |a| <= MAX_ACCEL          :400
         d = clampd(d, -cfg.max_steer, cfg.max_steer);             // |delta| <= MAX_STEER      :401
         if (t > 0) d = clampd(d, pd - dmax, pd + dmax);           // |d delta| <= MAX_DSTEER*DTK :391-394
@@ -80,11 +139,11 @@ __device__ __forceinline__ double kmpc_rollout_cost(const float* __restrict__ ce
 }
 
 // all rollouts of this thread, first-minimum argmin
-template <bool FAST>
-__device__ __forceinline__ void kmpc_rollouts(const float* __restrict__ ce, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
+template <bool FAST, typename Src>
+__device__ __forceinline__ void kmpc_rollouts(const Src& src, const double* sref, const f1p_kmpc_cfg& cfg, double sx,
                                               double sy, double sv, double syaw, double dmax, int tid, double& bc, int& bi) {
     for (int r = tid; r < cfg.n_rollouts; r += blockDim.x) {
-        const double cost = kmpc_rollout_cost<FAST>(ce, sref, cfg, sx, sy, sv, syaw, dmax, r);
+        const double cost = kmpc_rollout_cost<FAST>(src, sref, cfg, sx, sy, sv, syaw, dmax, r);
         if (argmin_better(cost, r, bc, bi)) { bc = cost; bi = r; }
     }
 }
@@ -118,14 +177,17 @@ __device__ __forceinline__ f1p_f2 med3x2(f1p_f2 x, float lo, float hi) {
 }
 struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd; };
 
-__device__ __forceinline__ void kmpc_load_chunk2(const float* __restrict__ ce, int T, int R, int r0, int r1, int t0,
+template <typename Src>
+__device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, int r1, int t0,
                                                  f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
 #pragma unroll
     for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
         const int t = t0 + j < T ? t0 + j : T - 1;                     // clamp: the tail re-reads the last step (unused)
-        const float* row = ce + (size_t)t * 2 * R;
-        av[j].x = row[r0]; av[j].y = row[r1];
-        dv[j].x = row[R + r0]; dv[j].y = row[R + r1];
+        float a0, d0, a1, d1;
+        src.get(t, r0, a0, d0);
+        src.get(t, r1, a1, d1);
+        av[j].x = a0; av[j].y = a1;
+        dv[j].x = d0; dv[j].y = d1;
     }
 }
 
@@ -180,14 +242,14 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
 // sin / cos / rcp sequence of __tanf.  Contraction is on in the step function: this is the filter, its error budget is the
 // refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
 // The controls of F1P_K4_CHUNK2 time steps are requested up front (4 x CHUNK2 independent 256-byte wave loads in flight).
-template <bool POLY>
-__device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const float* __restrict__ ce, const float* sref32, const KmpcF32& k, int T, int R,
+template <bool POLY, typename Src>
+__device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const float* sref32, const KmpcF32& k, int T,
                                                          int r0, int r1) {
     KmpcState2 s;
     s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f;
     for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK2) {
         f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
-        kmpc_load_chunk2(ce, T, R, r0, r1, t0, a0, d0);
+        kmpc_load_chunk2(src, T, r0, r1, t0, a0, d0);
         kmpc_steps2<POLY>(s, sref32, k, T, t0, a0, d0);
     }
     const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + T], e1 = s.y - sref32[1 * (T + 1) + T];
@@ -208,22 +270,33 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const float* __restric
 #endif
 #define F1P_K4_MAX_REFINE 64
 
-// the winner's applied sequence (clamp, then the sequential rate limit) and the per-ego outputs; one thread
-__device__ __forceinline__ void kmpc_emit(const float* __restrict__ ce, const f1p_kmpc_cfg& cfg, double sv, double dmax, int e, int bi,
+// the winner's applied sequence (clamp, then the sequential rate limit) and the per-ego outputs; one thread.
+// warm_out (nullable, global [T][2] f32 of this ego): the next plan's warm start = the applied sequence shifted by one step with
+// the last step repeated (kinematic_mpc.py:491-498 keeps self.oa / self.odelta_v the same way).  The caller's `src` must not
+// read warm_out's memory (the generator reads the workgroup's LDS copy).
+template <typename Src>
+__device__ __forceinline__ void kmpc_emit(const Src& src, const f1p_kmpc_cfg& cfg, double sv, double dmax, int e, int bi,
                                           double bc, double* __restrict__ steer, double* __restrict__ speed,
-                                          int32_t* __restrict__ best_idx, double* __restrict__ best_cost, double* __restrict__ best_seq) {
-    const int T = cfg.horizon, R = cfg.n_rollouts;
+                                          int32_t* __restrict__ best_idx, double* __restrict__ best_cost, double* __restrict__ best_seq,
+                                          float* __restrict__ warm_out = nullptr) {
+    const int T = cfg.horizon;
     double pd = 0.0;
     for (int t = 0; t < T; ++t) {
-        double a = clampd((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_accel, cfg.max_accel);
-        double d = clampd((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_steer, cfg.max_steer);
+        float af, df;
+        src.get(t, bi, af, df);
+        double a = clampd((double)af, -cfg.max_accel, cfg.max_accel);
+        double d = clampd((double)df, -cfg.max_steer, cfg.max_steer);
         if (t > 0) d = clampd(d, pd - dmax, pd + dmax);
         if (t == 0) {
             steer[e] = d;                       // :506  steer_output = odelta_v[0]
             speed[e] = sv + a * cfg.dt;         // :508  speed_output = v + oa[0] * DTK
         }
         if (best_seq) { best_seq[((size_t)e * T + t) * 2] = a; best_seq[((size_t)e * T + t) * 2 + 1] = d; }
-        else if (t == 0) break;
+        if (warm_out) {
+            if (t > 0) { warm_out[2 * (t - 1)] = (float)a; warm_out[2 * (t - 1) + 1] = (float)d; }
+            if (t == T - 1) { warm_out[2 * t] = (float)a; warm_out[2 * t + 1] = (float)d; }
+        }
+        if (!best_seq && !warm_out && t == 0) break;
         pd = d;
     }
     best_idx[e] = bi;
@@ -233,10 +306,12 @@ __device__ __forceinline__ void kmpc_emit(const float* __restrict__ ce, const f1
 // fp64 re-evaluation by the whole workgroup (all 256 threads must call it; workgroup-uniform arguments).  n > 0: the listed
 // survivors, one lane each; n < 0: every rollout, one lane per rollout (the code of the plain kernel).  `sref` is LDS scratch
 // of 4 (T+1) + 4 doubles + 4 ints.
-__device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref, const float* __restrict__ ce, const f1p_kmpc_cfg& cfg,
+template <typename Src>
+__device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref, const Src& ce, const f1p_kmpc_cfg& cfg,
                                                   double sx, double sy, double sv, double syaw, int e, int n, const int* list, double* sref,
                                                   double* __restrict__ steer, double* __restrict__ speed, int32_t* __restrict__ best_idx,
-                                                  double* __restrict__ best_cost, double* __restrict__ best_seq, int32_t* __restrict__ n_refined) {
+                                                  double* __restrict__ best_cost, double* __restrict__ best_seq, int32_t* __restrict__ n_refined,
+                                                  float* __restrict__ warm_out = nullptr) {
     const int T = cfg.horizon, tid = threadIdx.x;
     double* red_d = sref + 4 * (T + 1);
     int* red_i = reinterpret_cast<int*>(red_d + 4);
@@ -253,7 +328,7 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
     }
     block_argmin(bc, bi, red_d, red_i);
     if (tid == 0) {
-        kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq);
+        kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
         if (n_refined) n_refined[e] = n;
     }
 }
@@ -281,7 +356,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     const int e = blockIdx.x;
     if (e >= E) return;
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
-    const float* ce = controls + (size_t)e * T * 2 * R;
+    const SrcStream ce{controls + (size_t)e * T * 2 * R, R};
     if (!(fabs(syaw) <= 1.0e4) || !(fabs(cfg.max_steer) <= 1.0e4)) {  // workgroup-uniform: outside the fast paths' ranges
         kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
         return;
@@ -307,7 +382,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     const bool poly = k.max_steer <= 0.45f;               // polynomial tan inside its accuracy range (the reference's MAX_STEER is 0.4189)
     for (int r = tid; r < R; r += 2 * blockDim.x) {                    // rollouts r and r + 256 share the packed lanes
         const int r1 = r + (int)blockDim.x < R ? r + (int)blockDim.x : r;
-        const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(ce, sref32, k, T, R, r, r1) : kmpc_rollout_cost_f32x2<false>(ce, sref32, k, T, R, r, r1);
+        const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(ce, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(ce, sref32, k, T, r, r1);
         c32[r] = c.x;
         if (cost32_out) cost32_out[(size_t)e * R + r] = c.x;
         fmin_ = fminf(fmin_, c.x);                                     // NaN costs are ignored here and caught below
@@ -345,6 +420,151 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Shooting with IN-KERNEL control generation (f1p_kmpc_plan_*): the same f32 filter + fp64 refinement as k_kmpc_shoot_mixed, the
+// controls coming from SrcGen instead of HBM.  No 8 B per rollout-step stream: the kernel is VALU-bound (Philox4x32-10 is ~75
+// integer instructions per rollout-step, the packed rollout ~20 per rollout).
+// Grid = E x G workgroups: workgroup (e, g) filters rollouts [g Rs, (g+1) Rs) of ego e.  G > 1 (launcher: E < 2 x CUs, e.g. the
+// 128 egos per GPU of BASELINE configs[4]) spreads one ego's rollouts over several CUs; the filter costs go to a global
+// [E][R] f32 scratch, a per-ego ticket counts the finished workgroups and the LAST one to arrive runs the second stage --
+// minimum, near-minimum set, fp64 refinement, winner re-emission, warm-start update -- with no second launch.
+// warm_in / warm_out: [E][T][2] f32 (may alias: every workgroup copies its ego's row to LDS before the ticket; the last
+// workgroup writes only after every other one has passed its ticket).
+// ---------------------------------------------------------------------------------------------------
+struct KmpcGenArgs {
+    uint32_t k0, k1, call;
+    float sig_a, sig_d;
+    const float* warm_in;     // nullable: no warm start
+    float* warm_out;          // nullable
+    float* cost32;            // [E][R] scratch (G > 1) or the test hook (nullable when G == 1)
+    unsigned int* tickets;    // [E], zero before the launch; reset by the last workgroup (G > 1)
+    int G, Rs;
+};
+
+__global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_plan_gen(const double* __restrict__ x0, const double* __restrict__ ref, int E,
+                                                       f1p_kmpc_cfg cfg, KmpcF32 kf, KmpcGenArgs ga,
+                                                       double* __restrict__ steer, double* __restrict__ speed,
+                                                       int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
+                                                       double* __restrict__ best_seq, int32_t* __restrict__ n_refined) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    float* sref32 = reinterpret_cast<float*>(lds_raw);                // [4][T+1] relative to the ego state, f32
+    float* warm_s = sref32 + 4 * (T + 1);                             // [T][2] this ego's warm start
+    float* red_f = warm_s + 2 * T;                                    // [4]
+    int* list = reinterpret_cast<int*>(red_f + 4);                    // [F1P_K4_MAX_REFINE]
+    int* cnt = list + F1P_K4_MAX_REFINE;                              // [2]: survivors, "this workgroup is the last one"
+    double* sref = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(cnt + 2) + 7) & ~(uintptr_t)7);   // fp64 refinement scratch
+    float* c32 = reinterpret_cast<float*>(sref + 4 * (T + 1) + 4 + 2);   // [R] filter costs (G == 1: LDS only)
+    const int e = blockIdx.x / ga.G, g = blockIdx.x - e * ga.G;
+    if (e >= E) return;
+    const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
+    for (int q = tid; q < 2 * T; q += blockDim.x) warm_s[q] = ga.warm_in ? ga.warm_in[(size_t)e * 2 * T + q] : 0.0f;
+    SrcGen src;
+    src.k0 = ga.k0; src.k1 = ga.k1; src.call = ga.call; src.ego = (uint32_t)e; src.sig_a = ga.sig_a; src.sig_d = ga.sig_d;
+    src.warm = warm_s;
+    float* warm_out = ga.warm_out ? ga.warm_out + (size_t)e * 2 * T : nullptr;
+    const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4;     // workgroup-uniform: the fast paths' ranges
+    for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
+        const double rv = ref[(size_t)e * 4 * (T + 1) + q];
+        const int row = q / (T + 1);
+        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));
+    }
+    if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    KmpcF32 k = kf;
+    double s0d, c0d;
+    sincos_core(in_range ? syaw : 0.0, &s0d, &c0d);
+    k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
+    k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
+    k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
+
+    // ---- pass A: f32 filter over this workgroup's slice ---------------------------------------------------------------
+    const int r_lo = g * ga.Rs, r_hi = min(R, r_lo + ga.Rs);
+    float* cost_out = ga.G > 1 ? ga.cost32 + (size_t)e * R : c32;
+    if (in_range) {
+        const bool poly = k.max_steer <= 0.45f;
+        const int half = (r_hi - r_lo + 1) >> 1;                      // rollouts r and r + half share the packed lanes
+        for (int q = tid; q < half; q += blockDim.x) {
+            const int r = r_lo + q, r1 = r + half < r_hi ? r + half : r;
+            const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(src, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(src, sref32, k, T, r, r1);
+            cost_out[r] = c.x;
+            if (r1 != r) cost_out[r1] = c.y;
+            if (ga.G == 1 && ga.cost32) { ga.cost32[(size_t)e * R + r] = c.x; if (r1 != r) ga.cost32[(size_t)e * R + r1] = c.y; }
+        }
+    }
+    if (ga.G > 1) {
+        __threadfence();                                              // this workgroup's costs are visible device-wide ...
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int t_ = atomicAdd(&ga.tickets[e], 1u);    // ... before its ticket is
+            cnt[1] = (t_ == (unsigned int)ga.G - 1u) ? 1 : 0;
+            if (cnt[1]) ga.tickets[e] = 0u;                           // ready for the next launch (stream-ordered)
+        }
+        __syncthreads();
+        if (!cnt[1]) return;
+        __threadfence();
+    } else {
+        __syncthreads();
+    }
+
+    // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
+    if (!in_range) {
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+        return;
+    }
+    float fmin_ = __builtin_huge_valf();
+    for (int r = tid; r < R; r += blockDim.x) {
+        float c;
+        if (ga.G > 1) c = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        else c = cost_out[r];
+        fmin_ = fminf(fmin_, c);                                      // NaN costs are ignored here and caught below
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
+    if (lane == 0) red_f[wave] = fmin_;
+    __syncthreads();
+    fmin_ = red_f[0];
+    for (int w = 1; w < nwaves; ++w) fmin_ = fminf(fmin_, red_f[w]);
+    const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
+    for (int r = tid; r < R; r += blockDim.x) {
+        float c;
+        if (ga.G > 1) c = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        else c = cost_out[r];
+        if (!(c > thr)) {                                              // includes NaN
+            const int pos = atomicAdd(cnt, 1);
+            if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+        }
+    }
+    __syncthreads();
+    const int n = cnt[0];
+    if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+    } else if (n == 1 && !best_cost) {
+        if (tid == 0) {                                                // a single survivor needs no fp64 cost unless it is asked for
+            kmpc_emit(src, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
+            if (n_refined) n_refined[e] = 1;
+        }
+    } else {
+        // the survivors in ascending rollout order: the atomic list is in arrival order, the decision (first minimum) is by index
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+    }
+}
+
+// materialise SrcGen's controls as the [E][T][2][R] f32 buffer of the streamed entry points (tests: generated == streamed)
+__global__ __launch_bounds__(256) void k_kmpc_gen_controls(float* __restrict__ controls, int E, int T, int R, KmpcGenArgs ga) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)E * T * R) return;
+    const size_t et = i / R;
+    const int r = (int)(i - et * R), e = (int)(et / T), t = (int)(et - (size_t)e * T);
+    SrcGen src;
+    src.k0 = ga.k0; src.k1 = ga.k1; src.call = ga.call; src.ego = (uint32_t)e; src.sig_a = ga.sig_a; src.sig_d = ga.sig_d;
+    src.warm = ga.warm_in ? ga.warm_in + (size_t)e * 2 * T : nullptr;
+    float a, d;
+    src.get(t, r, a, d);
+    controls[(et * 2 + 0) * R + r] = a;
+    controls[(et * 2 + 1) * R + r] = d;
+}
+
 __global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot(const double* __restrict__ x0, const double* __restrict__ ref,
                                                     const float* __restrict__ controls, int E, f1p_kmpc_cfg cfg,
                                                     double* __restrict__ steer, double* __restrict__ speed,
@@ -360,7 +580,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot(const double* 
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 4 * (T + 1) + q];
     __syncthreads();
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
-    const float* ce = controls + (size_t)e * T * 2 * R;
+    const SrcStream ce{controls + (size_t)e * T * 2 * R, R};
     const double dmax = cfg.max_dsteer * cfg.dt;
 
     double bc = __builtin_huge_val(); int bi = 0x7fffffff;
@@ -470,18 +690,15 @@ __global__ void k_argmin_mask(const uint64_t* __restrict__ own, const uint64_t* 
     cost_out[e] = k == 0ull ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double((long long)b);
 }
 
+static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg);
+
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                       double* d_best_cost, double* d_best_seq) {
     if (E <= 0) return F1P_OK;
     const size_t T1 = (size_t)cfg->horizon + 1;
     if (ctx->kmpc_mixed && cfg->n_rollouts <= 8192) {
-        KmpcF32 kf;
-        for (int i = 0; i < 4; ++i) { kf.q[i] = (float)cfg->q[i]; kf.qf[i] = (float)cfg->qf[i]; }
-        for (int i = 0; i < 2; ++i) { kf.r[i] = (float)cfg->r[i]; kf.rd[i] = (float)cfg->rd[i]; }
-        kf.dt = (float)cfg->dt; kf.inv_wb_dt = (float)(cfg->dt / cfg->wheelbase); kf.max_steer = (float)cfg->max_steer;
-        kf.max_accel = (float)cfg->max_accel; kf.max_speed = (float)cfg->max_speed; kf.min_speed = (float)cfg->min_speed;
-        kf.dmax = (float)(cfg->max_dsteer * cfg->dt); kf.c0 = 1.f; kf.s0 = 0.f; kf.v0 = 0.f;
+        const KmpcF32 kf = make_kf(cfg);
         const size_t lds = sizeof(float) * (4 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 1) + 8 +
                            sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
         hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, kf,
@@ -492,6 +709,85 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
     hipLaunchKernelGGL(k_kmpc_shoot, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E,
                        *cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot launch");
+}
+
+static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg) {
+    KmpcF32 kf;
+    for (int i = 0; i < 4; ++i) { kf.q[i] = (float)cfg->q[i]; kf.qf[i] = (float)cfg->qf[i]; }
+    for (int i = 0; i < 2; ++i) { kf.r[i] = (float)cfg->r[i]; kf.rd[i] = (float)cfg->rd[i]; }
+    kf.dt = (float)cfg->dt; kf.inv_wb_dt = (float)(cfg->dt / cfg->wheelbase); kf.max_steer = (float)cfg->max_steer;
+    kf.max_accel = (float)cfg->max_accel; kf.max_speed = (float)cfg->max_speed; kf.min_speed = (float)cfg->min_speed;
+    kf.dmax = (float)(cfg->max_dsteer * cfg->dt); kf.c0 = 1.f; kf.s0 = 0.f; kf.v0 = 0.f;
+    return kf;
+}
+
+static KmpcGenArgs make_gen_args(const f1p_kmpc_sampler* smp) {
+    KmpcGenArgs ga;
+    ga.k0 = (uint32_t)(smp->seed & 0xffffffffull); ga.k1 = (uint32_t)(smp->seed >> 32); ga.call = smp->call;
+    ga.sig_a = (float)smp->sigma_accel; ga.sig_d = (float)smp->sigma_steer;
+    ga.warm_in = nullptr; ga.warm_out = nullptr; ga.cost32 = nullptr; ga.tickets = nullptr; ga.G = 1; ga.Rs = 0;
+    return ga;
+}
+
+// number of workgroups per ego: fill ~2 workgroups per CU when the batch alone cannot, never below one wave of rollout pairs
+int kmpc_plan_groups(const f1p_ctx* ctx, int E, int R) {
+    if (ctx->kmpc_groups > 0) return ctx->kmpc_groups;              // test / A-B override
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int G = (2 * cus + E - 1) / E;
+    const int g_max = (R + 127) / 128;                               // >= 128 rollouts (64 packed pairs = one wave) per workgroup
+    if (G > g_max) G = g_max;
+    if (G > 64) G = 64;
+    return G < 1 ? 1 : G;
+}
+
+int launch_kmpc_plan_gen(f1p_ctx* ctx, const double* d_x0, const double* d_ref, int E, const f1p_kmpc_cfg* cfg,
+                         const f1p_kmpc_sampler* smp, const float* d_warm_in, float* d_warm_out, double* d_steer, double* d_speed,
+                         int32_t* d_best_idx, double* d_best_cost, double* d_best_seq) {
+    if (E <= 0) return F1P_OK;
+    const size_t T1 = (size_t)cfg->horizon + 1, T = cfg->horizon, R = cfg->n_rollouts;
+    KmpcGenArgs ga = make_gen_args(smp);
+    ga.warm_in = d_warm_in; ga.warm_out = d_warm_out;
+    ga.G = kmpc_plan_groups(ctx, E, (int)R);
+    ga.Rs = (int)((R + ga.G - 1) / ga.G);
+    ga.cost32 = ctx->d_dbg_cost32;
+    if (ga.G > 1) {
+        const size_t need = sizeof(float) * (size_t)E * R + sizeof(unsigned int) * (size_t)E + 256;
+        if (need > ctx->kmpc_scratch_bytes) {
+            F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_kmpc_scratch) (void)hipFree(ctx->d_kmpc_scratch);
+            ctx->d_kmpc_scratch = nullptr; ctx->kmpc_scratch_bytes = 0;
+            F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_scratch, need));
+            ctx->kmpc_scratch_bytes = need;
+            ctx->kmpc_tickets_E = 0;
+        }
+        unsigned int* tickets = reinterpret_cast<unsigned int*>(ctx->d_kmpc_scratch);
+        if (ctx->kmpc_tickets_E < E) {                               // first use: zero; afterwards the kernel resets its own tickets
+            F1P_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(unsigned int) * (size_t)E, ctx->stream));
+            ctx->kmpc_tickets_E = E;
+        }
+        ga.tickets = tickets;
+        if (!ga.cost32) ga.cost32 = reinterpret_cast<float*>(ctx->d_kmpc_scratch + ((sizeof(unsigned int) * (size_t)E + 255) & ~(size_t)255));
+    }
+    const int pairs = (ga.Rs + 1) / 2;
+    int block = ((pairs + 63) / 64) * 64;
+    if (block > 256) block = 256;
+    if (block < 64) block = 64;
+    size_t lds = sizeof(float) * (4 * T1 + 2 * T + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 2) + 8 + sizeof(double) * (4 * T1 + 4 + 2) + sizeof(int) * 4;
+    if (ga.G == 1) lds += sizeof(float) * R;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > (size_t)ctx->prop.sharedMemPerBlock) return set_error(ctx, F1P_EINVAL, "horizon / n_rollouts need more LDS than a workgroup has: use fewer rollouts per plan");
+    hipLaunchKernelGGL(k_kmpc_plan_gen, dim3((unsigned)((size_t)E * ga.G)), dim3(block), lds, ctx->stream, d_x0, d_ref, E, *cfg, make_kf(cfg), ga,
+                       d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_nref);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_plan_gen launch");
+}
+
+int launch_kmpc_gen_controls(f1p_ctx* ctx, float* d_controls, int E, const f1p_kmpc_cfg* cfg, const f1p_kmpc_sampler* smp, const float* d_warm) {
+    const size_t n = (size_t)E * cfg->horizon * cfg->n_rollouts;
+    if (n == 0) return F1P_OK;
+    KmpcGenArgs ga = make_gen_args(smp);
+    ga.warm_in = d_warm;
+    hipLaunchKernelGGL(k_kmpc_gen_controls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_controls, E, cfg->horizon, cfg->n_rollouts, ga);
+    return check_hip(ctx, hipGetLastError(), "k_kmpc_gen_controls launch");
 }
 
 int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, const double* d_od, int E,

@@ -353,6 +353,43 @@ class Context:
         self._check(self.lib.f1p_kmpc_shoot_dev(self.h, p(d_x0), p(d_ref), p(d_controls), int(E), C.byref(cfg), p(d_steer),
                                                 p(d_speed), p(d_best_idx), p(d_best_cost), p(d_best_seq)))
 
+    # in-kernel control generation + device-resident warm start (f1p_kmpc_plan_*)
+    def kmpc_plan(self, x0, cfg: KmpcCfg, sampler, dl=0.03, want_seq=True, want_cost=True):
+        """KMPCPlanner.plan for E egos in ONE call: reference extraction, sampling around the ctx's warm start, rollouts,
+        argmin, new warm start -- nothing but x0 goes up and the winners come down."""
+        x0 = _f64(x0, (-1, 4)); E = x0.shape[0]; T = cfg.horizon
+        out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32))
+        if want_cost:
+            out["best_cost"] = np.empty(E)
+        if want_seq:
+            out["best_seq"] = np.empty((E, T, 2))
+        self._check(self.lib.f1p_kmpc_plan_batch(self.h, _ptr(x0), E, C.byref(cfg), float(dl), C.byref(sampler), _ptr(out["steer"]),
+                                                 _ptr(out["speed"]), _ptr(out["best_idx"]), _ptr(out.get("best_cost")), _ptr(out.get("best_seq"))))
+        return out
+
+    def kmpc_plan_dev(self, d_x0, d_ref, E, cfg: KmpcCfg, sampler, d_steer, d_speed, d_best_idx, d_best_cost=None, d_best_seq=None):
+        p = lambda b: None if b is None else b.ptr   # noqa: E731
+        self._check(self.lib.f1p_kmpc_plan_dev(self.h, p(d_x0), p(d_ref), int(E), C.byref(cfg), C.byref(sampler), p(d_steer), p(d_speed),
+                                               p(d_best_idx), p(d_best_cost), p(d_best_seq)))
+
+    def kmpc_gen_controls_dev(self, d_controls, E, cfg: KmpcCfg, sampler):
+        self._check(self.lib.f1p_kmpc_gen_controls_dev(self.h, d_controls.ptr, int(E), C.byref(cfg), C.byref(sampler)))
+
+    def kmpc_warm_reset(self):
+        self._check(self.lib.f1p_kmpc_warm_reset(self.h))
+
+    def kmpc_warm_get(self, E, T):
+        w = np.empty((int(E), int(T), 2), np.float32)
+        self._check(self.lib.f1p_kmpc_warm_get(self.h, _ptr(w), int(E), int(T)))
+        return w
+
+    def kmpc_warm_set(self, warm):
+        w = np.ascontiguousarray(warm, np.float32)
+        self._check(self.lib.f1p_kmpc_warm_set(self.h, _ptr(w), w.shape[0], w.shape[1]))
+
+    def kmpc_set_groups(self, groups=0):
+        self._check(self.lib.f1p_kmpc_set_groups(self.h, int(groups)))
+
     def kmpc_sample_controls_dev(self, d_controls, E, cfg: KmpcCfg, seed, sigma_accel=1.5, sigma_steer=0.15):
         self._check(self.lib.f1p_kmpc_sample_controls_dev(self.h, d_controls.ptr, int(E), C.byref(cfg),
                                                           C.c_uint64(int(seed)), float(sigma_accel), float(sigma_steer)))

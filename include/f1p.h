@@ -325,6 +325,47 @@ int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, con
                                  uint64_t seed, double sigma_accel, double sigma_steer);
 
 /* ------------------------------------------------------------------------------------------------
+ * Shooting MPC with the controls GENERATED IN THE KERNEL and the warm start resident on the device: what
+ * KMPCPlanner.plan does per call (kinematic_mpc.py:115-160, 477-508) with the QP replaced by sampling -- reference
+ * extraction (:162-206), R candidate sequences around the previous solution shifted by one step (the reference's warm start
+ * self.oa / self.odelta_v, :108-110, :491-498), rollout + objective + bounds, argmin, output map, new warm start.
+ * Nothing per-rollout exists in memory: control (rollout r, step t) of ego e is a pure function of (seed, call, e, r, t):
+ *   Philox4x32-10, counter = (t, r, e, call), key = seed  ->  128 bits;
+ *   accel = fma(sigma_accel, z_a, warm_a[t]),  steer = fma(sigma_steer, z_d, warm_d[t])   in f32, where z = (sum of 8 of those
+ *   bytes - 1020) / 209.02153 is a standardised Irwin-Hall variate (bounded near-normal, integer arithmetic => bit-identical to the
+ *   CPU restatement oracle/f1p_oracle.c:orc_kmpc_gen_controls); rollout 0 = the warm start itself, rollout 1 = all zero.
+ * The bounds are applied by the rollout's projection exactly as for streamed controls, so
+ *   f1p_kmpc_gen_controls_dev + f1p_kmpc_shoot_dev  ==  f1p_kmpc_plan_dev   bit for bit (tests/test_gpu_kmpc_gen.py).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct f1p_kmpc_sampler {
+    uint64_t seed;           /* Philox key                                                                          */
+    uint32_t call;           /* plan counter (counter word 3): the caller increments it every plan                  */
+    int32_t use_warm;        /* 1: sample around the ctx's warm start when it holds one for this (E, T); 0: around 0 */
+    double sigma_accel;      /* std of the acceleration perturbation [m/s^2]                                        */
+    double sigma_steer;      /* std of the steering perturbation [rad]                                              */
+} f1p_kmpc_sampler;
+/* x0 [E][4] = (x, y, v, yaw) HOST -> reference from the ctx waypoints (cols x, y, v, psi; dl = mpc_config.dlk) -> plan.
+ * Outputs as f1p_kmpc_shoot_batch (best_cost / best_seq nullable).  Updates the ctx's warm start ([E][T][2] f32, device). */
+int f1p_kmpc_plan_batch(f1p_ctx* ctx, const double* x0, int32_t E, const f1p_kmpc_cfg* cfg, double dl,
+                        const f1p_kmpc_sampler* smp, double* steer, double* speed, int32_t* best_idx, double* best_cost,
+                        double* best_seq);
+/* the same on device buffers with the reference trajectories given (d_ref [E][4][T+1]); asynchronous on the ctx stream */
+int f1p_kmpc_plan_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, int32_t E, const f1p_kmpc_cfg* cfg,
+                      const f1p_kmpc_sampler* smp, double* d_steer, double* d_speed, int32_t* d_best_idx,
+                      double* d_best_cost, double* d_best_seq);
+/* materialise the generated controls as the f32 [E][T][2][R] buffer of f1p_kmpc_shoot_dev (around the ctx's current warm
+ * start when smp->use_warm and one is held): the parity hook "generated == streamed" */
+int f1p_kmpc_gen_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const f1p_kmpc_cfg* cfg,
+                              const f1p_kmpc_sampler* smp);
+/* warm start of the ctx: forget it / read it back / install one (warm [E][T][2] f32 host = (accel, steer) per step) */
+int f1p_kmpc_warm_reset(f1p_ctx* ctx);
+int f1p_kmpc_warm_get(f1p_ctx* ctx, float* warm, int32_t E, int32_t T);
+int f1p_kmpc_warm_set(f1p_ctx* ctx, const float* warm, int32_t E, int32_t T);
+/* workgroups per ego of f1p_kmpc_plan_*: 0 = automatic (one per ego when the batch fills the chip, several -- each filtering a
+ * slice of the rollouts, the last one to finish reducing -- below 2 x CUs egos); > 0 forces the count (tests, A/B runs) */
+int f1p_kmpc_set_groups(f1p_ctx* ctx, int32_t groups);
+
+/* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8f rank 2 -- the dynamic single-track model as a second model for shooting MPC
  * (control/dynamic_mpc/dynamic_mpc.py): predict_motion / update_state (:280-404), calc_ref_trajectory (:195-233),
  * objective :616-622, bounds :685-706, output map :1112-1117.

@@ -656,6 +656,77 @@ ORC_API void orc_kmpc_shoot_batch(const double* x0, const double* ref, const flo
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* In-kernel control generation of the shooting MPC (BUILD-DEFINED sampler; the reference solves a QP) */
+/* Restates csrc/k_kmpc.hip SrcGen bit for bit: Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11: the      */
+/* published round function and Weyl key schedule) on counter (t, rollout, ego, call) with key = seed;      */
+/* each control = fma(sigma, z, warm) in f32 with z = (sum of 8 random bytes - 1020) * (1/209.02153f), a     */
+/* standardised Irwin-Hall variate -- integer byte sums, so there is no library transcendental between the */
+/* two implementations.  Rollout 0 = the warm start, rollout 1 = zeros.                                     */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static uint32_t orc_byte_sum(uint32_t x) { return (x & 0xffu) + ((x >> 8) & 0xffu) + ((x >> 16) & 0xffu) + (x >> 24); }
+
+/* controls [T][2][R] f32 of ego e; warm [T][2] f32 or NULL */
+ORC_API void orc_kmpc_gen_controls(uint64_t seed, uint32_t call, int e, int T, int R, double sigma_a, double sigma_d,
+                                   const float* warm, float* out) {
+    const float sa = (float)sigma_a, sd = (float)sigma_d;
+    const uint32_t key[2] = {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
+    for (int t = 0; t < T; ++t) {
+        const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ctr[4] = {(uint32_t)t, (uint32_t)r, (uint32_t)e, call};
+            uint32_t x[4];
+            orc_philox4x32_10(ctr, key, x);
+            const float za = ((float)(int)(orc_byte_sum(x[0]) + orc_byte_sum(x[1])) - 1020.0f) * 0.0047842013f;
+            const float zd = ((float)(int)(orc_byte_sum(x[2]) + orc_byte_sum(x[3])) - 1020.0f) * 0.0047842013f;
+            float a = fmaf(sa, za, wa), d = fmaf(sd, zd, wd);
+            if (r == 0) { a = wa; d = wd; }
+            else if (r == 1) { a = 0.0f; d = 0.0f; }
+            out[((size_t)t * 2 + 0) * R + r] = a;
+            out[((size_t)t * 2 + 1) * R + r] = d;
+        }
+    }
+}
+
+/* f1p_kmpc_plan_*: generate around the warm start, shoot, update the warm start (the applied winner shifted by one step,
+ * last step repeated: what KMPCPlanner keeps in self.oa / self.odelta_v, kinematic_mpc.py:491-498).
+ * warm [E][T][2] f32 in/out; warm_valid = 0: sample around zero. */
+ORC_API void orc_kmpc_plan_batch(const double* x0, const double* ref, int E, const f1p_kmpc_cfg* c, uint64_t seed, uint32_t call,
+                                 double sigma_a, double sigma_d, float* warm, int warm_valid, double* steer, double* speed,
+                                 int32_t* best_idx, double* best_cost, double* best_seq, int nthreads) {
+    int T = c->horizon, R = c->n_rollouts;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int e = 0; e < E; ++e) {
+        float* ctrl = (float*)malloc(sizeof(float) * 2 * (size_t)T * R);
+        double* seq = (double*)malloc(sizeof(double) * 2 * (size_t)T);
+        float* we = warm + (size_t)e * 2 * T;
+        orc_kmpc_gen_controls(seed, call, e, T, R, sigma_a, sigma_d, warm_valid ? we : NULL, ctrl);
+        orc_kmpc_shoot_batch(&x0[4 * e], &ref[(size_t)e * 4 * (T + 1)], ctrl, 1, c, &steer[e], &speed[e], &best_idx[e],
+                             best_cost ? &best_cost[e] : NULL, seq, NULL, 1);
+        for (int t = 0; t < T; ++t) {
+            int src = t + 1 < T ? t + 1 : T - 1;
+            we[2 * t] = (float)seq[2 * src]; we[2 * t + 1] = (float)seq[2 * src + 1];
+        }
+        if (best_seq) memcpy(&best_seq[(size_t)e * T * 2], seq, sizeof(double) * 2 * (size_t)T);
+        free(seq); free(ctrl);
+    }
+}
+
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -243,6 +243,35 @@ def kmpc_shoot_batch(x0, ref, controls, cfg: KmpcCfg, want_all=False, nthreads=1
     return out
 
 
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, np.uint32).copy(); k = np.asarray(key, np.uint32).copy(); out = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def kmpc_gen_controls(seed, call, E, cfg: KmpcCfg, sigma_a, sigma_d, warm=None):
+    """the in-kernel sampler of f1p_kmpc_plan_* restated: controls f32 [E, T, 2, R]; warm [E, T, 2] f32 or None"""
+    T, R = cfg.horizon, cfg.n_rollouts
+    out = np.zeros((E, T, 2, R), np.float32)
+    w = None if warm is None else np.ascontiguousarray(warm, np.float32)
+    for e in range(E):
+        lib().orc_kmpc_gen_controls(C.c_uint64(seed), C.c_uint32(call), C.c_int(e), C.c_int(T), C.c_int(R), C.c_double(sigma_a),
+                                    C.c_double(sigma_d), None if w is None else _p(w[e]), _p(out[e]))
+    return out
+
+
+def kmpc_plan_batch(x0, ref, cfg: KmpcCfg, seed, call, sigma_a, sigma_d, warm=None, nthreads=1):
+    """f1p_kmpc_plan_*: generate around `warm` ([E, T, 2] f32 or None), shoot, return outputs + the next warm start"""
+    x0 = _f64(x0); ref = _f64(ref); E = x0.shape[0]; T = cfg.horizon
+    w = np.zeros((E, T, 2), np.float32) if warm is None else np.ascontiguousarray(warm, np.float32).copy()
+    out = dict(steer=np.zeros(E), speed=np.zeros(E), best_idx=np.zeros(E, np.int32), best_cost=np.zeros(E), best_seq=np.zeros((E, T, 2)))
+    lib().orc_kmpc_plan_batch(_p(x0), _p(ref), C.c_int(E), C.byref(cfg), C.c_uint64(seed), C.c_uint32(call), C.c_double(sigma_a),
+                              C.c_double(sigma_d), _p(w), C.c_int(0 if warm is None else 1), _p(out["steer"]), _p(out["speed"]),
+                              _p(out["best_idx"]), _p(out["best_cost"]), _p(out["best_seq"]), C.c_int(nthreads))
+    out["warm"] = w
+    return out
+
+
 # ---- Stanley / LQR (SURVEY 8f rank 1) ------------------------------------------------------------------------
 def stanley_batch(states, waypoints, wheelbase=0.33, k_path=5.0, cols=(0, 1, 2, 3)):
     """StanleyPlanner.plan (control/stanley/stanley.py:114-139) over states [E, 4] = (x, y, theta, v)"""
