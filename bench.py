@@ -348,6 +348,22 @@ def leg_kmpc_c4(rk, args, steps):
            "rollout_steps_per_s": float(E_total) * R * T * steps / elapsed, "ms_per_plan": elapsed / steps * 1e3, "kernel_ms": kernel_ms,
            "control_stream_GBps_per_gpu": abytes / (kernel_ms * 1e-3) / 1e9,
            "note": "controls streamed from HBM as f32 [E][T][2][R]; 126 MB per 1024 egos, i.e. Infinity-Cache resident below ~2048 egos per GPU"}
+    # the same plan with the controls generated in the kernel around the device-resident warm start (no control buffer at all)
+    from f1tenth_planning_amd import _abi
+    calls = [0]
+
+    def gstep():
+        smp = _abi.kmpc_sampler(seed=2 + rk.rank, call=calls[0]); calls[0] += 1
+        ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, None)
+    g_elapsed, g_ms = timed_region(rk, ctx, gstep, 5, steps)
+    ts = []
+    for _ in range(30):                                   # host boundary: x0 up, reference extraction, plan, winners down
+        smp = _abi.kmpc_sampler(seed=2 + rk.rank, call=calls[0]); calls[0] += 1
+        t1 = time.perf_counter(); ctx.kmpc_plan(states, cfg, smp, want_seq=False, want_cost=False); ts.append((time.perf_counter() - t1) * 1e3)
+    out["generated_in_kernel"] = {"rollout_steps_per_s": float(E_total) * R * T * steps / g_elapsed, "ms_per_plan": g_elapsed / steps * 1e3,
+                                  "kernel_ms": g_ms / steps, "host_boundary_p50_ms": float(np.percentile(ts, 50)),
+                                  "note": "f1p_kmpc_plan_*: Philox4x32-10 controls in registers around the ctx's warm start; VALU-bound, no HBM stream; "
+                                          "below 2 x CUs egos the rollouts of one ego are split over several workgroups (last one reduces)"}
     ctx.close()
     return out
 
@@ -689,24 +705,38 @@ def main_kmpc(args):
     T, R = args.horizon, args.rollouts
     ctx, cfg, states, ref, _ = kmpc_setup(rk, args, E, T, R)
     rk.init()
+    from f1tenth_planning_amd import _abi
     d_x0, d_ref = ctx.to_device(states), ctx.to_device(ref)
-    d_ctrl = ctx.alloc(4 * E * T * 2 * R)
-    ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=2 + rank)
+    stream = args.kmpc_stream or args.kmpc_f64
+    d_ctrl = ctx.alloc(4 * E * T * 2 * R) if stream or not args.no_cpu_baseline else None
+    if stream:
+        ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=2 + rank)
     d_steer, d_speed, d_bi, d_bc = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E)
     ctx.kmpc_set_mode(not args.kmpc_f64)
+    calls = [0]
 
     def step():
-        ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc if (args.kmpc_cost or args.kmpc_f64) else None)
+        if stream:
+            ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc if (args.kmpc_cost or args.kmpc_f64) else None)
+        else:
+            smp = _abi.kmpc_sampler(seed=2 + rank, call=calls[0]); calls[0] += 1
+            ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, d_bc if args.kmpc_cost else None)
     elapsed, ms_total = timed_region(rk, ctx, step, args.warmup, args.steps)
     kernel_ms = ms_total / args.steps
+    if not stream and not args.no_cpu_baseline and rank == 0:      # parity leg: the last plan's controls, materialised, for the oracle
+        ctx.kmpc_warm_reset()
+        smp = _abi.kmpc_sampler(seed=2 + rank, call=12345, use_warm=False)
+        ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, None)
+        ctx.kmpc_gen_controls_dev(d_ctrl, E, cfg, smp)
     if rank == 0:
-        abytes = E * R * T * 8 + E * (T + 1) * 32 + E * 32 + E * 28
+        abytes = (E * R * T * 8 if stream else 0) + E * (T + 1) * 32 + E * 32 + E * 28 + (0 if stream else E * T * 16)
         value = float(E_total) * R * T * args.steps / elapsed
         out = {"metric": "rollout-steps/sec (kinematic-MPC random shooting)", "value": value, "unit": "rollout-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 on f32 controls" if args.kmpc_f64 else "f32 filter + f64 refinement of the near-minimum set (decision in f64)",
                "data": "synthetic",
-               "config": {"workload": f"kmpc shooting: {E_total} egos x {R} rollouts x {T} steps over {world} GPU(s), {E} egos per GPU (BASELINE configs[4])"},
+               "config": {"workload": f"kmpc shooting: {E_total} egos x {R} rollouts x {T} steps over {world} GPU(s), {E} egos per GPU (BASELINE configs[4])",
+                          "controls": "streamed from HBM (f32 [E][T][2][R])" if stream else "generated in the kernel (Philox4x32-10 around the device-resident warm start)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_kmpc_shoot",
                             "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,

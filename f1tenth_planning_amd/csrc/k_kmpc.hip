@@ -54,14 +54,20 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 //   SrcGen   : generated in registers from (seed, call, ego, rollout, t) around the ego's warm start (f1p_kmpc_plan_*): nothing
 //              per-rollout ever exists in memory.  Every consumer -- the f32 filter, the fp64 refinement, the winner's
 //              re-emission -- calls the same pure function, so they all see the same controls.
-// Generator: Philox4x32-10 (Salmon et al., SC'11; counter = (t, rollout, ego, call), key = seed) -> 128 bits per
-// (rollout, step); each control is a standardised Irwin-Hall sum of 8 of those bytes (v_sad_u8: integer, hence bit-identical
-// to the CPU restatement oracle/f1p_oracle.c orc_kmpc_gen_controls -- no transcendental whose last bit differs between
-// libraries), a bounded near-normal variate (+-4.9 sigma, excess kurtosis -0.15):
-//     z = (sum of 8 bytes - 1020) * (1 / 209.0215...);  accel = fma(sigma_a, z, warm_a[t]);  steer = fma(sigma_d, z', warm_d[t])
+// Generator: Philox4x32-10 (Salmon et al., SC'11; counter = (t / 2, rollout, ego, call), key = seed) -> 128 bits per
+// (rollout, PAIR of steps): word 0 / 1 give (accel, steer) of the even step, word 2 / 3 of the odd one.  Each control is a
+// standardised Irwin-Hall sum of the 4 bytes of its word (one v_sad_u8: integer, hence bit-identical to the CPU restatement
+// oracle/f1p_oracle.c orc_kmpc_gen_controls -- no transcendental whose last bit differs between libraries), a bounded
+// near-normal variate (+-3.46 sigma; the bounds clip accel at 2 sigma and steer at 2.8 sigma anyway):
+//     z = (sum of 4 bytes - 510) * (1 / 147.8005...);  accel = fma(sigma_a, z, warm_a[t]);  steer = fma(sigma_d, z', warm_d[t])
+// (measured: Philox is ~75 of the ~125 VALU instructions per rollout-step when called once per step; one call per two steps
+// takes the generated-controls kernel from 0.47 to 0.40 ms at 8192 egos.)
 // Rollout 0 is the unperturbed warm start (previous solution shifted by one step, kinematic_mpc.py:491-498), rollout 1 is all
 // zero.  The bounds (:391-401) are applied by the rollout's projection, exactly as for streamed controls.
 // ---------------------------------------------------------------------------------------------------
+#define F1P_IH_MEAN 510.0f                     // 4 bytes x 127.5
+#define F1P_IH_INV_STD 0.0067658765f           // 1 / sqrt(4 (256^2 - 1) / 12) = 1 / 147.80054, rounded to f32 (same literal in the oracle)
+
 struct SrcStream {
     const float* __restrict__ ce;
     int R;
@@ -69,10 +75,12 @@ struct SrcStream {
         a = ce[((size_t)t * 2 + 0) * R + r];
         d = ce[((size_t)t * 2 + 1) * R + r];
     }
+    // steps te and te + 1 (te even); the tail re-reads the last step (unused)
+    __device__ __forceinline__ void get2(int te, int T, int r, float& a0, float& d0, float& a1, float& d1) const {
+        get(te < T ? te : T - 1, r, a0, d0);
+        get(te + 1 < T ? te + 1 : T - 1, r, a1, d1);
+    }
 };
-
-#define F1P_IH_MEAN 1020.0f                    // 8 bytes x 127.5
-#define F1P_IH_INV_STD 0.0047842013f           // 1 / sqrt(8 (256^2 - 1) / 12) = 1 / 209.02153, rounded to f32 (same literal in the oracle)
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
@@ -90,18 +98,26 @@ struct SrcGen {
     uint32_t k0, k1, call, ego;
     float sig_a, sig_d;
     const float* warm;          // [T][2] (accel, steer) of this ego, LDS or global; nullptr = no warm start (zeros)
+    __device__ __forceinline__ void one(int t, int r, uint32_t xa, uint32_t xd, float& a, float& d) const {
+        const float za = ((float)(int)__builtin_amdgcn_sad_u8(xa, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;   // sum of the word's 4 bytes
+        const float zd = ((float)(int)__builtin_amdgcn_sad_u8(xd, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;
+        const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
+        const float ga = __builtin_fmaf(sig_a, za, wa), gd = __builtin_fmaf(sig_d, zd, wd);
+        a = r == 0 ? wa : (r == 1 ? 0.0f : ga);                       // selects, not branches: r differs per lane
+        d = r == 0 ? wd : (r == 1 ? 0.0f : gd);
+    }
     __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
         uint32_t x0, x1, x2, x3;
-        philox4x32_10((uint32_t)t, (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
-        const uint32_t sa = __builtin_amdgcn_sad_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0u));   // sum of the 8 bytes of (x0, x1)
-        const uint32_t sd = __builtin_amdgcn_sad_u8(x3, 0u, __builtin_amdgcn_sad_u8(x2, 0u, 0u));
-        const float za = ((float)(int)sa - F1P_IH_MEAN) * F1P_IH_INV_STD;
-        const float zd = ((float)(int)sd - F1P_IH_MEAN) * F1P_IH_INV_STD;
-        const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
-        a = __builtin_fmaf(sig_a, za, wa);
-        d = __builtin_fmaf(sig_d, zd, wd);
-        if (r == 0) { a = wa; d = wd; }
-        else if (r == 1) { a = 0.0f; d = 0.0f; }
+        philox4x32_10((uint32_t)(t >> 1), (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
+        one(t, r, (t & 1) ? x2 : x0, (t & 1) ? x3 : x1, a, d);
+    }
+    // steps te and te + 1 (te even) from ONE Philox call; steps >= T are generated like any other (and unused)
+    __device__ __forceinline__ void get2(int te, int T, int r, float& a0, float& d0, float& a1, float& d1) const {
+        uint32_t x0, x1, x2, x3;
+        philox4x32_10((uint32_t)(te >> 1), (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
+        const int tb = te + 1 < T ? te + 1 : te;                      // warm[] has T rows
+        one(te < T ? te : T - 1, r, x0, x1, a0, d0);
+        one(tb < T ? tb : T - 1, r, x2, x3, a1, d1);
     }
 };
 
@@ -162,7 +178,7 @@ struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_a
 #define F1P_K4_WAVES_FILTER 4
 #endif
 #ifndef F1P_K4_CHUNK2
-#define F1P_K4_CHUNK2 5   // time steps per register buffer of the packed filter (4 x CHUNK2 VGPRs)
+#define F1P_K4_CHUNK2 6   // time steps per register buffer of the packed filter (4 x CHUNK2 VGPRs); even: loaded as pairs of steps
 #endif
 
 // Two rollouts per thread in the lanes of packed-f32 instructions: plain f32 VALU ops issue 16 lanes per clock on CDNA4 and
@@ -180,14 +196,14 @@ struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd; };
 template <typename Src>
 __device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, int r1, int t0,
                                                  f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
+    static_assert(F1P_K4_CHUNK2 % 2 == 0, "the chunk is loaded in pairs of steps");
 #pragma unroll
-    for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
-        const int t = t0 + j < T ? t0 + j : T - 1;                     // clamp: the tail re-reads the last step (unused)
-        float a0, d0, a1, d1;
-        src.get(t, r0, a0, d0);
-        src.get(t, r1, a1, d1);
-        av[j].x = a0; av[j].y = a1;
-        dv[j].x = d0; dv[j].y = d1;
+    for (int j = 0; j < F1P_K4_CHUNK2; j += 2) {
+        float a00, d00, a01, d01, a10, d10, a11, d11;
+        src.get2(t0 + j, T, r0, a00, d00, a01, d01);                   // t0 is a multiple of the (even) chunk size
+        src.get2(t0 + j, T, r1, a10, d10, a11, d11);
+        av[j].x = a00; av[j].y = a10; dv[j].x = d00; dv[j].y = d10;
+        av[j + 1].x = a01; av[j + 1].y = a11; dv[j + 1].x = d01; dv[j + 1].y = d11;
     }
 }
 

@@ -330,9 +330,9 @@ int f1p_kmpc_sample_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, con
  * extraction (:162-206), R candidate sequences around the previous solution shifted by one step (the reference's warm start
  * self.oa / self.odelta_v, :108-110, :491-498), rollout + objective + bounds, argmin, output map, new warm start.
  * Nothing per-rollout exists in memory: control (rollout r, step t) of ego e is a pure function of (seed, call, e, r, t):
- *   Philox4x32-10, counter = (t, r, e, call), key = seed  ->  128 bits;
- *   accel = fma(sigma_accel, z_a, warm_a[t]),  steer = fma(sigma_steer, z_d, warm_d[t])   in f32, where z = (sum of 8 of those
- *   bytes - 1020) / 209.02153 is a standardised Irwin-Hall variate (bounded near-normal, integer arithmetic => bit-identical to the
+ *   Philox4x32-10, counter = (t / 2, r, e, call), key = seed  ->  four 32-bit words = (accel, steer) of steps 2 (t/2), 2 (t/2) + 1;
+ *   accel = fma(sigma_accel, z_a, warm_a[t]),  steer = fma(sigma_steer, z_d, warm_d[t])   in f32, where z = (sum of the word's 4
+ *   bytes - 510) / 147.80054 is a standardised Irwin-Hall variate (bounded near-normal, integer arithmetic => bit-identical to the
  *   CPU restatement oracle/f1p_oracle.c:orc_kmpc_gen_controls); rollout 0 = the warm start itself, rollout 1 = all zero.
  * The bounds are applied by the rollout's projection exactly as for streamed controls, so
  *   f1p_kmpc_gen_controls_dev + f1p_kmpc_shoot_dev  ==  f1p_kmpc_plan_dev   bit for bit (tests/test_gpu_kmpc_gen.py).

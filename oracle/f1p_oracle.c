@@ -660,7 +660,8 @@ ORC_API void orc_kmpc_shoot_batch(const double* x0, const double* ref, const flo
 /* In-kernel control generation of the shooting MPC (BUILD-DEFINED sampler; the reference solves a QP) */
 /* Restates csrc/k_kmpc.hip SrcGen bit for bit: Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11: the      */
 /* published round function and Weyl key schedule) on counter (t, rollout, ego, call) with key = seed;      */
-/* each control = fma(sigma, z, warm) in f32 with z = (sum of 8 random bytes - 1020) * (1/209.02153f), a     */
+/* (t / 2, rollout, ego, call): words 0 / 1 = (accel, steer) of the even step, words 2 / 3 of the odd one;   */
+/* each control = fma(sigma, z, warm) in f32 with z = (sum of the word's 4 bytes - 510) * (1/147.80054f), a  */
 /* standardised Irwin-Hall variate -- integer byte sums, so there is no library transcendental between the */
 /* two implementations.  Rollout 0 = the warm start, rollout 1 = zeros.                                     */
 /* ------------------------------------------------------------------------------------------------ */
@@ -686,11 +687,11 @@ ORC_API void orc_kmpc_gen_controls(uint64_t seed, uint32_t call, int e, int T, i
     for (int t = 0; t < T; ++t) {
         const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
         for (int r = 0; r < R; ++r) {
-            const uint32_t ctr[4] = {(uint32_t)t, (uint32_t)r, (uint32_t)e, call};
+            const uint32_t ctr[4] = {(uint32_t)(t >> 1), (uint32_t)r, (uint32_t)e, call};
             uint32_t x[4];
             orc_philox4x32_10(ctr, key, x);
-            const float za = ((float)(int)(orc_byte_sum(x[0]) + orc_byte_sum(x[1])) - 1020.0f) * 0.0047842013f;
-            const float zd = ((float)(int)(orc_byte_sum(x[2]) + orc_byte_sum(x[3])) - 1020.0f) * 0.0047842013f;
+            const float za = ((float)(int)orc_byte_sum(x[(t & 1) ? 2 : 0]) - 510.0f) * 0.0067658765f;
+            const float zd = ((float)(int)orc_byte_sum(x[(t & 1) ? 3 : 1]) - 510.0f) * 0.0067658765f;
             float a = fmaf(sa, za, wa), d = fmaf(sd, zd, wd);
             if (r == 0) { a = wa; d = wd; }
             else if (r == 1) { a = 0.0f; d = 0.0f; }
