@@ -249,7 +249,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -655,6 +655,15 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
     }
     F1P_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F1P_OK;
+}
+
+int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state) {
+    if (!ctx) return F1P_EINVAL;
+    if (mixed < 0 || mixed > 2) return set_error(ctx, F1P_EINVAL, "mixed must be 0 (all fp64), 1 (f32 filter from 256 egos) or 2 (f32 filter always)");
+    ctx->lattice_mixed = mixed;
+    ctx->d_dbg_lat_cost32 = d_cost32;
+    ctx->d_dbg_lat_state = d_state;
     return F1P_OK;
 }
 

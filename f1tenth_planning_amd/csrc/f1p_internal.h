@@ -55,6 +55,13 @@ struct f1p_ctx {
     char* d_bb_scratch = nullptr;
     size_t bb_scratch_bytes = 0;
 
+    // mixed-precision lattice schedule (f32 filter + fp64 decision): 0 = off, 1 = from F1P_MIX_MIN_EGOS egos (default), 2 = always
+    int lattice_mixed = 1;
+    char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
+    size_t mix_scratch_bytes = 0;
+    float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
+    int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
+
     // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

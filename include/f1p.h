@@ -269,6 +269,16 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
                          int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                          int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
                          double* d_best_traj, double* d_all_cost, double* d_all_traj);
+/* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
+ *   mixed = 1 (default): batches of >= 256 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
+ *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
+ *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
+ *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;
+ *   mixed = 2: the same for any batch size;  mixed = 0: all fp64 (with cfg.prune: branch and bound).
+ * d_cost32 [E][C] f32 and d_state [E][C] i32 (device pointers, nullable) receive the filter's costs and states
+ * (0 free, 1 hit, 2 unsure, 3 infeasible) of the following launches: the hook the tests calibrate the margins with. */
+int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state);
+
 /* Re-generate candidate `cand_idx[e]` of each ego and track it: the "emit" half of plan(), used after a
  * cross-rank argmin when one ego's candidates are sharded over several GPUs. */
 int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,
