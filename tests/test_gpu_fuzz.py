@@ -1,7 +1,7 @@
-"""Randomised configurations of the lattice planner against the oracle, exhaustive and branch-and-bound schedules alike: station
+"""Randomised configurations of the lattice planner against the oracle -- exhaustive, branch-and-bound and mixed-precision schedules alike: station
 counts 2..120, ragged goal grids (1..40 look-aheads x 1..40 widths, more than 256 candidates included), random weights, shifts,
 tracker parameters, maps with different resolutions, inflation, previous trajectories, both generators.  Indices and status exact,
-steering / trajectory within the north_star tolerances; the two schedules bit-identical to each other."""
+steering / trajectory within the north_star tolerances; the three schedules bit-identical to each other."""
 import os
 
 import numpy as np
@@ -48,10 +48,15 @@ def test_random_lattice_configurations(ctx, orc, seed):
     prev = None
     if seed % 3 == 1 and S - n_shift - n_cull > 0:
         prev = rng.normal(0, 0.3, (E, S))
+    ctx.lattice_set_mode(0)                                    # all fp64: exhaustive and branch and bound
     a = ctx.lattice_plan(poses, full, prev_theta=prev)
     b = ctx.lattice_plan(poses, bb, prev_theta=prev)
+    ctx.lattice_set_mode(2)                                    # f32 filter + fp64 decision, whatever the batch size
+    m = ctx.lattice_plan(poses, full, prev_theta=prev)
+    ctx.lattice_set_mode(1)
     for k in a:
-        np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=f"schedules differ in {k}")
+        np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=f"branch and bound differs in {k}")
+        np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"mixed precision differs in {k}")
     if seed % 2:                                               # the oracle sees the un-inflated image: compare without inflation
         ctx.inflate_grid(0.0)
         a = ctx.lattice_plan(poses, full, prev_theta=prev)

@@ -226,7 +226,9 @@ def _same(a, b):
 def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
     """cfg.prune = 1 skips the station loop of candidates whose cost lower bound exceeds the best cost so far; index, cost,
     status, steering, speed and trajectory must not change in any bit -- with collisions, with the similarity term, with more
-    than 256 candidates, on a candidate shard, with blocked egos, host goals, NaN goals and a NaN previous trajectory."""
+    than 256 candidates, on a candidate shard, with blocked egos, host goals, NaN goals and a NaN previous trajectory.
+    (mode 0 = all fp64: from 256 egos the default schedule is the mixed-precision one, tests/test_gpu_lattice_mixed.py)"""
+    ctx.lattice_set_mode(0)
     rl, img, origin = scene
     import copy
     for n_cand, E, seed, sig in ((256, 1024, 5, 0.3), (512, 256, 6, 0.3), (256, 512, 7, 0.9), (48, 128, 8, 0.3)):
@@ -275,6 +277,7 @@ def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
     # a negative weight disables the bound (falls back to the exhaustive kernel): still the same answer
     kw = dict(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=37, weights=(1.5, -0.5, 0.0, 0.0), check_collision=True)
     _same(ctx.lattice_plan(poses, _abi.lattice_cfg(**kw), goals=goals), ctx.lattice_plan(poses, _abi.lattice_cfg(prune=True, **kw), goals=goals))
+    ctx.lattice_set_mode(1)
 
 
 def test_clothoid_class_and_sample_traj_on_the_gpu(orc):
@@ -342,6 +345,7 @@ def test_long_station_counts_fit_the_lds_or_fail_cleanly(ctx, orc, scene):
     must fall back to the single-kernel schedule instead of failing at launch -- with the same outputs as the exhaustive kernel"""
     rl, img, origin = scene
     poses = synth.make_egos(rl, 260, seed=12)                           # >= 256 egos: the two-kernel schedule is the default
+    ctx.lattice_set_mode(0)
     for S in (400, 1000):
         full = synth.bench_lattice_cfg(n_cand=32, n_stations=S)
         bb = synth.bench_lattice_cfg(n_cand=32, n_stations=S, prune=True)
@@ -349,6 +353,7 @@ def test_long_station_counts_fit_the_lds_or_fail_cleanly(ctx, orc, scene):
     one = ctx.lattice_plan(poses[:3], synth.bench_lattice_cfg(n_cand=32, n_stations=1000), want_all=True)      # materialised rows at S = 1000
     want = orc.lattice_plan_batch(poses[:3], rl, synth.bench_lattice_cfg(n_cand=32, n_stations=1000), grid=(img, 0.058, origin[0], origin[1], 206))
     np.testing.assert_array_equal(one["best_idx"], want["best_idx"])
+    ctx.lattice_set_mode(1)
 
 
 def test_g1_fit_branch_against_the_independent_solver(ctx, golden):

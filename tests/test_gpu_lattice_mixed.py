@@ -1,0 +1,116 @@
+"""The mixed-precision lattice schedule (f32 filter over every candidate-trajectory-step, fp64 decision; csrc/k_lattice.hip
+k_lattice_filter / _refine / _select): outputs bit-identical to the all-fp64 kernel, and the filter's own claims -- its cost
+bracket contains the fp64 cost, FREE candidates are collision-free in fp64, HIT candidates collide in fp64 -- checked through the
+debug hook of f1p_lattice_set_mode."""
+import copy
+
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+NAMES = ("steer", "speed", "best_idx", "best_cost", "status", "near_idx", "best_traj")
+
+
+@pytest.fixture(scope="module")
+def scene():
+    rl = synth.make_raceline(seed=0)
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+    return rl, img, origin
+
+
+@pytest.fixture(scope="module")
+def ctx(scene):
+    from f1tenth_planning_amd.runtime import Context
+    rl, img, origin = scene
+    with Context(0) as c:
+        c.set_waypoints(rl); c.set_grid(img, 0.058, origin, 206)
+        yield c
+
+
+def _both(ctx, poses, cfg, **kw):
+    ctx.lattice_set_mode(0); a = ctx.lattice_plan(poses, cfg, **kw)
+    ctx.lattice_set_mode(2); b = ctx.lattice_plan(poses, cfg, **kw)
+    ctx.lattice_set_mode(1)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        np.testing.assert_array_equal(b[k], a[k], err_msg=k)
+    return a
+
+
+def test_bit_identical_to_the_all_fp64_kernel(ctx, scene):
+    rl, img, origin = scene
+    rng = np.random.default_rng(2)
+    for n_cand, S, E, sigma in ((256, 50, 700, 0.3), (256, 50, 500, 0.9), (512, 50, 300, 0.5), (64, 23, 300, 0.4), (1024, 30, 40, 0.4), (32, 100, 260, 0.6)):
+        cfg = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=S)
+        poses = synth.make_egos(rl, E, seed=n_cand + S, pos_sigma=sigma)
+        poses[0, :2] += 400.0; poses[1, 2] += np.pi; poses[2, :2] += [1.5, 1.5]          # off the map / backwards / in the wall
+        a = _both(ctx, poses, cfg)
+        assert a["status"][0] == _abi.ST_ALL_BLOCKED and (a["status"] == 0).mean() > 0.3
+        prev = a["best_traj"][:, :, 2] + rng.normal(0, 0.05, (E, S))                       # similarity term
+        _both(ctx, poses, cfg, prev_theta=prev)
+        prev[5, 7] = np.nan; prev[6] = np.nan                                              # NaN costs: np.argmin takes the first NaN
+        _both(ctx, poses, cfg, prev_theta=prev)
+        sh = copy.copy(cfg); sh.cand_begin, sh.cand_count = n_cand // 4, n_cand // 2        # a candidate shard (the multi-GPU split)
+        _both(ctx, poses, sh)
+    # tight goals (sharp clothoids: the f32 one-piece series and the 16-node rule reach their limits -> UNSURE -> fp64 decides)
+    tight = _abi.lattice_cfg(lookaheads=np.linspace(0.3, 1.0, 8), widths=np.linspace(-1.5, 1.5, 16), n_stations=40, weights=(0.25,) * 4)
+    _both(ctx, synth.make_egos(rl, 300, seed=5, pos_sigma=0.5, yaw_sigma=0.6), tight)
+    # weights: one term only, zero, negative, huge
+    poses = synth.make_egos(rl, 280, seed=8)
+    for w in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 0), (1.5, -0.5, 0.0, 0.0), (1e6, 1e-6, 1.0, 0.0)):
+        cfgw = _abi.lattice_cfg(lookaheads=np.linspace(0.6, 3.0, 8), widths=np.linspace(-1, 1, 9), n_stations=37, weights=tuple(float(v) for v in w))
+        _both(ctx, poses, cfgw)
+    # host goals incl. NaN rows, goals behind the ego and at the fit's +-pi seams
+    E, C = 270, 64
+    goals = np.stack([np.column_stack([rng.uniform(-1.0, 3.0, C), rng.uniform(-1.5, 1.5, C), rng.uniform(-np.pi, np.pi, C)]) for _ in range(E)])
+    goals[:, 5] = np.nan; goals[3] = np.nan; goals[:, 6] = [-1.0, 1e-9, 0.3]; goals[:, 7] = [1.0, 1.0, -np.pi + 1e-7]; goals[:, 8] = 0.0
+    cfgh = _abi.lattice_cfg(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=50, weights=(0.25,) * 4)
+    _both(ctx, synth.make_egos(rl, E, seed=9), cfgh, goals=goals)
+    # no grid / collision check off
+    nc = synth.bench_lattice_cfg(n_cand=128, n_stations=50); nc.check_collision = 0
+    _both(ctx, synth.make_egos(rl, 300, seed=10), nc)
+
+
+def test_other_map_resolutions_and_inflation(scene):
+    from f1tenth_planning_amd.runtime import Context
+    rl, _, _ = scene
+    with Context(0) as c:
+        c.set_waypoints(rl)
+        for res, size in ((0.03, (3600, 3600)), (0.11, (1100, 1100))):
+            img, origin = synth.make_grid(rl[:, :2], size=size, resolution=res)
+            c.set_grid(img, res, origin, 206)
+            for infl in (0.0, 0.2):
+                c.inflate_grid(infl)
+                _both(c, synth.make_egos(rl, 400, seed=int(res * 1000), pos_sigma=0.6), synth.bench_lattice_cfg(n_cand=128, n_stations=50))
+
+
+def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
+    """the exactness argument's two premises, measured: |cost32 - cost64| well inside the margin, and no wrong certain state"""
+    rl, img, origin = scene
+    E, C, S = 1024, 256, 50
+    worst = 0.0
+    for sigma, seed in ((0.3, 1), (0.8, 2)):
+        cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+        poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sigma)
+        d_poses = ctx.to_device(poses)
+        out = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
+        d_all, d_c32, d_st = ctx.alloc(8 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+        ctx.lattice_set_mode(0)
+        ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_all_cost=d_all)
+        c64 = d_all.download(np.float64, (E, C))
+        ctx.lattice_set_mode(2, d_c32, d_st)
+        ctx.lattice_plan_dev(d_poses, E, cfg, *out)
+        ctx.lattice_set_mode(1)
+        c32 = d_c32.download(np.float32, (E, C)).astype(np.float64); st = d_st.download(np.int32, (E, C))
+        fin = np.isfinite(c64)
+        assert not ((st == 0) & ~fin).any(), "a FREE candidate collides in fp64"
+        assert not ((st == 1) & fin).any(), "a HIT candidate is collision-free in fp64"
+        assert not ((st == 3) & fin).any(), "a BAD candidate is feasible in fp64"
+        both = fin & (st < 3) & np.isfinite(c32)
+        worst = max(worst, float((np.abs(c32 - c64)[both] / np.abs(c64[both])).max()))
+        assert 0.02 < ((st == 2) | (st >= 4)).mean() < 0.25                        # the uncertain share stays small
+        for b in out + [d_all, d_c32, d_st, d_poses]:
+            b.free()
+    assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
