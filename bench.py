@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--kmpc-f64", action="store_true", help="kmpc: plain fp64 evaluation instead of the f32 filter + fp64 refinement")
     ap.add_argument("--kmpc-cost", action="store_true", help="kmpc: also request best_cost (forces an fp64 re-evaluation of every winner)")
     ap.add_argument("--kmpc-stream", action="store_true", help="kmpc: controls streamed from an HBM buffer instead of generated in registers")
+    ap.add_argument("--all-fp64", action="store_true", help="lattice: time the all-fp64 kernel (f1p_lattice_set_mode 0) instead of the default f32-filter / fp64-decision schedule")
     ap.add_argument("--prune", action="store_true", help="lattice: time the branch-and-bound kernel as the step (default: exhaustive; the default run reports branch and bound beside it)")
     ap.add_argument("--rollouts", type=int, default=512)
     ap.add_argument("--horizon", type=int, default=30)
@@ -385,6 +386,8 @@ def main_lattice(args):
     ctx = rk.open_context()
     ctx.set_waypoints(rl)
     ctx.set_grid(img, res, origin, 206)
+    if args.all_fp64 or args.prune:
+        ctx.lattice_set_mode(0)
     rk.init()
     materialised = args.workload == "lattice-materialised"
     secondary = not args.no_secondary and not materialised and args.generator == "clothoid"
@@ -418,12 +421,16 @@ def main_lattice(args):
         q50, q95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True))
         r50, r95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=False, reuse_outputs=True))
         cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
+        ctx.lattice_set_mode(0)
         b50, b95 = percentiles(lambda: ctx.lattice_plan(poses, cfg_bb, want_traj=True, reuse_outputs=True))
+        f50, f95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
+        ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
         lat = {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
                "includes": "H2D poses + kernel + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays",
                "pageable_host_arrays": {"p50_ms": q50, "p95_ms": q95},
                "without_best_traj": {"p50_ms": r50, "p95_ms": r95},
-               "branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 (the planner classes' default): bit-identical outputs"}}
+               "all_fp64": {"p50_ms": f50, "p95_ms": f95},
+               "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"}}
 
     cs = None
     if cand_sharded:
@@ -444,33 +451,51 @@ def main_lattice(args):
         steer = d_steer.download(np.float64, (E,)); bidx = d_bidx.download(np.int32, (E,)); status = d_status.download(np.int32, (E,))
         ref_cost = d_bcost.download(np.float64, (E,)); ref_traj = d_traj.download(np.float64, (E, S, 4))
 
-    # the same plan with branch and bound over the candidates (cfg.prune): bit-identical outputs, fewer station loops.
-    # Reported beside `value`, which stays the exhaustive evaluation of every candidate-trajectory-step.
-    bnb = None
-    if rank == 0 and not materialised and not args.prune and args.generator == "clothoid" and not cand_sharded:
+    # The same plan by the other schedules, every one checked bit for bit against the timed plan's outputs:
+    #   all_fp64          the plain kernel (one fp64 thread per candidate; round 1's headline kernel)
+    #   branch_and_bound  all fp64 with cfg.prune = 1 (station loops skipped while a cost lower bound exceeds the best so far)
+    # `value` is the default schedule: f32 filter over EVERY candidate-trajectory-step + fp64 decision (k_lattice_filter / _refine /
+    # _select), or --all-fp64 / --prune.
+    bnb = fp64 = None
+    if rank == 0 and not materialised and args.generator == "clothoid" and not cand_sharded:
         import copy
-        cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
-        b_steer, b_speed, b_idx, b_cost, b_status, b_near, b_traj = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E),
-                                                                      ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
+        alt = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
 
-        def bb_step():
-            ctx.lattice_plan_dev(d_poses, E, cfg_bb, b_steer, b_speed, b_idx, b_cost, b_status, b_near, b_traj)
-        for _ in range(args.warmup):
-            bb_step()
-        ctx.sync()
-        ctx.timer_begin()
-        for _ in range(args.steps):
-            bb_step()
-        bb_ms = ctx.timer_end() / args.steps
-        same = bool((b_idx.download(np.int32, (E,)) == bidx).all() and
-                    np.array_equal(b_cost.download(np.float64, (E,)), ref_cost, equal_nan=True) and
-                    np.array_equal(b_steer.download(np.float64, (E,)), steer) and
-                    np.array_equal(b_traj.download(np.float64, (E, S, 4)), ref_traj))
-        bnb = {"kernel_ms": bb_ms, "candidate_steps_per_s_equivalent": float(E) * C * S / (bb_ms * 1e-3),
-               "outputs_bit_identical_to_exhaustive": same,
-               "note": "cfg.prune = 1: candidates are sorted by a lower bound of their cost after the fit; a station loop runs only while the bound does not exceed the best cost found"}
-        for b in (b_steer, b_speed, b_idx, b_cost, b_status, b_near, b_traj):
+        def other(cfg_x, mode):
+            ctx.lattice_set_mode(mode)
+            for _ in range(args.warmup):
+                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt)
+            ctx.sync()
+            ctx.timer_begin()
+            for _ in range(args.steps):
+                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt)
+            ms = ctx.timer_end() / args.steps
+            same = bool((alt[2].download(np.int32, (E,)) == bidx).all() and
+                        np.array_equal(alt[3].download(np.float64, (E,)), ref_cost, equal_nan=True) and
+                        np.array_equal(alt[0].download(np.float64, (E,)), steer) and
+                        np.array_equal(alt[6].download(np.float64, (E, S, 4)), ref_traj))
+            return {"kernel_ms": ms, "candidate_steps_per_s_equivalent": float(E) * C * S / (ms * 1e-3), "outputs_bit_identical_to_the_timed_plan": same}
+        cfg_ex = copy.copy(cfg); cfg_ex.prune = 0
+        cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
+        fp64 = other(cfg_ex, 0)
+        fp64["note"] = "f1p_lattice_set_mode(0): every candidate-step in fp64, one thread per candidate (k_lattice)"
+        bnb = other(cfg_bb, 0)
+        bnb["note"] = "all fp64 + cfg.prune = 1: candidates sorted by a lower bound of their cost after the fit; a station loop runs only while the bound does not exceed the best cost found"
+        ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
+        for b in alt:
             b.free()
+
+    # per-kernel durations of the default schedule (HIP events between its three kernels, outside the timed region)
+    mixed_ms = None
+    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 256:
+        ctx.lattice_profile(True)
+        acc = np.zeros(3)
+        for _ in range(max(10, min(args.steps, 50))):
+            step()
+            acc += np.array(ctx.lattice_profile(True, read=True))
+        ctx.lattice_profile(False)
+        acc /= max(10, min(args.steps, 50))
+        mixed_ms = {"k_lattice_filter": float(acc[0]), "k_lattice_refine": float(acc[1]), "k_lattice_select": float(acc[2])}
 
     selftest = kmpc_c4 = None
     if secondary and not cand_sharded:
@@ -487,13 +512,15 @@ def main_lattice(args):
         abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0])
         if materialised:
             abytes += E * C * S * 32 + E * C * 8      # every candidate's rows (x, y, theta, |kappa|) + its cost, written once
-        achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9
-        pmc = load_pmc({"egos": E, "cands": C, "stations": S, "workload": args.workload, "generator": args.generator})
-        same_cfg = bool(pmc and not cand_sharded and not args.prune)
+        dom_ms = mixed_ms["k_lattice_filter"] if mixed_ms else kernel_ms          # the dominant kernel's own average duration
+        achieved_gbs = abytes / (dom_ms * 1e-3) / 1e9
+        pmc = load_pmc({"egos": E, "cands": C, "stations": S, "workload": args.workload, "generator": args.generator,
+                        "schedule": "all_fp64" if args.all_fp64 else ("bnb" if args.prune else "mixed")})
+        same_cfg = bool(pmc and not cand_sharded)
         valu = None
         if same_cfg and pmc.get("SQ_INSTS_VALU") and pmc.get("waves"):
             per_cand = pmc["SQ_INSTS_VALU"] / pmc["waves"]            # wave-instructions per wave = lane-instructions per candidate
-            valu_tlanes = per_cand * E * C / (kernel_ms * 1e-3) / 1e12
+            valu_tlanes = per_cand * E * C / (dom_ms * 1e-3) / 1e12
             valu = {"achieved": valu_tlanes, "peak": FP64_VALU_PEAK_TLANES, "unit": "T lane-instr/s", "frac": valu_tlanes / FP64_VALU_PEAK_TLANES,
                     "sustained_peak": FP64_VALU_SUSTAINED_TLANES, "frac_of_sustained": valu_tlanes / FP64_VALU_SUSTAINED_TLANES,
                     "valu_instr_per_candidate": per_cand, "source": pmc["source"]}
@@ -505,7 +532,8 @@ def main_lattice(args):
             "metric": "candidate-trajectory-steps/sec per GPU; p50 plan() latency @4096 egos",
             "value": value, "unit": "candidate-trajectory-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if cand_sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if cand_sharded else "weak", "vs_baseline": None,
+            "dtype": "f64" if (args.all_fp64 or args.prune or materialised or args.generator != "clothoid") else "f32 filter + f64 decision", "data": "synthetic",
             "config": {"workload": (f"batched lattice, candidate-sharded: {E} egos x {C} candidates x {S} stations, candidates split over {world} GPU(s) + RCCL all-reduce(min)"
                                     if cand_sharded else
                                     f"batched lattice{' (all_traj materialised)' if materialised else ''}: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[{3 if world == 8 and E == 4096 else 2}])"),
@@ -518,6 +546,9 @@ def main_lattice(args):
             "per_gpu_value": value / (1 if cand_sharded else world),
             "pcie_inclusive_value": pcie_value,
             "plan_latency_host_boundary": lat,
+            "schedule": ("all fp64" + (" + branch and bound" if args.prune else "")) if (args.all_fp64 or args.prune) else
+                        "f32 filter over every candidate-step + fp64 decision (outputs bit-identical to the all-fp64 kernel)",
+            "all_fp64": fp64,
             "branch_and_bound": bnb,
             "candidate_sharded": cs,
             "exchange_selftest": selftest,
@@ -526,9 +557,9 @@ def main_lattice(args):
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": pmc["source"] if traffic is not None else None,
                          "kernel": pmc["kernel"] if pmc else "k_lattice",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                         "kernel_ms": dom_ms, "plan_ms": kernel_ms, "kernels_ms": mixed_ms, "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_candidate_step": abytes / (E * C * S),
-                         "note": "fused kernel is fp64-VALU/transcendental bound by construction; HBM fraction is tiny",
+                         "note": "the planning kernels are VALU / transcendental bound by construction (0.14 B per candidate-step); the HBM fraction is tiny and reported as such",
                          "valu_fp64": valu},
             "blocked_egos": None if status is None else int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
@@ -739,7 +770,7 @@ def main_kmpc(args):
                           "controls": "streamed from HBM (f32 [E][T][2][R])" if stream else "generated in the kernel (Philox4x32-10 around the device-resident warm start)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_kmpc_shoot",
-                            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
+                            "kernel_ms": dom_ms, "plan_ms": kernel_ms, "kernels_ms": mixed_ms, "algorithmic_bytes_per_launch": abytes,
                             "bytes_per_rollout_step": abytes / (E * R * T),
                             "note": "below ~2048 egos per GPU the 123 KB-per-ego control buffer is Infinity-Cache resident across launches: "
                                     "the figure is then a cache-stream rate, not HBM evidence"}}

@@ -256,6 +256,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto& ev : ctx->ev_chunk) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->ev_prof) if (ev) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->rccl_lib) dlclose(ctx->rccl_lib);
     delete ctx;
@@ -664,6 +665,20 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
     ctx->lattice_mixed = mixed;
     ctx->d_dbg_lat_cost32 = d_cost32;
     ctx->d_dbg_lat_state = d_state;
+    return F1P_OK;
+}
+
+int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[3]) {
+    F1P_ENTER(ctx);
+    if (kernel_ms) {
+        if (!ctx->lattice_profile || !ctx->lattice_profile_valid) return set_error(ctx, F1P_ESTATE, "no profiled mixed-schedule plan has run");
+        F1P_HIP(ctx, hipEventSynchronize(ctx->ev_prof[3]));
+        for (int k = 0; k < 3; ++k) F1P_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_prof[k], ctx->ev_prof[k + 1]));
+    }
+    if (enable && !ctx->ev_prof[0])
+        for (auto& ev : ctx->ev_prof) F1P_HIP(ctx, hipEventCreate(&ev));
+    ctx->lattice_profile = enable != 0;
+    if (!enable) ctx->lattice_profile_valid = false;
     return F1P_OK;
 }
 

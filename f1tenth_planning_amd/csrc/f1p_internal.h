@@ -59,6 +59,8 @@ struct f1p_ctx {
     int lattice_mixed = 1;
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;
+    bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
+    hipEvent_t ev_prof[4] = {};
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
     int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
 

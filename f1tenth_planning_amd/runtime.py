@@ -312,6 +312,13 @@ class Context:
         self._check(self.lib.f1p_lattice_set_mode(self.h, int(mixed), None if d_cost32 is None else d_cost32.ptr,
                                                   None if d_state is None else d_state.ptr))
 
+    def lattice_profile(self, enable=True, read=False):
+        """HIP-event timing between the three kernels of the mixed schedule; read=True returns (filter, refine, select) ms of the
+        last profiled plan"""
+        ms = (C.c_float * 3)()
+        self._check(self.lib.f1p_lattice_profile(self.h, 1 if enable else 0, ms if read else None))
+        return tuple(ms) if read else None
+
     def lattice_emit_dev(self, d_poses, E, cfg: LatticeCfg, d_cand_idx, d_cand_cost, d_steer, d_speed, d_status=None,
                          d_near_idx=None, d_best_traj=None, d_goals=None):
         p = lambda b: None if b is None else b.ptr   # noqa: E731

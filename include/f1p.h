@@ -279,6 +279,11 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
  * (0 free, 1 hit, 2 unsure, 3 infeasible) of the following launches: the hook the tests calibrate the margins with. */
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state);
 
+/* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream between k_lattice_filter,
+ * k_lattice_refine and k_lattice_select of every following plan; kernel_ms (nullable) receives the three durations of the LAST
+ * profiled plan (synchronises on it).  bench.py takes the dominant kernel's duration for `roofline` from here. */
+int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[3]);
+
 /* Re-generate candidate `cand_idx[e]` of each ego and track it: the "emit" half of plan(), used after a
  * cross-rank argmin when one ego's candidates are sharded over several GPUs. */
 int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,

@@ -68,6 +68,13 @@ def test_bit_identical_to_the_all_fp64_kernel(ctx, scene):
     goals[:, 5] = np.nan; goals[3] = np.nan; goals[:, 6] = [-1.0, 1e-9, 0.3]; goals[:, 7] = [1.0, 1.0, -np.pi + 1e-7]; goals[:, 8] = 0.0
     cfgh = _abi.lattice_cfg(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=50, weights=(0.25,) * 4)
     _both(ctx, synth.make_egos(rl, E, seed=9), cfgh, goals=goals)
+    # the independent solver's goal set (behind the ego, |theta| up to pi, normalisation seams): several model steps and the panel
+    # rule inside the refinement's cooperative fit
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g14_clothoid_g1.npz"))["goals"]
+    G = np.concatenate([g, g[:1728 - len(g)]])[:1728].reshape(27, 64, 3) * np.array([1.0, 1.0, 1.0])
+    big = G.copy(); big[:, :, :2] *= 40.0                                                  # long clothoids: large phase excursions
+    for goals_x in (G, big):
+        _both(ctx, synth.make_egos(rl, 27, seed=11), cfgh, goals=goals_x)
     # no grid / collision check off
     nc = synth.bench_lattice_cfg(n_cand=128, n_stations=50); nc.check_collision = 0
     _both(ctx, synth.make_egos(rl, 300, seed=10), nc)

@@ -1,17 +1,21 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root:  bash tools/profile_gpu.sh <tag> [bench args...]
-# Kernel trace + separate PMC passes (never combined with other trace domains), outputs under gpurun_out/<tag>_*.
+# Run ON THE GPU BOX (via gpurun) from the repo root:  bash tools/profile_gpu.sh <tag> <headline-kernel-substring> <schedule> [bench args...]
+# Kernel trace + separate PMC passes (never combined with other trace domains), outputs under gpurun_out/<tag>_*; the markdown
+# summary and the machine-readable <tag>_pmc.json (parsed by bench.py at run time) are what gets copied into profiles/.
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; HEAD=${2:-k_lattice_filter}; SCHED=${3:-mixed}; shift 3 || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline --latency-iters 0 $*"
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --latency-iters 0 $*"
+export TMPDIR=/tmp
+cd $ROOT
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o run -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/${TAG}_pmc_$N -o run -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_$N.log 2>&1 || echo "pmc pass $C failed (see log)"
+  rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/${TAG}_pmc_$N -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_$N.log 2>&1 || echo "pmc pass $C failed (see log)"
 done
-cd $ROOT && python3 tools/prof_summary.py $OUT/${TAG}_trace $OUT/${TAG}_pmc_* > $OUT/${TAG}_summary.md 2>$OUT/${TAG}_summary.err
+python3 tools/prof_summary.py --json $OUT/${TAG}_pmc.json --headline "$HEAD" \
+    --config "{\"egos\": 4096, \"cands\": 256, \"stations\": 50, \"workload\": \"lattice\", \"generator\": \"clothoid\", \"schedule\": \"$SCHED\"}" \
+    $OUT/${TAG}_trace $OUT/${TAG}_pmc_* > $OUT/${TAG}_summary.md 2>$OUT/${TAG}_summary.err
 grep -h '"metric"' $OUT/${TAG}_trace.log | head -1 > $OUT/${TAG}_bench_line.json
-cat $OUT/${TAG}_summary.md | head -60
+head -40 $OUT/${TAG}_summary.md | cut -c1-220
