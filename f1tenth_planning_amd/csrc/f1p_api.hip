@@ -249,7 +249,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -665,6 +665,13 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
     ctx->lattice_mixed = mixed;
     ctx->d_dbg_lat_cost32 = d_cost32;
     ctx->d_dbg_lat_state = d_state;
+    return F1P_OK;
+}
+
+int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups) {
+    if (!ctx) return F1P_EINVAL;
+    if (groups < 0 || groups > 16) return set_error(ctx, F1P_EINVAL, "groups must be in [0, 16]");
+    ctx->lattice_split = groups;
     return F1P_OK;
 }
 

@@ -64,6 +64,11 @@ struct f1p_ctx {
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
     int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
 
+    // candidate slices of one ego over several workgroups (few egos, many candidates): partial winners + tickets
+    char* d_split_scratch = nullptr;
+    size_t split_scratch_bytes = 0;
+    int lattice_split = 0;             // 0 = automatic, > 0 forces the number of workgroups per ego (tests, A/B runs)
+
     // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -312,6 +312,10 @@ class Context:
         self._check(self.lib.f1p_lattice_set_mode(self.h, int(mixed), None if d_cost32 is None else d_cost32.ptr,
                                                   None if d_state is None else d_state.ptr))
 
+    def lattice_set_split(self, groups=0):
+        """workgroups per ego of the single-kernel lattice schedules (0 = automatic)"""
+        self._check(self.lib.f1p_lattice_set_split(self.h, int(groups)))
+
     def lattice_profile(self, enable=True, read=False):
         """HIP-event timing between the three kernels of the mixed schedule; read=True returns (filter, refine, select) ms of the
         last profiled plan"""

@@ -279,6 +279,11 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
  * (0 free, 1 hit, 2 unsure, 3 infeasible) of the following launches: the hook the tests calibrate the margins with. */
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state);
 
+/* Workgroups per ego of the single-kernel schedules: 0 = automatic (with fewer egos than half the CUs and more than 256
+ * candidates -- BASELINE configs[1], one ego x 512 candidates -- each workgroup evaluates a slice of 256 candidates and the last
+ * one to finish merges the partial winners, re-emits and tracks: no second launch); n > 0 forces n slices (tests, A/B runs). */
+int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
+
 /* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream between k_lattice_filter,
  * k_lattice_refine and k_lattice_select of every following plan; kernel_ms (nullable) receives the three durations of the LAST
  * profiled plan (synchronises on it).  bench.py takes the dominant kernel's duration for `roofline` from here. */

@@ -369,3 +369,29 @@ def test_g1_fit_branch_against_the_independent_solver(ctx, golden):
         assert (np.abs(got[sel] - g[name][sel]) / scale).max() < 1e-9, name
     for i in np.nonzero(g["ambiguous"])[0]:
         assert abs(L[i] - g["L"][i]) < 1e-9 and abs(abs(k0[i]) - abs(g["k0"][i])) < 1e-9
+
+
+def test_candidate_slices_over_several_workgroups(ctx, scene):
+    """BASELINE configs[1] shape (few egos, many candidates): each workgroup evaluates a slice, the last one merges (split_merge).
+    Every output must equal the one-workgroup-per-ego plan bit for bit -- exhaustive and branch-and-bound, plans and shards."""
+    import copy
+    rl, img, origin = scene
+    for E, n_cand, S in ((1, 512, 50), (3, 1024, 30), (7, 512, 64), (5, 256, 50), (2, 48, 20)):
+        poses = synth.make_egos(rl, E, seed=E + n_cand, pos_sigma=0.4)
+        if E > 2:
+            poses[1, :2] += 300.0                                    # an ego with nothing feasible
+        for prune in (False, True):
+            cfg = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=S, prune=prune) if n_cand % 16 == 0 else None
+            ctx.lattice_set_split(1)
+            one = ctx.lattice_plan(poses, cfg)
+            for groups in (0, 2, 3, 8):
+                ctx.lattice_set_split(groups)
+                many = ctx.lattice_plan(poses, cfg)
+                for k in one:
+                    np.testing.assert_array_equal(many[k], one[k], err_msg=f"{k} E={E} C={n_cand} prune={prune} groups={groups}")
+                sh = copy.copy(cfg); sh.cand_begin, sh.cand_count = 32, n_cand - 40       # a shard, evaluated in slices
+                ctx.lattice_set_split(1); a = ctx.lattice_plan(poses, sh)
+                ctx.lattice_set_split(groups); b = ctx.lattice_plan(poses, sh)
+                for k in a:
+                    np.testing.assert_array_equal(b[k], a[k], err_msg=f"shard {k}")
+    ctx.lattice_set_split(0)

@@ -29,3 +29,9 @@ lp.configure(lookahead_distances=np.linspace(0.6, 3.0, 16), widths=np.linspace(-
              weights=(0.25, 0.25, 0.25, 0.25))
 lp.set_map(img, 0.058, origin, occupied_thresh=0.2)
 print("lattice, 1 vehicle x 512 candidates x 50 (configs[1]): p50 %.3f ms  p95 %.3f ms" % p50(lambda: lp.plan(pose[0], pose[1], pose[2], pose[3])))
+ctx = lp._context()
+for label, groups, mode in (("one workgroup (round 1)", 1, 1), ("slices over workgroups, last one merges (default)", 0, 1), ("4 slices", 4, 1), ("8 slices", 8, 1),
+                            ("f32 filter + fp64 decision (3 kernels)", 0, 2)):
+    ctx.lattice_set_split(groups); ctx.lattice_set_mode(mode)
+    print("  %-52s p50 %.3f ms  p95 %.3f ms" % ((label,) + p50(lambda: lp.plan(pose[0], pose[1], pose[2], pose[3]))))
+ctx.lattice_set_split(0); ctx.lattice_set_mode(1)
