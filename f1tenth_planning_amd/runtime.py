@@ -11,6 +11,27 @@ from . import _abi
 from ._abi import F1PLibraryError, KmpcCfg, LatticeCfg  # noqa: F401
 
 
+import contextlib
+import os
+import sys
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner to the C stdout when a communicator is created (flushed at process exit, i.e. AFTER a
+    caller's own output -- bench.py must print exactly one JSON line): send fd 1 to stderr for the duration of the call."""
+    libc = C.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush(); libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class F1PError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libf1p error {code}: {msg}")
@@ -449,12 +470,16 @@ class Context:
     # ---- multi-GPU exchange step -----------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
-        self._check(self.lib.f1p_comm_unique_id(self.h, buf))
+        with _stdout_to_stderr():
+            rc = self.lib.f1p_comm_unique_id(self.h, buf)
+        self._check(rc)
         return bytes(buf)
 
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(uid)
-        self._check(self.lib.f1p_comm_init(self.h, buf, int(nranks), int(rank)))
+        with _stdout_to_stderr():
+            rc = self.lib.f1p_comm_init(self.h, buf, int(nranks), int(rank))
+        self._check(rc)
 
     def comm_info(self):
         """(nranks, rank) as the RCCL communicator reports them."""
