@@ -174,6 +174,7 @@ PROTOTYPES = {
     "f1p_set_grid": (C.c_int, [_P, _P, _I, _I, _D, _D, _D, _I]),
     "f1p_grid_distance_batch": (C.c_int, [_P, _P, _I]),
     "f1p_inflate_grid": (C.c_int, [_P, _D]),
+    "f1p_set_footprint": (C.c_int, [_P, _I, _P, _D]),
     "f1p_nearest_point_batch": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),
     "f1p_intersect_point_batch": (C.c_int, [_P, _P, _P, _I, _D, _I, _P, _P, _P, _P]),
     "f1p_pure_pursuit_batch": (C.c_int, [_P, _P, _I, _D, _D, _D, _P, _P, _P, _P, _P]),

@@ -408,7 +408,7 @@ int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncol
 static void drop_grid(f1p_ctx* ctx) {
     if (ctx->d_bits) (void)hipFree(ctx->d_bits);
     if (ctx->d_bits0) (void)hipFree(ctx->d_bits0);
-    ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0;
+    ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0; ctx->n_disc = 0;
 }
 
 int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
@@ -478,6 +478,19 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
     rc = launch_grid_edt(ctx, (int)cap, (uint32_t)thr, nullptr, nullptr, ctx->d_bits);
     if (rc == F1P_OK) ctx->inflate_radius = radius;
     return rc;
+}
+
+int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius) {
+    F1P_ENTER(ctx);
+    if (n_discs < 0 || n_discs > 4 || (n_discs > 0 && !offsets)) return set_error(ctx, F1P_EINVAL, "between 0 and 4 footprint discs are supported");
+    if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
+    for (int d = 0; d < n_discs; ++d)
+        if (!isfinite(offsets[d]) || fabs(offsets[d]) > 100.0) return set_error(ctx, F1P_EINVAL, "footprint offsets must be finite and within +-100 m");
+    int rc = f1p_inflate_grid(ctx, n_discs > 0 ? radius : 0.0);       // the disc radius becomes the dilation of the bitmap
+    if (rc) return rc;
+    ctx->n_disc = n_discs;
+    for (int d = 0; d < 4; ++d) ctx->disc_off[d] = d < n_discs ? offsets[d] : 0.0;
+    return F1P_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

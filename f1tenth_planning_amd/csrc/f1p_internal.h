@@ -29,6 +29,8 @@ struct f1p_ctx {
     uint32_t* d_bits = nullptr;    // active collision bitmap (the uploaded grid, or its inflation by f1p_inflate_grid)
     uint32_t* d_bits0 = nullptr;   // the grid as uploaded
     double inflate_radius = 0.0;
+    int n_disc = 0;                // oriented footprint: discs along the heading (0 = the station point only)
+    double disc_off[4] = {0, 0, 0, 0};
     int gw = 0, gh = 0, gwwords = 0;
     double res = 0, inv_res = 0, ox = 0, oy = 0;
 

@@ -60,6 +60,7 @@ class LatticePlanner():
         self._ctx = None
         self._map = None
         self._inflate = 0.0
+        self._foot = None
 
     # ---- plug-in API (lattice_planner.py:57-111) -------------------------------------------------------------
     def add_cost_function(self, func):
@@ -123,10 +124,26 @@ class LatticePlanner():
         occupied_below = int(np.ceil(255.0 * (1.0 - occupied_thresh)))      # v < 255 (1 - thresh)  <=>  p > thresh
         self._map = (np.ascontiguousarray(img), float(resolution), (float(origin[0]), float(origin[1])), occupied_below)
         self._inflate = float(inflate)
+        self._foot = None                                    # a new map clears the footprint (f1p_set_grid does)
         if self._ctx is not None:
             self._ctx.set_grid(*self._map)
             if self._inflate > 0.0:
                 self._ctx.inflate_grid(self._inflate)
+
+    def set_footprint(self, length=0.58, width=0.31, n_discs=3, center_offset=0.0):
+        """Oriented footprint collision test: cover the length x width rectangle (the reference's vehicle, kinematic_mpc.py:60-61)
+        whose centre sits `center_offset` metres ahead of the pose along its heading by n_discs equal discs, dilate the map by
+        their radius and test every station at the disc centres (f1p_set_footprint).  n_discs = 0 restores the point test.
+        Call after set_map / load_map."""
+        if n_discs <= 0:
+            self._foot = ((), 0.0)
+        else:
+            seg = length / n_discs
+            offsets = [center_offset - 0.5 * length + (k + 0.5) * seg for k in range(n_discs)]
+            self._foot = (tuple(offsets), float(np.hypot(0.5 * seg, 0.5 * width)))
+        if self._ctx is not None and self._map is not None:
+            self._ctx.set_footprint(*self._foot)
+        return self._foot
 
     def load_map(self, yaml_path, inflate=0.0):
         """Read a ROS map_server YAML + image (examples/control/Spielberg_map.yaml) and install it as the occupancy grid."""
@@ -173,6 +190,8 @@ class LatticePlanner():
                 self._ctx.set_grid(*self._map)
                 if self._inflate > 0.0:
                     self._ctx.inflate_grid(self._inflate)
+                if getattr(self, "_foot", None):
+                    self._ctx.set_footprint(*self._foot)
         return self._ctx
 
     def _bind(self, waypoints):

@@ -222,6 +222,12 @@ class Context:
         """Dilate the collision bitmap by a disc of `radius` metres (0 restores the uploaded grid)."""
         self._check(self.lib.f1p_inflate_grid(self.h, float(radius)))
 
+    def set_footprint(self, offsets, radius):
+        """Oriented footprint: discs of `radius` at longitudinal `offsets` [m] along the heading (f1p_set_footprint); offsets = ()
+        restores the point test."""
+        off = _f64(list(offsets)).reshape(-1)
+        self._check(self.lib.f1p_set_footprint(self.h, int(off.shape[0]), _ptr(off) if off.shape[0] else None, float(radius)))
+
     # ---- leaf kernels ----------------------------------------------------------------------------------
     def nearest_point(self, pts):
         pts = _f64(pts, (-1, 2)); E = pts.shape[0]
@@ -562,6 +568,9 @@ class MultiContext:
 
     def inflate_grid(self, radius):
         self._each(lambda c, g: c.inflate_grid(radius))
+
+    def set_footprint(self, offsets, radius):
+        self._each(lambda c, g: c.set_footprint(offsets, radius))
 
     def sync(self):
         self._each(lambda c, g: c.sync())

@@ -200,6 +200,14 @@ int f1p_grid_distance_batch(f1p_ctx* ctx, float* dist, int32_t cap_cells);
  * disc test.  radius = 0 restores the uploaded grid.  Planning kernels are unchanged. */
 int f1p_inflate_grid(f1p_ctx* ctx, double radius);
 
+/* Oriented vehicle footprint (the reference's vehicle is LENGTH 0.58 m x WIDTH 0.31 m, kinematic_mpc.py:60-61; its collision hook
+ * map_collision, utils/utils.py:297-301, is a stub): the footprint is covered by n_discs discs of `radius` whose centres sit at
+ * longitudinal `offsets` [m] from the pose along its heading.  The bitmap is dilated by `radius` (f1p_inflate_grid) and every
+ * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
+ * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the un-dilated grid.  Needs the grid;
+ * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel. */
+int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
+
 /* ------------------------------------------------------------------------------------------------
  * Leaf kernels of utils/utils.py, batched over E query points against the ctx waypoints.
  * ---------------------------------------------------------------------------------------------- */

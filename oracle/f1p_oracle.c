@@ -399,6 +399,17 @@ ORC_API void orc_cubic_row(const orc_cubic* q, double u, double out[4]) {
     out[3] = fabs(xd * ydd - yd * xdd) / (sp * sqrt(sp));
 }
 
+/* Oriented footprint (BUILD-DEFINED; the reference's map_collision is a stub, its vehicle 0.58 m x 0.31 m, kinematic_mpc.py:60-61):
+ * n discs whose centres sit at longitudinal offsets from the station along its heading; each centre is tested against the grid
+ * handed in (the caller passes the image dilated by the disc radius).  n = 0: the station point itself.  A process-wide setting
+ * of the checker (set before a batch, read-only during it). */
+static int g_foot_n = 0;
+static double g_foot_off[4] = {0, 0, 0, 0};
+ORC_API void orc_set_footprint(int n, const double* offsets) {
+    g_foot_n = n < 0 ? 0 : (n > 4 ? 4 : n);
+    for (int d = 0; d < 4; ++d) g_foot_off[d] = (offsets && d < g_foot_n) ? offsets[d] : 0.0;
+}
+
 /* one candidate: fit, sample, cost.  Returns the cost (+inf when infeasible / in collision).
  * traj_out may be NULL. */
 static double orc_lattice_candidate(const double* goal, int goal_valid, double px, double py, double ct, double st,
@@ -436,9 +447,14 @@ static double orc_lattice_candidate(const double* goal, int goal_valid, double p
         if (ak > maxk) maxk = ak;
         sumk += ak;
         if (cfg->check_collision && grid && grid->img) {
-            double xm = px + (ct * tr[4 * i] - st * tr[4 * i + 1]);
-            double ym = py + (st * tr[4 * i] + ct * tr[4 * i + 1]);
-            if (orc_cell_occupied(grid, xm, ym)) collide = 1;
+            int nd = g_foot_n > 0 ? g_foot_n : 1;
+            for (int d = 0; d < nd; ++d) {
+                double qx = tr[4 * i], qy = tr[4 * i + 1];
+                if (g_foot_n > 0) { qx += g_foot_off[d] * cos(tr[4 * i + 2]); qy += g_foot_off[d] * sin(tr[4 * i + 2]); }
+                double xm = px + (ct * qx - st * qy);
+                double ym = py + (st * qx + ct * qy);
+                if (orc_cell_occupied(grid, xm, ym)) collide = 1;
+            }
         }
     }
     if (prev_theta) { /* get_similarity_cost :287-296 with N = S */

@@ -165,6 +165,12 @@ def inflate_image(img, res, occupied_below, radius, nthreads=1):
     return out
 
 
+def set_footprint(offsets=()):
+    """footprint discs of the lattice collision test (orc_set_footprint); () = the station point"""
+    off = _f64(list(offsets)).reshape(-1)
+    lib().orc_set_footprint(C.c_int(len(off)), _p(off) if len(off) else None)
+
+
 def cell_occupied(grid, x, y):
     lib().orc_cell_occupied.restype = C.c_int
     return bool(lib().orc_cell_occupied(C.byref(grid), C.c_double(x), C.c_double(y)))

@@ -101,3 +101,37 @@ def test_inflated_grid_is_a_disc_footprint_test_in_the_planner(ctx, orc, radius)
     back = ctx.lattice_plan(poses, cfg)
     np.testing.assert_array_equal(back["best_idx"], plain["best_idx"])
     np.testing.assert_array_equal(back["steer"], plain["steer"])
+
+
+def test_oriented_footprint_against_the_oracle(orc):
+    """f1p_set_footprint: three discs covering the reference's 0.58 m x 0.31 m vehicle (kinematic_mpc.py:60-61), tested at every
+    station along the heading against the disc-dilated bitmap -- GPU vs the oracle's restatement on the oracle-dilated image; and
+    the footprint really is orientation-aware: it blocks candidates a disc of the same radius at the pose alone lets through."""
+    from f1tenth_planning_amd.planning.lattice_planner.lattice_planner import LatticePlanner
+    from f1tenth_planning_amd.runtime import Context
+    rl = synth.make_raceline(seed=0)
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058, half_width=0.9)
+    cfg = synth.bench_lattice_cfg(n_cand=128, n_stations=50)
+    poses = synth.make_egos(rl, 300, seed=21, pos_sigma=0.35, yaw_sigma=0.3)
+    pl = LatticePlanner(waypoints=rl)
+    offsets, radius = pl.set_footprint(length=0.58, width=0.31, n_discs=3, center_offset=0.145)   # pose at the rear axle-ish
+    assert len(offsets) == 3 and abs(radius - np.hypot(0.58 / 6, 0.155)) < 1e-12
+    with Context(0) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        ctx.set_footprint(offsets, radius)
+        got = ctx.lattice_plan(poses, cfg, want_all=True)
+        ctx.set_footprint((), 0.0)
+        ctx.inflate_grid(radius)                                   # same dilation, point test at the pose only
+        disc = ctx.lattice_plan(poses, cfg)
+    dil = orc.inflate_image(img, 0.058, 206, radius, nthreads=8)
+    orc.set_footprint(offsets)
+    try:
+        want = orc.lattice_plan_batch(poses, rl, cfg, grid=(dil, 0.058, origin[0], origin[1], 206), want_all=True, nthreads=8)
+    finally:
+        orc.set_footprint(())
+    np.testing.assert_array_equal(got["best_idx"], want["best_idx"])
+    np.testing.assert_array_equal(got["status"], want["status"])
+    np.testing.assert_array_equal(np.isinf(got["all_cost"]), np.isinf(want["all_cost"]))           # the same candidates are blocked
+    np.testing.assert_allclose(got["steer"], want["steer"], rtol=0, atol=1e-9)
+    blocked_foot = np.isinf(got["all_cost"]).mean()
+    assert (got["best_idx"] != disc["best_idx"]).sum() > 5 and 0.02 < blocked_foot < 0.9
