@@ -48,9 +48,8 @@ struct f1p_ctx {
     float* d_kmpc_warm = nullptr;      // [E][T][2] f32: previous plan's applied winner shifted by one step
     int kmpc_warm_E = 0, kmpc_warm_T = 0;
     bool kmpc_warm_valid = false;
-    char* d_kmpc_scratch = nullptr;    // split-rollout mode: per-ego tickets + [E][R] filter costs
-    size_t kmpc_scratch_bytes = 0;
-    int kmpc_tickets_E = 0;
+    char* d_kmpc_scratch = nullptr;    // split-rollout mode: per-ego tickets [cap_E] | [cap_E][cap_R] filter costs (layout by capacity)
+    int kmpc_cap_E = 0, kmpc_cap_R = 0;
     int kmpc_groups = 0;               // 0 = automatic number of workgroups per ego; > 0 forces it (tests, A/B runs)
 
     // two-kernel branch and bound of the lattice planner: bounds and clothoids handed from the fit kernel to the evaluation kernel
@@ -68,7 +67,7 @@ struct f1p_ctx {
 
     // candidate slices of one ego over several workgroups (few egos, many candidates): partial winners + tickets
     char* d_split_scratch = nullptr;
-    size_t split_scratch_bytes = 0;
+    int split_cap_E = 0;               // capacity (egos) the scratch is laid out for
     int lattice_split = 0;             // 0 = automatic, > 0 forces the number of workgroups per ego (tests, A/B runs)
 
     // RCCL (loaded lazily with dlopen; only the candidate-sharded mode needs it)

@@ -767,22 +767,22 @@ int launch_kmpc_plan_gen(f1p_ctx* ctx, const double* d_x0, const double* d_ref, 
     ga.Rs = (int)((R + ga.G - 1) / ga.G);
     ga.cost32 = ctx->d_dbg_cost32;
     if (ga.G > 1) {
-        const size_t need = sizeof(float) * (size_t)E * R + sizeof(unsigned int) * (size_t)E + 256;
-        if (need > ctx->kmpc_scratch_bytes) {
+        // layout by CAPACITY (tickets [cap_E] | costs [cap_E][cap_R]): a launch with another E or R must find its tickets where the
+        // previous launches left them zeroed, never on top of old filter costs
+        if (E > ctx->kmpc_cap_E || (int)R > ctx->kmpc_cap_R) {
             F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_kmpc_scratch) (void)hipFree(ctx->d_kmpc_scratch);
-            ctx->d_kmpc_scratch = nullptr; ctx->kmpc_scratch_bytes = 0;
+            ctx->d_kmpc_scratch = nullptr;
+            const size_t cap_e = (size_t)(E > ctx->kmpc_cap_E ? E + (E >> 1) + 64 : ctx->kmpc_cap_E);
+            const size_t cap_r = (size_t)((int)R > ctx->kmpc_cap_R ? R : (size_t)ctx->kmpc_cap_R);
+            ctx->kmpc_cap_E = 0; ctx->kmpc_cap_R = 0;
+            const size_t need = ((sizeof(unsigned int) * cap_e + 255) & ~(size_t)255) + sizeof(float) * cap_e * cap_r;
             F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_scratch, need));
-            ctx->kmpc_scratch_bytes = need;
-            ctx->kmpc_tickets_E = 0;
+            F1P_HIP(ctx, hipMemsetAsync(ctx->d_kmpc_scratch, 0, need, ctx->stream));
+            ctx->kmpc_cap_E = (int)cap_e; ctx->kmpc_cap_R = (int)cap_r;
         }
-        unsigned int* tickets = reinterpret_cast<unsigned int*>(ctx->d_kmpc_scratch);
-        if (ctx->kmpc_tickets_E < E) {                               // first use: zero; afterwards the kernel resets its own tickets
-            F1P_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(unsigned int) * (size_t)E, ctx->stream));
-            ctx->kmpc_tickets_E = E;
-        }
-        ga.tickets = tickets;
-        if (!ga.cost32) ga.cost32 = reinterpret_cast<float*>(ctx->d_kmpc_scratch + ((sizeof(unsigned int) * (size_t)E + 255) & ~(size_t)255));
+        ga.tickets = reinterpret_cast<unsigned int*>(ctx->d_kmpc_scratch);
+        if (!ga.cost32) ga.cost32 = reinterpret_cast<float*>(ctx->d_kmpc_scratch + ((sizeof(unsigned int) * (size_t)ctx->kmpc_cap_E + 255) & ~(size_t)255));
     }
     const int pairs = (ga.Rs + 1) / 2;
     int block = ((pairs + 63) / 64) * 64;

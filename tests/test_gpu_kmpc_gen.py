@@ -130,3 +130,25 @@ def test_planner_class_batch_is_one_call_and_host_time_tracks_the_kernel(ctx):
         t0 = time.perf_counter(); pl.plan_batch(x0, want_seq=False); ts.append(time.perf_counter() - t0)
     p50 = float(np.percentile(ts, 50)) * 1e3
     assert p50 < 5.0, p50                                               # was ~1 s of numpy RNG + a 126 MB upload per plan
+
+
+def test_split_scratch_survives_changing_batch_sizes(ctx):
+    """regression: tickets are laid out by capacity, so a plan after plans of other sizes still finds them zeroed"""
+    T, R = 30, 512
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    smp = _abi.kmpc_sampler(seed=5, call=1, use_warm=False)
+    first = {}
+    for E in (300, 7, 400, 3, 300, 7):
+        cl, x0, ref = _scene(ctx, E, seed=E)
+        d_x0, d_ref = ctx.to_device(x0), ctx.to_device(ref)
+        d_steer, d_speed, d_bi = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E)
+        ctx.kmpc_set_groups(4)
+        ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi)
+        got = d_bi.download(np.int32, (E,))
+        ctx.kmpc_set_groups(1)
+        ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi)
+        np.testing.assert_array_equal(got, d_bi.download(np.int32, (E,)))
+        if E in first:
+            np.testing.assert_array_equal(got, first[E])
+        first[E] = got
+    ctx.kmpc_set_groups(0)

@@ -395,3 +395,12 @@ def test_candidate_slices_over_several_workgroups(ctx, scene):
                 for k in a:
                     np.testing.assert_array_equal(b[k], a[k], err_msg=f"shard {k}")
     ctx.lattice_set_split(0)
+    # regression (found by the 240-seed fuzz run): the ticket / partial-winner scratch must not depend on the batch size of EARLIER
+    # launches -- a small batch's partials once landed where a later, larger batch looked for its zeroed tickets
+    cfg = synth.bench_lattice_cfg(n_cand=512, n_stations=30)
+    for E in (3, 90, 5, 120, 2, 70):
+        poses = synth.make_egos(rl, E, seed=E)
+        ctx.lattice_set_split(1); one = ctx.lattice_plan(poses, cfg)
+        ctx.lattice_set_split(0); many = ctx.lattice_plan(poses, cfg)
+        for k in one:
+            np.testing.assert_array_equal(many[k], one[k], err_msg=f"{k} E={E}")
