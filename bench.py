@@ -770,7 +770,7 @@ def main_kmpc(args):
                           "controls": "streamed from HBM (f32 [E][T][2][R])" if stream else "generated in the kernel (Philox4x32-10 around the device-resident warm start)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_kmpc_shoot",
-                            "kernel_ms": dom_ms, "plan_ms": kernel_ms, "kernels_ms": mixed_ms, "algorithmic_bytes_per_launch": abytes,
+                            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                             "bytes_per_rollout_step": abytes / (E * R * T),
                             "note": "below ~2048 egos per GPU the 123 KB-per-ego control buffer is Infinity-Cache resident across launches: "
                                     "the figure is then a cache-stream rate, not HBM evidence"}}

@@ -447,6 +447,9 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
 // warm_in / warm_out: [E][T][2] f32 (may alias: every workgroup copies its ego's row to LDS before the ticket; the last
 // workgroup writes only after every other one has passed its ticket).
 // ---------------------------------------------------------------------------------------------------
+#ifndef F1P_K4_WAVES_GEN
+#define F1P_K4_WAVES_GEN 4
+#endif
 struct KmpcGenArgs {
     uint32_t k0, k1, call;
     float sig_a, sig_d;
@@ -457,7 +460,7 @@ struct KmpcGenArgs {
     int G, Rs;
 };
 
-__global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_plan_gen(const double* __restrict__ x0, const double* __restrict__ ref, int E,
+__global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const double* __restrict__ x0, const double* __restrict__ ref, int E,
                                                        f1p_kmpc_cfg cfg, KmpcF32 kf, KmpcGenArgs ga,
                                                        double* __restrict__ steer, double* __restrict__ speed,
                                                        int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
