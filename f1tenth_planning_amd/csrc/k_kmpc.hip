@@ -319,6 +319,143 @@ __device__ __forceinline__ void kmpc_emit(const Src& src, const f1p_kmpc_cfg& cf
     if (best_cost) best_cost[e] = bc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TIME-PARALLEL fp64 evaluation of one rollout by a group of lanes (lane j of the group <-> time index j; T + 1 <= group).
+// A rollout is a chain in t, but only its ADDITIONS and CLAMPS are: everything expensive -- the Philox call, tan(delta), the
+// sincos of the heading, the products of the cost terms -- depends on the chain through one value per step, so it is done by
+// all lanes at once and the chains (rate limit, speed, heading, x, y, cost) run as T Jacobi sweeps of "lane j <- f(lane j-1,
+// own increment)" with the wave-shift DPP move (v_mov_b32_dpp wave_shr:1, no LDS): after sweep s lanes <= s hold their final
+// value, lanes beyond it hold garbage that is overwritten later.  Every quantity is produced by the same fp64 operations in
+// the same order as kmpc_rollout_cost<true> / kmpc_emit run them serially (contraction is off), so costs, sequences and
+// outputs are bit-identical; ~1 700 wave instructions instead of ~10 500 for T = 30 (the single-lane tail was half of the
+// generated-controls kernel: 91 -> 52 us at 1024 egos).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_up1(double v) {                // lane i <- lane i - 1 of the wave; lane 0 keeps its own
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// lane j (0 <= j < group size, j == 0 at the group's first lane) returns the applied controls (a, d) of step j (j < T) and, with
+// COST, the rollout's cost in EVERY lane j >= T ... of which the caller reads lane T.  `sref` as in kmpc_rollout_cost.
+template <bool COST, typename Src>
+__device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const double* sref, const f1p_kmpc_cfg& cfg, double sx, double sy,
+                                                     double sv, double syaw, double dmax, int r, int j, double& a, double& d) {
+    const int T = cfg.horizon;
+    const bool first = j == 0;
+    float af = 0.0f, df = 0.0f;
+    if (j < T) src.get(j, r, af, df);
+    a = clampd((double)af, -cfg.max_accel, cfg.max_accel);            // |a| <= MAX_ACCEL          :400
+    const double dc = clampd((double)df, -cfg.max_steer, cfg.max_steer);   // |delta| <= MAX_STEER  :401
+    d = dc;
+    if (!COST) {
+        for (int s = 1; s < T; ++s) {                                  // |d delta| <= MAX_DSTEER*DTK :391-394
+            const double pd = lane_up1(d);
+            const double dn = clampd(dc, pd - dmax, pd + dmax);
+            d = first ? dc : dn;
+        }
+        return 0.0;
+    }
+    // ---- chains 1: steering rate limit, speed ------------------------------------------------------------------------------
+    const double vinc = lane_up1(a * cfg.dt);                          // lane j: a_{j-1} DTK
+    double v = sv;
+    for (int s = 1; s <= T; ++s) {
+        const double pd = lane_up1(d), pv = lane_up1(v);
+        const double dn = clampd(dc, pd - dmax, pd + dmax);
+        double vn = pv + vinc;                                         // :236
+        if (vn > cfg.max_speed) vn = cfg.max_speed;                    // :238-241
+        else if (vn < cfg.min_speed) vn = cfg.min_speed;
+        d = first ? dc : dn;
+        v = first ? sv : vn;
+    }
+    // ---- chain 2: heading --------------------------------------------------------------------------------------------------
+    double dl = d;
+    if (dl >= cfg.max_steer) dl = cfg.max_steer;                       // :226-229
+    else if (dl <= -cfg.max_steer) dl = -cfg.max_steer;
+    double sd, cd;
+    sincos_core(dl, &sd, &cd);
+    const double tn = sd / cd;
+    const double yinc = lane_up1((v / cfg.wheelbase) * tn * cfg.dt);   // :233-235
+    double yaw = syaw;
+    for (int s = 1; s <= T; ++s) {
+        const double py = lane_up1(yaw);
+        const double yn = py + yinc;
+        yaw = first ? syaw : yn;
+    }
+    // ---- chains 3: position ------------------------------------------------------------------------------------------------
+    double sn, cs;
+    sincos_core(yaw, &sn, &cs);
+    const double xinc = lane_up1(v * cs * cfg.dt), yyinc = lane_up1(v * sn * cfg.dt);   // :231-232
+    double x = sx, y = sy;
+    for (int s = 1; s <= T; ++s) {
+        const double px = lane_up1(x), py = lane_up1(y);
+        const double xn = px + xinc, yn = py + yyinc;
+        x = first ? sx : xn;
+        y = first ? sy : yn;
+    }
+    // ---- stage terms (all lanes), then the cost in the reference's accumulation order -----------------------------------------
+    const int jj = j < T ? j : T;
+    const bool last = j >= T;
+    const double e0 = x - sref[0 * (T + 1) + jj], e1 = y - sref[1 * (T + 1) + jj];
+    const double e2 = v - sref[2 * (T + 1) + jj], e3 = yaw - sref[3 * (T + 1) + jj];
+    const double w0 = last ? cfg.qf[0] : cfg.q[0], w1 = last ? cfg.qf[1] : cfg.q[1], w2 = last ? cfg.qf[2] : cfg.q[2], w3 = last ? cfg.qf[3] : cfg.q[3];
+    const double A = ((w0 * e0 * e0 + w1 * e1 * e1) + w2 * e2 * e2) + w3 * e3 * e3;    // :331 (Qf at the last state)
+    const double B = cfg.r[0] * a * a + cfg.r[1] * d * d;                                // :328
+    const double da = a - lane_up1(a), dd = d - lane_up1(d);
+    const double Cc = cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                         // :334
+    const bool mid = !first && !last;
+    double cost = 0.0;
+    for (int s = 0; s <= T; ++s) {
+        const double pc = lane_up1(cost);
+        const double c1 = (first ? 0.0 : pc) + A;
+        const double c2 = c1 + B;
+        const double c2s = last ? c1 : c2;
+        const double c3 = c2s + Cc;
+        cost = mid ? c3 : c2s;
+    }
+    return cost;
+}
+
+// outputs of the winner from the lanes that hold its applied sequence (lane j: step j); same values as kmpc_emit
+__device__ __forceinline__ void kmpc_emit_lanes(const f1p_kmpc_cfg& cfg, double sv, int e, int j, double a, double d, int bi, double bc,
+                                                double* __restrict__ steer, double* __restrict__ speed, int32_t* __restrict__ best_idx,
+                                                double* __restrict__ best_cost, double* __restrict__ best_seq, float* __restrict__ warm_out) {
+    const int T = cfg.horizon;
+    if (j == 0) {
+        steer[e] = d;                           // :506  steer_output = odelta_v[0]
+        speed[e] = sv + a * cfg.dt;             // :508  speed_output = v + oa[0] * DTK
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+    }
+    if (j < T) {
+        if (best_seq) { best_seq[((size_t)e * T + j) * 2] = a; best_seq[((size_t)e * T + j) * 2 + 1] = d; }
+        if (warm_out) {                          // shifted by one step, the last step repeated (kinematic_mpc.py:491-498)
+            if (j > 0) { warm_out[2 * (j - 1)] = (float)a; warm_out[2 * (j - 1) + 1] = (float)d; }
+            if (j == T - 1) { warm_out[2 * j] = (float)a; warm_out[2 * j + 1] = (float)d; }
+        }
+    }
+}
+
+// lanes per rollout of the time-parallel evaluation (0: horizon too long for one wave -> the serial code)
+__device__ __forceinline__ int kmpc_lane_group(int T) { return T + 1 <= 32 ? 32 : (T + 1 <= 64 ? 64 : 0); }
+
+// the winner's re-emission by the first wave (every thread of the workgroup may call it; workgroup-uniform arguments)
+template <typename Src>
+__device__ __forceinline__ void kmpc_emit_wave(const Src& src, const f1p_kmpc_cfg& cfg, double sv, double dmax, int e, int bi, double bc,
+                                               double* __restrict__ steer, double* __restrict__ speed, int32_t* __restrict__ best_idx,
+                                               double* __restrict__ best_cost, double* __restrict__ best_seq, float* __restrict__ warm_out) {
+    const int tid = threadIdx.x;
+    if (tid >= 64) return;
+    if (cfg.horizon <= 64) {
+        double a, d;
+        kmpc_rollout_lanes<false>(src, nullptr, cfg, 0.0, 0.0, sv, 0.0, dmax, bi, tid, a, d);
+        kmpc_emit_lanes(cfg, sv, e, tid, a, d, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
+    } else if (tid == 0) {
+        kmpc_emit(src, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
+    }
+}
+
 // fp64 re-evaluation by the whole workgroup (all 256 threads must call it; workgroup-uniform arguments).  n > 0: the listed
 // survivors, one lane each; n < 0: every rollout, one lane per rollout (the code of the plain kernel).  `sref` is LDS scratch
 // of 4 (T+1) + 4 doubles + 4 ints.
@@ -335,6 +472,22 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
     __syncthreads();
     const double dmax = cfg.max_dsteer * cfg.dt;
     double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    const int GL = kmpc_lane_group(T);
+    if (n > 0 && GL > 0 && n <= (int)blockDim.x / GL) {
+        // few survivors (the usual case): one lane GROUP per survivor, time steps across its lanes
+        const int gid = tid / GL, j = tid - gid * GL;
+        double a = 0.0, d = 0.0;
+        int mine = -1;
+        if (gid < n) {
+            mine = list[gid];
+            const double c = kmpc_rollout_lanes<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, mine, j, a, d);
+            if (j == T) { bc = c; bi = mine; }
+        }
+        block_argmin(bc, bi, red_d, red_i);
+        if (mine == bi) kmpc_emit_lanes(cfg, sv, e, j, a, d, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
+        if (tid == 0 && n_refined) n_refined[e] = n;
+        return;
+    }
     if (n > 0) {
         if (tid < n) { bi = list[tid]; bc = kmpc_rollout_cost<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, bi); }
     } else {
@@ -343,10 +496,8 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
         else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     }
     block_argmin(bc, bi, red_d, red_i);
-    if (tid == 0) {
-        kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
-        if (n_refined) n_refined[e] = n;
-    }
+    kmpc_emit_wave(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
+    if (tid == 0 && n_refined) n_refined[e] = n;
 }
 
 // Mixed-precision shooting: the f32 filter over all rollouts (HBM-streaming, 8 B per rollout-step), then -- only for the ~1 %
@@ -427,10 +578,9 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
         kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
     } else if (n == 1 && !best_cost) {
-        if (tid == 0) {                                                // a single survivor needs no fp64 cost unless it is asked for
-            kmpc_emit(ce, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq);
-            if (n_refined) n_refined[e] = 1;
-        }
+        // a single survivor needs no fp64 cost unless it is asked for
+        kmpc_emit_wave(ce, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, nullptr);
+        if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
         kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
     }
@@ -526,6 +676,9 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
         __syncthreads();
     }
 
+#if defined(F1P_K4_ABLATE) && F1P_K4_ABLATE == 1
+    return;                                                           // timing experiment: the filter alone
+#endif
     // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
     if (!in_range) {
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
@@ -556,13 +709,16 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     }
     __syncthreads();
     const int n = cnt[0];
+#if defined(F1P_K4_ABLATE) && F1P_K4_ABLATE == 2
+    if (tid == 0) best_idx[e] = list[0];                              // timing experiment: no refinement, no re-emission
+    return;
+#endif
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
     } else if (n == 1 && !best_cost) {
-        if (tid == 0) {                                                // a single survivor needs no fp64 cost unless it is asked for
-            kmpc_emit(src, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
-            if (n_refined) n_refined[e] = 1;
-        }
+        // a single survivor needs no fp64 cost unless it is asked for
+        kmpc_emit_wave(src, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
+        if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
         // the survivors in ascending rollout order: the atomic list is in arrival order, the decision (first minimum) is by index
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
@@ -607,7 +763,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES) void k_kmpc_shoot(const double* 
     if (fast) kmpc_rollouts<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     else kmpc_rollouts<false>(ce, sref, cfg, sx, sy, sv, syaw, dmax, tid, bc, bi);
     block_argmin(bc, bi, red_d, red_i);
-    if (tid == 0) kmpc_emit(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq);
+    kmpc_emit_wave(ce, cfg, sv, dmax, e, bi, bc, steer, speed, best_idx, best_cost, best_seq, nullptr);
 }
 
 // predict_motion_kinematic :208-221: one thread per ego, T sequential steps, path [E][4][T+1]

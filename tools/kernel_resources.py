@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-kernel register / spill / scratch table of every .hip translation unit in csrc/ ("check with
+-Rpass-analysis=kernel-resource-usage ... and fail on VGPR spills per instantiation").
+
+    python tools/kernel_resources.py            # table
+    python tools/kernel_resources.py --check    # exit 1 when a kernel outside ALLOWED has VGPR spills or scratch
+
+Compiles to /dev/null-equivalent objects under /tmp; CPU only (hipcc cross-compiles gfx950).
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+         "-Rpass-analysis=kernel-resource-usage"]
+# instantiations that are allowed to carry VGPR spills / scratch: the materialising debug variants (all_traj requested), which
+# are HBM-write-bound, not VALU-bound
+ALLOWED = ("ILb1E",)
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        return [re.sub(r"\(.*$", "", o).replace("f1p::", "") for o in out[:len(names)]]
+    except OSError:
+        return names
+
+
+def resources(src):
+    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", src, "-o", "/tmp/_kres.o"], capture_output=True, text=True, cwd=CSRC)
+    if r.returncode:
+        sys.stderr.write(r.stderr)
+        raise SystemExit(r.returncode)
+    rows, cur = [], None
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]):\s*(\S+)", ln)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "Function Name":
+            cur = {"name": v}
+            rows.append(cur)
+        elif cur is not None:
+            cur[k.split(" [")[0]] = v
+    return rows
+
+
+def main():
+    check = "--check" in sys.argv
+    bad = []
+    print(f"{'kernel':<58} {'SGPR':>5} {'VGPR':>5} {'AGPR':>5} {'sgpr-spill':>10} {'vgpr-spill':>10} {'scratch':>8} {'occ':>4} {'LDS':>7}")
+    for src in sorted(glob.glob(os.path.join(CSRC, "k_*.hip"))) + [os.path.join(CSRC, "f1p_api.hip")]:
+        rows = resources(src)
+        names = demangle([r["name"] for r in rows])
+        for r, nm in zip(rows, names):
+            print(f"{nm[:58]:<58} {r.get('TotalSGPRs', '?'):>5} {r.get('VGPRs', '?'):>5} {r.get('AGPRs', '?'):>5} {r.get('SGPRs Spill', '?'):>10} "
+                  f"{r.get('VGPRs Spill', '?'):>10} {r.get('ScratchSize', '?'):>8} {r.get('Occupancy', '?'):>4} {r.get('LDS Size', '?'):>7}")
+            if (int(r.get("VGPRs Spill", 0)) or int(r.get("ScratchSize", 0))) and not any(a in r["name"] for a in ALLOWED):
+                bad.append(nm)
+    if check and bad:
+        print("VGPR spills / scratch in:", ", ".join(bad))
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
