@@ -9,7 +9,7 @@ from f1tenth_planning_amd.runtime import Context
 E, S = 4096, 50
 rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
 poses = synth.make_egos(rl, E, seed=1)
-names = ["nearest + argmin + seg_project", "look-ahead centres", "tile + setup", "f32 candidates", "T reduce + count + queue write"]
+names = ["tile loads + setup + nearest + argmin", "look-ahead centres", "f32 candidates", "T reduce + count + queue write"]
 with Context(0) as ctx:
     ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
     d_poses = ctx.to_device(poses)
@@ -20,8 +20,8 @@ with Context(0) as ctx:
         d_c, d_s = ctx.alloc(4 * E * max(C, 8)), ctx.alloc(4 * E * max(C, 8))
         ctx.lattice_set_mode(2, d_c, d_s)
         for _ in range(5): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
-        ph = d_c.download(np.float32, (E, C))[:, :5]
+        ph = d_c.download(np.float32, (E, C))[:, :4]
         tot = ph.sum(1).mean()
         print(f"--- {nl} look-aheads x {nw} widths")
-        for k in range(5): print(f"{names[k]:34s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %")
+        for k in range(4): print(f"{names[k]:34s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %")
         print(f"workgroup lifetime {tot:.0f} ticks")
