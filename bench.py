@@ -38,11 +38,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# fp64 vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (= 78.6 TFLOP/s of FMA)
-FP64_VALU_PEAK_TLANES = 39.3
-# what a pure v_fma_f64 loop sustains on this chip once the clocks have settled (tools/microbench/valu.hip, 13 ms launches:
-# 32.8-33.1 T lane-instr/s = 66 TFLOP/s; 1.4 ms launches from idle: 28.5-29.7)
-FP64_VALU_SUSTAINED_TLANES = 33.0
+# vector issue peak: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s (one VALU instruction per wave per
+# 4 cycles; = 78.6 TFLOP/s of f64 or unpacked-f32 FMA).  A pure v_fma_f64 loop sustains 32.8-33.1 T on this chip
+# (tools/microbench/valu.hip); packed f32 and a few plain VOP2 forms go above the figure, transcendentals and VOP3 integer
+# forms stay below it (tools/microbench/intops.hip), so the fraction is an issue-slot utilisation, not a flop rate.
+VALU_ISSUE_PEAK_TLANES = 39.3
 
 
 def parse_args(argv=None):
@@ -219,7 +219,7 @@ def load_pmc(config):
             continue
         for k in d.get("kernels", []):
             if k.get("headline"):
-                best = dict(k, source=os.path.relpath(p, ROOT))
+                best = dict(k, source=os.path.relpath(p, ROOT), all_kernels=d.get("kernels", []))
     return best
 
 
@@ -513,20 +513,31 @@ def main_lattice(args):
         if materialised:
             abytes += E * C * S * 32 + E * C * 8      # every candidate's rows (x, y, theta, |kappa|) + its cost, written once
         dom_ms = mixed_ms["k_lattice_filter"] if mixed_ms else kernel_ms          # the dominant kernel's own average duration
-        achieved_gbs = abytes / (dom_ms * 1e-3) / 1e9
         pmc = load_pmc({"egos": E, "cands": C, "stations": S, "workload": args.workload, "generator": args.generator,
                         "schedule": "all_fp64" if args.all_fp64 else ("bnb" if args.prune else "mixed")})
         same_cfg = bool(pmc and not cand_sharded)
         valu = None
         if same_cfg and pmc.get("SQ_INSTS_VALU") and pmc.get("waves"):
-            per_cand = pmc["SQ_INSTS_VALU"] / pmc["waves"]            # wave-instructions per wave = lane-instructions per candidate
+            per_cand = pmc["SQ_INSTS_VALU"] / pmc["waves"]            # wave-instructions per wave = lane-instructions per candidate (one lane per candidate)
             valu_tlanes = per_cand * E * C / (dom_ms * 1e-3) / 1e12
-            valu = {"achieved": valu_tlanes, "peak": FP64_VALU_PEAK_TLANES, "unit": "T lane-instr/s", "frac": valu_tlanes / FP64_VALU_PEAK_TLANES,
-                    "sustained_peak": FP64_VALU_SUSTAINED_TLANES, "frac_of_sustained": valu_tlanes / FP64_VALU_SUSTAINED_TLANES,
+            valu = {"kernel": pmc["kernel"], "achieved": valu_tlanes, "peak": VALU_ISSUE_PEAK_TLANES, "unit": "T lane-instr/s",
+                    "frac": valu_tlanes / VALU_ISSUE_PEAK_TLANES,
+                    "peak_definition": "1024 SIMDs x 16 lanes/clk x 2.4 GHz: one VALU instruction per wave per 4 cycles (f64 and unpacked f32 alike)",
+                    "arithmetic": "f64" if (args.all_fp64 or args.prune) else "f32 (the filter kernel; the fp64 kernels after it are 28 % of the plan time)",
                     "valu_instr_per_candidate": per_cand, "source": pmc["source"]}
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' busy clocks
+                valu["busy_frac_profiled"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
         traffic = None
-        if same_cfg and pmc.get("FETCH_SIZE_KiB") is not None and pmc.get("WRITE_SIZE_KiB") is not None:
-            traffic = int((pmc["FETCH_SIZE_KiB"] * 2 + pmc["WRITE_SIZE_KiB"]) * 1024)    # gfx950 wide-read correction x2 (MI355X_MICROARCH.md)
+        if same_cfg:
+            # one plan = every kernel of the schedule (the filter reads the scene, k_lattice_select writes best_traj): their PMC bytes are summed
+            names = ("k_lattice_filter", "k_lattice_refine", "k_lattice_select") if mixed_ms else (pmc["kernel"],)
+            tb = 0.0
+            for k in pmc.get("all_kernels", []):
+                if any(nm in k.get("kernel", "") for nm in names) and k.get("FETCH_SIZE_KiB") is not None and k.get("WRITE_SIZE_KiB") is not None:
+                    tb += (k["FETCH_SIZE_KiB"] * 2 + k["WRITE_SIZE_KiB"]) * 1024    # gfx950 wide-read correction x2 (MI355X_MICROARCH.md)
+            traffic = int(tb) if tb > 0 else None
+        achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9              # the plan's algorithmic bytes over the plan's kernel time
         pcie_value = (float(E) * C * S / (lat["p50_ms"] * 1e-3)) if lat else None
         out = {
             "metric": "candidate-trajectory-steps/sec per GPU; p50 plan() latency @4096 egos",
@@ -556,11 +567,12 @@ def main_lattice(args):
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": pmc["source"] if traffic is not None else None,
-                         "kernel": pmc["kernel"] if pmc else "k_lattice",
-                         "kernel_ms": dom_ms, "plan_ms": kernel_ms, "kernels_ms": mixed_ms, "algorithmic_bytes_per_launch": abytes,
+                         "kernel": ("k_lattice_filter + k_lattice_refine + k_lattice_select (one plan; the dominant kernel is k_lattice_filter, see valu)"
+                                    if mixed_ms else (pmc["kernel"] if pmc else "k_lattice")),
+                         "kernel_ms": kernel_ms, "dominant_kernel_ms": dom_ms, "kernels_ms": mixed_ms, "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_candidate_step": abytes / (E * C * S),
                          "note": "the planning kernels are VALU / transcendental bound by construction (0.14 B per candidate-step); the HBM fraction is tiny and reported as such",
-                         "valu_fp64": valu},
+                         "valu": valu},
             "blocked_egos": None if status is None else int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
         if not args.no_cpu_baseline and not cand_sharded:
@@ -769,11 +781,25 @@ def main_kmpc(args):
                "config": {"workload": f"kmpc shooting: {E_total} egos x {R} rollouts x {T} steps over {world} GPU(s), {E} egos per GPU (BASELINE configs[4])",
                           "controls": "streamed from HBM (f32 [E][T][2][R])" if stream else "generated in the kernel (Philox4x32-10 around the device-resident warm start)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_kmpc_shoot",
+                            "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "k_kmpc_shoot" if args.kmpc_f64 else ("k_kmpc_shoot_mixed" if stream else "k_kmpc_plan_gen"),
                             "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": abytes,
                             "bytes_per_rollout_step": abytes / (E * R * T),
-                            "note": "below ~2048 egos per GPU the 123 KB-per-ego control buffer is Infinity-Cache resident across launches: "
-                                    "the figure is then a cache-stream rate, not HBM evidence"}}
+                            "note": ("below ~2048 egos per GPU the 123 KB-per-ego control buffer is Infinity-Cache resident across launches: "
+                                     "the figure is then a cache-stream rate, not HBM evidence") if stream else
+                                    "controls are generated in registers: no per-rollout byte ever exists in memory, the kernel is VALU-bound "
+                                    "(Philox4x32-10 + the packed-f32 rollout) and the HBM fraction is reported as the tiny number it is; see valu"}}
+        pmc = None if stream else load_pmc({"workload": "kmpc", "egos": E, "rollouts": R, "horizon": T, "controls": "generated"})
+        if pmc and pmc.get("SQ_INSTS_VALU"):
+            tl = pmc["SQ_INSTS_VALU"] * 64.0 / (kernel_ms * 1e-3) / 1e12
+            out["roofline"]["valu"] = {"kernel": pmc["kernel"], "achieved": tl, "peak": VALU_ISSUE_PEAK_TLANES, "unit": "T lane-instr/s",
+                                       "frac": tl / VALU_ISSUE_PEAK_TLANES, "valu_instr_per_rollout_step": pmc["SQ_INSTS_VALU"] * 64.0 / (E * R * T),
+                                       "source": pmc["source"]}
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+                out["roofline"]["valu"]["busy_frac_profiled"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+            if pmc.get("FETCH_SIZE_KiB") is not None and pmc.get("WRITE_SIZE_KiB") is not None:
+                out["roofline"]["traffic"] = int((pmc["FETCH_SIZE_KiB"] * 2 + pmc["WRITE_SIZE_KiB"]) * 1024)
+                out["roofline"]["traffic_source"] = pmc["source"]
         if not args.no_cpu_baseline:
             from oracle import oracle
             nthr = oracle.max_threads()

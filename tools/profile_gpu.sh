@@ -14,8 +14,10 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LD
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/${TAG}_pmc_$N -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_$N.log 2>&1 || echo "pmc pass $C failed (see log)"
 done
+# PROF_CONFIG (optional env): the JSON object bench.py's load_pmc() matches the profile against; default = the lattice headline
+CONFIG=${PROF_CONFIG:-"{\"egos\": 4096, \"cands\": 256, \"stations\": 50, \"workload\": \"lattice\", \"generator\": \"clothoid\", \"schedule\": \"$SCHED\"}"}
 python3 tools/prof_summary.py --json $OUT/${TAG}_pmc.json --headline "$HEAD" \
-    --config "{\"egos\": 4096, \"cands\": 256, \"stations\": 50, \"workload\": \"lattice\", \"generator\": \"clothoid\", \"schedule\": \"$SCHED\"}" \
+    --config "$CONFIG" \
     $OUT/${TAG}_trace $OUT/${TAG}_pmc_* > $OUT/${TAG}_summary.md 2>$OUT/${TAG}_summary.err
 grep -h '"metric"' $OUT/${TAG}_trace.log | head -1 > $OUT/${TAG}_bench_line.json
 head -40 $OUT/${TAG}_summary.md | cut -c1-220
