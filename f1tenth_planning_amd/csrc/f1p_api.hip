@@ -249,7 +249,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -408,6 +408,8 @@ int f1p_set_waypoints_ex(f1p_ctx* ctx, const double* wp, int32_t n, int32_t ncol
 static void drop_grid(f1p_ctx* ctx) {
     if (ctx->d_bits) (void)hipFree(ctx->d_bits);
     if (ctx->d_bits0) (void)hipFree(ctx->d_bits0);
+    if (ctx->d_bits_clear) (void)hipFree(ctx->d_bits_clear);
+    ctx->d_bits_clear = nullptr; ctx->clear_dist = 0.0;
     ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0; ctx->n_disc = 0;
 }
 
@@ -465,6 +467,7 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
     if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
     if (!(radius >= 0.0) || !isfinite(radius)) return set_error(ctx, F1P_EINVAL, "inflation radius must be finite and >= 0");
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->clear_dist = 0.0;                                  // the active bitmap changes: its clearance map is stale
     if (radius == 0.0) {
         F1P_HIP(ctx, hipMemcpy(ctx->d_bits, ctx->d_bits0, sizeof(uint32_t) * (size_t)ctx->gwwords * ctx->gh, hipMemcpyDeviceToDevice));
         ctx->inflate_radius = 0.0;
@@ -685,6 +688,13 @@ int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups) {
     if (!ctx) return F1P_EINVAL;
     if (groups < 0 || groups > 16) return set_error(ctx, F1P_EINVAL, "groups must be in [0, 16]");
     ctx->lattice_split = groups;
+    return F1P_OK;
+}
+
+int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side) {
+    if (!ctx) return F1P_EINVAL;
+    if (stations_each_side < 0 || stations_each_side > 2) return set_error(ctx, F1P_EINVAL, "stations_each_side must be 0, 1 or 2");
+    ctx->lattice_clear_r = stations_each_side;
     return F1P_OK;
 }
 

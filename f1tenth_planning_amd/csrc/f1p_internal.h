@@ -29,6 +29,9 @@ struct f1p_ctx {
     uint32_t* d_bits = nullptr;    // active collision bitmap (the uploaded grid, or its inflation by f1p_inflate_grid)
     uint32_t* d_bits0 = nullptr;   // the grid as uploaded
     double inflate_radius = 0.0;
+    uint32_t* d_bits_clear = nullptr;   // clearance map of d_bits for the f32 lattice filter (k_grid.hip ensure_clear_map); null / clear_dist 0 = stale
+    double clear_dist = 0.0;            // centre distance [cells] it was built for
+    int lattice_clear_r = 1;            // stations proved free on each side of a tested one (0 = test every station against d_bits)
     int n_disc = 0;                // oriented footprint: discs along the heading (0 = the station point only)
     double disc_off[4] = {0, 0, 0, 0};
     int gw = 0, gh = 0, gwwords = 0;
@@ -104,7 +107,8 @@ int launch_pure_pursuit(f1p_ctx* ctx, const double* d_poses, int E, double looka
                         double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near, int32_t* d_la,
                         int32_t* d_status);
 int launch_pack_grid(f1p_ctx* ctx, const uint8_t* d_img, int w, int h, int occupied_below);
-int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uint32_t* d_d2, uint32_t* d_bits_out);
+int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uint32_t* d_d2, uint32_t* d_bits_out, const uint32_t* src = nullptr);
+int ensure_clear_map(f1p_ctx* ctx, double dist_cells);
 
 enum LatticeMode { LATTICE_FULL = 0, LATTICE_EVAL = 1, LATTICE_EMIT = 2 };
 int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,

@@ -71,14 +71,14 @@ __global__ __launch_bounds__(256) void k_edt_rows(const uint16_t* __restrict__ g
     }
 }
 
-// distance transform of ctx->d_bits0 (the grid as uploaded).  Any of d_dist_img / d_d2 / d_bits_out may be null.
-int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uint32_t* d_d2, uint32_t* d_bits_out) {
+// distance transform of `src` (default: ctx->d_bits0, the grid as uploaded).  Any of d_dist_img / d_d2 / d_bits_out may be null.
+int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uint32_t* d_d2, uint32_t* d_bits_out, const uint32_t* src) {
     const int w = ctx->gw, h = ctx->gh;
     uint16_t* d_g = nullptr;
     hipError_t e = hipMalloc((void**)&d_g, sizeof(uint16_t) * (size_t)w * h);
     if (e != hipSuccess) return check_hip(ctx, e, "hipMalloc(edt scratch)");
     dim3 grid((w + 255) / 256, h);
-    hipLaunchKernelGGL(k_edt_cols, grid, dim3(256), 0, ctx->stream, ctx->d_bits0, w, h, ctx->gwwords, cap, d_g);
+    hipLaunchKernelGGL(k_edt_cols, grid, dim3(256), 0, ctx->stream, src ? src : ctx->d_bits0, w, h, ctx->gwwords, cap, d_g);
     const size_t lds = sizeof(uint16_t) * (size_t)(256 + 2 * cap);
     hipLaunchKernelGGL(k_edt_rows, grid, dim3(256), lds, ctx->stream, d_g, w, h, ctx->gwwords, cap, ctx->res, thr2,
                        d_dist_img, d_d2, d_bits_out);
@@ -86,6 +86,26 @@ int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uin
     hipError_t es = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_g);
     if (rc == F1P_OK) rc = check_hip(ctx, es, "hipStreamSynchronize(edt)");
+    return rc;
+}
+
+// CLEARANCE map of the active collision bitmap (ctx->d_bits): bit = 1 where the centre of the cell is within `dist_cells` of the
+// centre of an occupied (or out-of-image) cell.  The f32 lattice filter tests one station in 2 r + 1 against it: a station in a
+// cell whose bit is 0 proves the r stations before and after it collision-free.  Rebuilt when the bitmap or the
+// distance changes; a map built for a larger distance (up to 1.3 x) is reused -- it is only more conservative.
+int ensure_clear_map(f1p_ctx* ctx, double dist_cells) {
+    if (!ctx->has_grid || !(dist_cells > 0.0) || dist_cells > 4096.0) return F1P_EINVAL;
+    if (ctx->d_bits_clear && ctx->clear_dist >= dist_cells && ctx->clear_dist <= 1.3 * dist_cells + 0.5) return F1P_OK;
+    const size_t bit_bytes = sizeof(uint32_t) * (size_t)ctx->gwwords * ctx->gh;
+    if (!ctx->d_bits_clear) {
+        hipError_t e = hipMalloc((void**)&ctx->d_bits_clear, bit_bytes);
+        if (e != hipSuccess) { ctx->d_bits_clear = nullptr; return check_hip(ctx, e, "hipMalloc(clearance map)"); }
+    }
+    ctx->clear_dist = 0.0;
+    const double thr = __builtin_floor(dist_cells * dist_cells) + 1.0;        // integer d2 <= D^2  <=>  d2 < floor(D^2) + 1
+    const int cap = (int)__builtin_ceil(dist_cells) + 1;
+    int rc = launch_grid_edt(ctx, cap, (uint32_t)thr, nullptr, nullptr, ctx->d_bits_clear, ctx->d_bits);
+    if (rc == F1P_OK) ctx->clear_dist = dist_cells;
     return rc;
 }
 

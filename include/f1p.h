@@ -292,6 +292,15 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
  * one to finish merges the partial winners, re-emits and tracks: no second launch); n > 0 forces n slices (tests, A/B runs). */
 int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
 
+/* Occupancy test of the f32 filter (mixed schedule, device-sampled goals).  stations_each_side = r > 0 (default 1): the filter
+ * looks up one station in 2 r + 1 in a CLEARANCE map of the active bitmap (cells whose centre is within
+ * r * ds_cap + (sqrt 2 + 1) cells of an occupied or off-map cell, ds_cap = 1.2 * hypot(max look-ahead, max width) / (S - 1);
+ * built on the device at the first plan and whenever the bitmap changes): a tested station in a clear cell proves the r
+ * stations before and after it collision-free, anything else is decided by the fp64 kernels on the real bitmap, so every
+ * output stays bit-identical.  r = 0: every station against the bitmap itself with a boundary band (the first version).
+ * Range 0..2. */
+int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side);
+
 /* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream between k_lattice_filter,
  * k_lattice_refine and k_lattice_select of every following plan; kernel_ms (nullable) receives the three durations of the LAST
  * profiled plan (synchronises on it).  bench.py takes the dominant kernel's duration for `roofline` from here. */
