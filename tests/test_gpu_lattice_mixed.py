@@ -121,3 +121,61 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         for b in out + [d_all, d_c32, d_st, d_poses]:
             b.free()
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
+
+
+def test_clearance_mode_is_exact_and_follows_the_bitmap(ctx, scene):
+    """f1p_lattice_set_clearance: one station in 2 r + 1 looked up in the clearance map (r = 1 default, 2) against every station on
+    the bitmap (r = 0) and the all-fp64 kernel: bit-identical outputs on centred, off-centre and wall-hugging egos; the filter's
+    FREE / HIT claims hold in fp64; the map is rebuilt when the bitmap (inflation, footprint, a new grid) or the goal grid changes"""
+    rl, img, origin = scene
+    from f1tenth_planning_amd.runtime import Context
+    with Context(0) as c:
+        c.set_waypoints(rl); c.set_grid(img, 0.058, origin, 206)
+        cfgs = [synth.bench_lattice_cfg(n_cand=256, n_stations=50), synth.bench_lattice_cfg(n_cand=64, n_stations=17),
+                _abi.lattice_cfg(lookaheads=np.linspace(0.5, 6.0, 12), widths=np.linspace(-1.4, 1.4, 9), n_stations=31, weights=(0.25,) * 4)]
+        for ci, cfg in enumerate(cfgs):
+            C, S = cfg.n_lookahead * cfg.n_width, cfg.n_stations
+            for sigma in (0.3, 0.9):
+                E = 400
+                poses = synth.make_egos(rl, E, seed=17 + ci, pos_sigma=sigma)
+                poses[0, :2] += 400.0; poses[1, :2] += [1.3, 1.3]
+                c.lattice_set_mode(0)
+                want = c.lattice_plan(poses, cfg)
+                d_all = c.alloc(8 * E * C)
+                d_poses = c.to_device(poses)
+                b = (c.alloc(8 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(4 * E), c.alloc(8 * E * S * 4))
+                c.lattice_plan_dev(d_poses, E, cfg, *b, d_all_cost=d_all)
+                c64 = d_all.download(np.float64, (E, C))
+                for r in (0, 1, 2):
+                    c.lattice_set_clearance(r)
+                    d_c, d_s = c.alloc(4 * E * C), c.alloc(4 * E * C)
+                    c.lattice_set_mode(2, d_c, d_s)
+                    got = c.lattice_plan(poses, cfg)
+                    for k in want:
+                        np.testing.assert_array_equal(got[k], want[k], err_msg=f"cfg {ci} sigma {sigma} r {r} {k}")
+                    c.lattice_plan_dev(d_poses, E, cfg, *b)
+                    st = d_s.download(np.int32, (E, C))
+                    assert not ((st == 0) & ~np.isfinite(c64)).any(), "a candidate declared FREE collides in fp64"
+                    assert not ((st == 1) & np.isfinite(c64)).any(), "a candidate declared HIT is free in fp64"
+                    if r > 0 and sigma < 0.5 and ci < 2:
+                        assert (st == 0).mean() > 0.3                       # the mode still decides a good share of the candidates by itself
+                    c.lattice_set_mode(2)
+                c.lattice_set_clearance(1)
+        # the bitmap changes under the cached clearance map: inflation, footprint, a different grid
+        cfg = cfgs[0]
+        poses = synth.make_egos(rl, 300, seed=3, pos_sigma=0.4)
+        for step in ("inflate", "footprint", "plain", "other grid"):
+            if step == "inflate":
+                c.inflate_grid(0.25)
+            elif step == "footprint":
+                c.set_footprint(np.array([-0.1, 0.2, 0.4]), 0.17)
+            elif step == "plain":
+                c.set_footprint((), 0.0)
+            else:
+                img2, origin2 = synth.make_grid(rl[:, :2], size=(1200, 1200), resolution=0.1)
+                c.set_grid(img2, 0.1, origin2, 206)
+            c.lattice_set_mode(0); want = c.lattice_plan(poses, cfg)
+            c.lattice_set_mode(2); got = c.lattice_plan(poses, cfg)
+            for k in want:
+                np.testing.assert_array_equal(got[k], want[k], err_msg=f"{step} {k}")
+            assert 0 < (want["status"] == 0).sum()
