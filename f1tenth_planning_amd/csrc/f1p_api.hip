@@ -66,13 +66,30 @@ struct Stage {
     f1p_ctx* ctx;
     struct Out { void* host; void* dev; size_t bytes; };
     std::vector<Out> outs;
-    size_t total = 0;
+    size_t total = 0, out_total = 0;
+    // Small calls (a single vehicle, a few hundred egos): the outputs -- and inputs of a few hundred bytes, i.e. a pose or two --
+    // live in the context's page-locked, device-visible block: the kernels write their results straight into host memory and no
+    // hipMemcpy is issued at all (each one is ~10-15 us of latency; a single-vehicle plan() is otherwise mostly copies).
+    // Larger inputs still go through a copy: a kernel that re-reads them (previous headings, controls) must find them in HBM.
+    bool zc = false;
+    size_t zc_used = 0;
     explicit Stage(f1p_ctx* c) : ctx(c) {}
     void need(size_t bytes, bool used = true) { if (used) total += al256(bytes); }
-    int begin() { return arena_reset(ctx, total); }
+    int begin() {
+        zc = total <= F1P_SMALL_D2H_BYTES && ensure_bounce(ctx) == F1P_OK;
+        zc_used = 0;
+        return arena_reset(ctx, total);
+    }
+    void* zc_take(size_t bytes) { void* p = ctx->h_bounce + zc_used; zc_used += al256(bytes); return p; }
     template <typename T> int in(const T* host, size_t count, const T** dev) {
         *dev = nullptr;
         if (!host || count == 0) return F1P_OK;
+        if (zc && count * sizeof(T) <= 512) {
+            T* d = (T*)zc_take(count * sizeof(T));
+            memcpy(d, host, count * sizeof(T));
+            *dev = d;
+            return F1P_OK;
+        }
         T* d = (T*)arena_take(ctx, count * sizeof(T));
         F1P_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         *dev = d;
@@ -80,24 +97,18 @@ struct Stage {
     }
     template <typename T> T* out(T* host, size_t count) {
         if (!host || count == 0) return nullptr;
-        T* d = (T*)arena_take(ctx, count * sizeof(T));
+        T* d = zc ? (T*)zc_take(count * sizeof(T)) : (T*)arena_take(ctx, count * sizeof(T));
         outs.push_back({(void*)host, (void*)d, count * sizeof(T)});
         return d;
     }
     int finish() {
-        // Small results (a single vehicle, a few hundred egos): the outputs sit back to back in the arena, so ONE copy into the
-        // context's page-locked bounce buffer and a host-side scatter replace one hipMemcpyAsync per array (~10 us each --
-        // the bulk of a single-vehicle plan()'s latency).
-        if (outs.size() > 1) {
-            char* lo = (char*)outs.front().dev;
-            char* hi = (char*)outs.back().dev + outs.back().bytes;
-            const size_t span = (size_t)(hi - lo);
-            if (span <= F1P_SMALL_D2H_BYTES && ensure_bounce(ctx) == F1P_OK) {
-                F1P_HIP(ctx, hipMemcpyAsync(ctx->h_bounce, lo, span, hipMemcpyDeviceToHost, ctx->stream));
-                F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                for (auto& o : outs) memcpy(o.host, ctx->h_bounce + ((char*)o.dev - lo), o.bytes);
-                return F1P_OK;
-            }
+        if (zc) {
+            auto in_block = [&](const void* p) { return (const char*)p >= ctx->h_bounce && (const char*)p < ctx->h_bounce + F1P_SMALL_D2H_BYTES; };
+            for (auto& o : outs)                                  // an in/out buffer that went through the device arena (larger than a pose)
+                if (!in_block(o.dev)) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+            F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (auto& o : outs) if (in_block(o.dev)) memcpy(o.host, o.dev, o.bytes);
+            return F1P_OK;
         }
         for (auto& o : outs) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
