@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for a in 0 1 3 7; do
+for a in 0 8 1 3 7; do
   if [ $a = 0 ]; then unset F1P_LIBRARY; else export F1P_LIBRARY=$PWD/f1tenth_planning_amd/csrc/libf1p_ab$a.so; fi
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS -f csv -d gpurun_out/abl_$a -o run -- python3 tools/time_mixed.py > gpurun_out/abl_$a.log 2>&1
   python3 - <<PY
