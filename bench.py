@@ -364,7 +364,7 @@ def leg_kmpc_c4(rk, args, steps):
     out["generated_in_kernel"] = {"rollout_steps_per_s": float(E_total) * R * T * steps / g_elapsed, "ms_per_plan": g_elapsed / steps * 1e3,
                                   "kernel_ms": g_ms / steps, "host_boundary_p50_ms": float(np.percentile(ts, 50)),
                                   "note": "f1p_kmpc_plan_*: Philox4x32-10 controls in registers around the ctx's warm start; VALU-bound, no HBM stream; "
-                                          "below 2 x CUs egos the rollouts of one ego are split over several workgroups (last one reduces)"}
+                                          "one workgroup per ego at every batch size (f1p_kmpc_set_groups can split an ego's rollouts; measured slower)"}
     ctx.close()
     return out
 

@@ -904,11 +904,14 @@ static KmpcGenArgs make_gen_args(const f1p_kmpc_sampler* smp) {
     return ga;
 }
 
-// number of workgroups per ego: fill ~2 workgroups per CU when the batch alone cannot, never below one wave of rollout pairs
+// number of workgroups per ego.  One: with the time-parallel tail a single workgroup per ego is the fastest layout at every batch
+// size (measured with kmpc_set_groups, 512 rollouts x 30 steps: E = 1: 20.8 us against 23.6 with two workgroups; E = 128: 27.1
+// against 42.8 / 42.4 / 49.5 with 2 / 4 / 8; E = 1024: 57.6 against 145) -- the second stage's global hand-over (costs through
+// memory, fence, ticket, agent-scope reloads) costs more than the idle CUs gain.  The split path stays for f1p_kmpc_set_groups.
 int kmpc_plan_groups(const f1p_ctx* ctx, int E, int R) {
-    if (ctx->kmpc_groups > 0) return ctx->kmpc_groups;              // test / A-B override
-    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    int G = (2 * cus + E - 1) / E;
+    (void)E;
+    if (ctx->kmpc_groups <= 0) return 1;
+    int G = ctx->kmpc_groups;
     const int g_max = (R + 127) / 128;                               // >= 128 rollouts (64 packed pairs = one wave) per workgroup
     if (G > g_max) G = g_max;
     if (G > 64) G = 64;

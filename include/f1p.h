@@ -398,8 +398,9 @@ int f1p_kmpc_gen_controls_dev(f1p_ctx* ctx, float* d_controls, int32_t E, const 
 int f1p_kmpc_warm_reset(f1p_ctx* ctx);
 int f1p_kmpc_warm_get(f1p_ctx* ctx, float* warm, int32_t E, int32_t T);
 int f1p_kmpc_warm_set(f1p_ctx* ctx, const float* warm, int32_t E, int32_t T);
-/* workgroups per ego of f1p_kmpc_plan_*: 0 = automatic (one per ego when the batch fills the chip, several -- each filtering a
- * slice of the rollouts, the last one to finish reducing -- below 2 x CUs egos); > 0 forces the count (tests, A/B runs) */
+/* workgroups per ego of f1p_kmpc_plan_*: 0 = default (one: measured fastest at every batch size since the refinement and the
+ * re-emission run with the time steps across lanes); > 0 forces the count -- each workgroup filters a slice of the rollouts, the
+ * last one to finish reduces (tests, A/B runs) */
 int f1p_kmpc_set_groups(f1p_ctx* ctx, int32_t groups);
 
 /* ------------------------------------------------------------------------------------------------

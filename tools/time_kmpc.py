@@ -11,7 +11,9 @@ cl = synth.make_centerline(seed=2)
 with Context(0) as ctx:
     ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
     out = []
-    for E in (128, 1024, 8192):
+    groups = int(os.environ.get("KMPC_GROUPS", "0"))
+    ctx.kmpc_set_groups(groups)
+    for E in tuple(int(x) for x in os.environ.get("KMPC_E", "128,1024,8192").split(",")):
         rng = np.random.default_rng(E)
         k = rng.integers(0, len(cl) - 1, E)
         x0 = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.uniform(0.5, 5.5, E), cl[k, 3] + rng.normal(0, 0.1, E)])
@@ -27,4 +29,4 @@ with Context(0) as ctx:
         for call in range(100):
             ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, _abi.kmpc_sampler(seed=1, call=10 + call, use_warm=True), *d, d_bc)
         out.append("E=%d %.4f ms" % (E, ctx.timer_end() / 100))
-    print(os.environ.get("F1P_LIBRARY", "default"), " ".join(out))
+    print(os.environ.get("F1P_LIBRARY", "default"), "groups", groups, " ".join(out))
