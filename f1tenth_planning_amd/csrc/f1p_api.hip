@@ -54,10 +54,11 @@ GridDev grid_dev(const f1p_ctx* ctx) {
     return g;
 }
 
-#define F1P_SMALL_D2H_BYTES ((size_t)64 * 1024)
+#define F1P_SMALL_D2H_BYTES ((size_t)64 * 1024)      // calls up to this size: outputs written by the kernels straight into the page-locked block
+#define F1P_BOUNCE_BYTES ((size_t)1024 * 1024)       // the block; results up to this size come back in ONE copy + a host-side scatter
 static int ensure_bounce(f1p_ctx* ctx) {
     if (ctx->h_bounce) return F1P_OK;
-    F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_bounce, F1P_SMALL_D2H_BYTES, hipHostMallocDefault));
+    F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_bounce, F1P_BOUNCE_BYTES, hipHostMallocDefault));
     return F1P_OK;
 }
 
@@ -103,14 +104,36 @@ struct Stage {
     }
     int finish() {
         if (zc) {
-            auto in_block = [&](const void* p) { return (const char*)p >= ctx->h_bounce && (const char*)p < ctx->h_bounce + F1P_SMALL_D2H_BYTES; };
+            auto in_block = [&](const void* p) { return (const char*)p >= ctx->h_bounce && (const char*)p < ctx->h_bounce + F1P_BOUNCE_BYTES; };
             for (auto& o : outs)                                  // an in/out buffer that went through the device arena (larger than a pose)
                 if (!in_block(o.dev)) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
             F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (auto& o : outs) if (in_block(o.dev)) memcpy(o.host, o.dev, o.bytes);
             return F1P_OK;
         }
-        for (auto& o : outs) F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return gather(nullptr);
+    }
+    // Results to the host: arrays that sit back to back in the arena and together fit the page-locked block come back in ONE copy
+    // and are scattered on the host (a hipMemcpyAsync per array is ~10 us of submission each -- six of them were a third of a
+    // 4096-ego plan()'s latency); anything else (the trajectories) is copied on its own.  `skip`: an output the caller copies itself.
+    int gather(const void* skip) {
+        std::vector<Out*> small;
+        const char *lo = nullptr, *hi = nullptr;
+        for (auto& o : outs) {
+            if (o.host == skip) continue;
+            const char* b = (const char*)o.dev;
+            const char* nlo = lo && lo < b ? lo : b;
+            const char* nhi = hi && hi > b + o.bytes ? hi : b + o.bytes;
+            if ((size_t)(nhi - nlo) <= F1P_BOUNCE_BYTES && o.bytes <= F1P_BOUNCE_BYTES / 4) { small.push_back(&o); lo = nlo; hi = nhi; }
+            else F1P_HIP(ctx, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (small.size() > 1 && ensure_bounce(ctx) == F1P_OK) {
+            F1P_HIP(ctx, hipMemcpyAsync(ctx->h_bounce, lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+            F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (Out* o : small) memcpy(o->host, ctx->h_bounce + ((const char*)o->dev - lo), o->bytes);
+            return F1P_OK;
+        }
+        for (Out* o : small) F1P_HIP(ctx, hipMemcpyAsync(o->host, o->dev, o->bytes, hipMemcpyDeviceToHost, ctx->stream));
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return F1P_OK;
     }
@@ -676,14 +699,11 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
                                        nullptr, nullptr))) return rc;
         F1P_HIP(ctx, hipEventRecord(ctx->ev_chunk[k], ctx->stream));
         F1P_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk[k], 0));
-        for (auto& o : s.outs) {
-            const size_t row = o.bytes / e;
-            F1P_HIP(ctx, hipMemcpyAsync((char*)o.host + e0 * row, (char*)o.dev + e0 * row, n * row, hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
+        F1P_HIP(ctx, hipMemcpyAsync(best_traj + e0 * S * 4, d_bt + e0 * S * 4, n * S * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
     }
+    rc = s.gather(best_traj);                                  // the per-ego scalars of every slice: one copy + scatter, on the planning stream
     F1P_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return F1P_OK;
+    return rc;
 }
 
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state) {
