@@ -278,7 +278,7 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
                          int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
                          double* d_best_traj, double* d_all_cost, double* d_all_traj);
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
- *   mixed = 1 (default): batches of >= 256 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
+ *   mixed = 1 (default): batches of >= 512 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
  *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
  *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;
