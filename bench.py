@@ -136,6 +136,7 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
+        self.oversubscribed = False
 
     def open_context(self):
         """One rank per GPU; fails loudly when the node has fewer devices than local ranks."""
@@ -143,9 +144,12 @@ class Ranks:
         from f1tenth_planning_amd.runtime import Context   # loads libf1p.so before torch is imported
         n = _abi.load_library().f1p_device_count()
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
-        if n < 1 or (self.world > 1 and n < local_world):
+        # F1P_BENCH_OVERSUBSCRIBE=1 (tests only): several ranks share the devices there are, to exercise the N-rank control flow
+        # (barriers, max over ranks, rank-0 line) on a 1-GPU box; RCCL refuses two ranks on one device, so those legs are skipped
+        self.oversubscribed = os.environ.get("F1P_BENCH_OVERSUBSCRIBE") == "1" and n >= 1 and n < local_world
+        if n < 1 or (self.world > 1 and n < local_world and not self.oversubscribed):
             raise SystemExit(f"bench.py: {local_world} ranks on this node but f1p_device_count() = {n}")
-        return Context(self.local_rank)
+        return Context(self.local_rank % n if self.oversubscribed else self.local_rank)
 
     def init(self):
         if self.world > 1:
@@ -390,7 +394,7 @@ def main_lattice(args):
         ctx.lattice_set_mode(0)
     rk.init()
     materialised = args.workload == "lattice-materialised"
-    secondary = not args.no_secondary and not materialised and args.generator == "clothoid"
+    secondary = not args.no_secondary and not materialised and args.generator == "clothoid" and not rk.oversubscribed
     if secondary or cand_sharded:
         rk.init_rccl(ctx)
 
@@ -487,7 +491,7 @@ def main_lattice(args):
 
     # per-kernel durations of the default schedule (HIP events between its three kernels, outside the timed region)
     mixed_ms = None
-    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 256:
+    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 512:
         ctx.lattice_profile(True)
         acc = np.zeros(3)
         for _ in range(max(10, min(args.steps, 50))):

@@ -130,3 +130,26 @@ def test_real_rccl_ranks(world):
         cs = line["candidate_sharded"]
         assert cs["rccl_ranks"] == world and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
         assert line["exchange_selftest"]["matches_np_argmin_on_every_rank"] is True and line["exchange_selftest"]["nan_costs"] > 0
+
+
+@pytest.mark.parametrize("workload", ["lattice", "kmpc"])
+def test_two_ranks_share_one_gpu_control_flow(workload):
+    """the N-rank control flow of bench.py (launcher -> one process per rank -> gloo barrier / max over ranks -> ONE JSON line from
+    rank 0 with n_gpus = N and the whole-job value) on a 1-GPU box: F1P_BENCH_OVERSUBSCRIBE lets the ranks share device 0 (the
+    RCCL legs are skipped -- RCCL refuses two ranks on one device; test_real_rccl_ranks covers them where N devices exist)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["F1P_BENCH_OVERSUBSCRIBE"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--workload", workload, "--latency-iters", "0", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
+    if workload == "lattice":
+        assert line["scaling"] == "weak" and line["config"]["egos_per_gpu"] == 4096
+        assert abs(line["value"] - 2 * line["per_gpu_value"]) < 1e-6 * line["value"]
