@@ -84,10 +84,15 @@ struct SrcStream {
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+    // the 32 x 32 -> 64 products as ONE v_mad_u64_u32 each: the compiler's v_mul_lo_u32 + v_mul_hi_u32 pair costs 1.5x as much
+    // (tools/microbench/intops.hip: 6.5 + 6.4 against 8.5 time units), and Philox is most of this kernel's instructions
+    const uint32_t m0 = 0xD2511F53u, m1 = 0xCD9E8D57u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned long long p0, p1;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "s"(m0), "v"(c0) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "s"(m1), "v"(c2) : "vcc");
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
