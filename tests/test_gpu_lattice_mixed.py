@@ -179,3 +179,30 @@ def test_clearance_mode_is_exact_and_follows_the_bitmap(ctx, scene):
             for k in want:
                 np.testing.assert_array_equal(got[k], want[k], err_msg=f"{step} {k}")
             assert 0 < (want["status"] == 0).sum()
+
+
+def test_few_stations_untrusted_positions_never_decide(ctx, scene):
+    """regression (fuzz seed 378): with 2 or 3 stations one series piece spans the whole clothoid; outside the series' range the f32
+    positions are far off and must decide nothing -- a HIT claimed from them pruned collision-free candidates"""
+    rl, img, origin = scene
+    E = 300
+    poses = synth.make_egos(rl, E, seed=378, pos_sigma=0.4, yaw_sigma=0.3)
+    for S in (2, 3, 5):
+        cfg = _abi.lattice_cfg(lookaheads=np.linspace(0.45, 3.4, 21), widths=np.linspace(-1.19, 1.19, 30), n_stations=S, weights=(0.0, 0.45, 0.27, 0.28))
+        C = cfg.n_lookahead * cfg.n_width
+        d_poses = ctx.to_device(poses)
+        b = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
+        d_all = ctx.alloc(8 * E * C)
+        ctx.lattice_set_mode(0)
+        ctx.lattice_plan_dev(d_poses, E, cfg, *b, d_all_cost=d_all)
+        c64 = d_all.download(np.float64, (E, C))
+        for r in (0, 1):
+            ctx.lattice_set_clearance(r)
+            d_c, d_s = ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+            ctx.lattice_set_mode(2, d_c, d_s)
+            ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+            st = d_s.download(np.int32, (E, C))
+            assert not ((st == 1) & np.isfinite(c64)).any() and not ((st == 0) & ~np.isfinite(c64)).any(), (S, r)
+            ctx.lattice_set_mode(2)
+        ctx.lattice_set_clearance(1)
+        _both(ctx, poses, cfg)
