@@ -57,6 +57,23 @@ def test_random_lattice_configurations(ctx, orc, seed):
     for k in a:
         np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=f"branch and bound differs in {k}")
         np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"mixed precision differs in {k}")
+    # the same three schedules on a candidate shard (the multi-GPU split), and with the filter's other occupancy rules
+    C = n_l * n_w
+    if seed % 3 == 2 and C >= 3 and kw["generator"] == "clothoid":
+        import copy
+        sh = copy.copy(full); sh.cand_begin = int(rng.integers(0, C - 1)); sh.cand_count = int(rng.integers(1, C - sh.cand_begin + 1))
+        ctx.lattice_set_mode(0)
+        sa = ctx.lattice_plan(poses, sh, prev_theta=prev)
+        for r in (0, 2, 1):
+            ctx.lattice_set_clearance(r)
+            ctx.lattice_set_mode(2)
+            sm = ctx.lattice_plan(poses, sh, prev_theta=prev)
+            fm = ctx.lattice_plan(poses, full, prev_theta=prev)
+            for k in sa:
+                np.testing.assert_array_equal(np.asarray(sm[k]), sa[k], err_msg=f"mixed precision (clearance {r}) differs on a shard in {k}")
+            for k in a:
+                np.testing.assert_array_equal(np.asarray(fm[k]), a[k], err_msg=f"mixed precision (clearance {r}) differs in {k}")
+        ctx.lattice_set_mode(1)
     if seed % 2:                                               # the oracle sees the un-inflated image: compare without inflation
         ctx.inflate_grid(0.0)
         a = ctx.lattice_plan(poses, full, prev_theta=prev)
