@@ -205,7 +205,8 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius);
  * longitudinal `offsets` [m] from the pose along its heading.  The bitmap is dilated by `radius` (f1p_inflate_grid) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
  * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the un-dilated grid.  Needs the grid;
- * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel. */
+ * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 512 egos with device-sampled goals --
+ * the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0); outputs are bit-identical either way. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
 
 /* ------------------------------------------------------------------------------------------------

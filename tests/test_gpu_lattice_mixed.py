@@ -206,3 +206,43 @@ def test_few_stations_untrusted_positions_never_decide(ctx, scene):
             ctx.lattice_set_mode(2)
         ctx.lattice_set_clearance(1)
         _both(ctx, poses, cfg)
+
+
+def test_oriented_footprint_under_the_mixed_schedule(scene):
+    """f1p_set_footprint with the f32 filter (clearance mode tests the disc centres; the fp64 refinement repeats station_loop<FOOT>'s
+    arithmetic): bit-identical to the all-fp64 footprint kernel, and the filter's FREE / HIT claims hold against its per-candidate costs"""
+    rl, img, origin = scene
+    from f1tenth_planning_amd.runtime import Context
+    with Context(0) as c:
+        c.set_waypoints(rl); c.set_grid(img, 0.058, origin, 206)
+        for offsets, radius in (((-0.0, 0.29, 0.58 - 0.145), 0.19), ((0.15,), 0.25), ((-0.2, 0.0, 0.2, 0.4), 0.12)):
+            c.set_footprint(offsets, radius)
+            for cfg, sigma in ((synth.bench_lattice_cfg(n_cand=256, n_stations=50), 0.25), (synth.bench_lattice_cfg(n_cand=64, n_stations=23), 0.6)):
+                E = 600
+                C, S = cfg.n_lookahead * cfg.n_width, cfg.n_stations
+                poses = synth.make_egos(rl, E, seed=len(offsets), pos_sigma=sigma)
+                c.lattice_set_mode(0)
+                want = c.lattice_plan(poses, cfg)
+                d_poses = c.to_device(poses)
+                b = (c.alloc(8 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(4 * E), c.alloc(8 * E * S * 4))
+                d_all = c.alloc(8 * E * C)
+                c.lattice_plan_dev(d_poses, E, cfg, *b, d_all_cost=d_all)
+                c64 = d_all.download(np.float64, (E, C))
+                for r in (1, 2):
+                    c.lattice_set_clearance(r)
+                    d_c, d_s = c.alloc(4 * E * C), c.alloc(4 * E * C)
+                    c.lattice_set_mode(2, d_c, d_s)
+                    got = c.lattice_plan(poses, cfg)
+                    for k in want:
+                        np.testing.assert_array_equal(got[k], want[k], err_msg=f"{offsets} r {r} {k}")
+                    c.lattice_plan_dev(d_poses, E, cfg, *b)
+                    st = d_s.download(np.int32, (E, C))
+                    assert not ((st == 0) & ~np.isfinite(c64)).any() and not ((st == 1) & np.isfinite(c64)).any()
+                    assert (st == 0).mean() > 0.2                     # the filter did run and decided a good share by itself
+                    c.lattice_set_mode(2)
+                c.lattice_set_clearance(1)
+            plain_first = want
+        c.set_footprint((), 0.0)
+        c.lattice_set_mode(2)
+        plain = c.lattice_plan(poses, cfg)
+        assert (plain["best_idx"] != plain_first["best_idx"]).any()     # the footprint does change decisions
