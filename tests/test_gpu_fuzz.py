@@ -122,3 +122,37 @@ def test_random_kmpc_configurations(ctx, orc, seed):
     np.testing.assert_array_equal(mixed["best_idx"], want["best_idx"])
     np.testing.assert_allclose(mixed["steer"], want["steer"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(mixed["speed"], want["speed"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("F1P_FUZZ_SEEDS", "12")) // 3)))
+def test_random_footprints_under_the_mixed_schedule(ctx, seed):
+    """random oriented footprints (1..4 discs, offsets to +-0.6 m, radii 0.05..0.3 m) on random maps and goal grids: the mixed schedule
+    (filter clearance 1 and 2) against the all-fp64 footprint kernel, bit for bit"""
+    rng = np.random.default_rng(7000 + seed)
+    rl = synth.make_raceline(seed=seed, n_pts=int(rng.integers(400, 1400)), spacing=float(rng.uniform(0.1, 0.3)))
+    res = float(rng.uniform(0.04, 0.1))
+    side = int(np.ceil((np.ptp(rl[:, 0]) + 8.0) / res)), int(np.ceil((np.ptp(rl[:, 1]) + 8.0) / res))
+    img, origin = synth.make_grid(rl[:, :2], size=(min(side[1], 2600), min(side[0], 2600)), resolution=res, half_width=float(rng.uniform(0.9, 1.6)))
+    ctx.set_waypoints(rl)
+    ctx.set_grid(img, res, origin, 206)
+    n_disc = int(rng.integers(1, 5))
+    ctx.set_footprint(np.sort(rng.uniform(-0.3, 0.6, n_disc)), float(rng.uniform(0.05, 0.3)))
+    E = int(rng.integers(20, 400))
+    poses = synth.make_egos(rl, E, seed=seed, pos_sigma=float(rng.uniform(0.1, 0.6)), yaw_sigma=float(rng.uniform(0.05, 0.4)))
+    n_l, n_w = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    S = int(rng.choice([3, 5, 17, 50, 64, 100]))
+    w = rng.uniform(0, 1, 4)
+    cfg = _abi.lattice_cfg(lookaheads=np.sort(rng.uniform(0.4, 3.5, n_l)), widths=np.sort(rng.uniform(-1.2, 1.2, n_w)), n_stations=S, weights=tuple(w),
+                           track_lookahead=float(rng.uniform(0.3, 1.5)))
+    prev = rng.normal(0, 0.3, (E, S)) if seed % 3 == 0 else None
+    try:
+        ctx.lattice_set_mode(0)
+        a = ctx.lattice_plan(poses, cfg, prev_theta=prev)
+        for r in (1, 2):
+            ctx.lattice_set_clearance(r)
+            ctx.lattice_set_mode(2)
+            m = ctx.lattice_plan(poses, cfg, prev_theta=prev)
+            for k in a:
+                np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"footprint, clearance {r}: mixed precision differs in {k}")
+    finally:
+        ctx.lattice_set_clearance(1); ctx.lattice_set_mode(1); ctx.set_footprint((), 0.0)
