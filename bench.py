@@ -178,7 +178,23 @@ class Ranks:
         self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN); self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
         return bool(lo.item() == hi.item())
 
+    def exchange(self, ctx, d_cost, d_idx, E):
+        """the cross-rank argmin of the candidate-sharded mode: RCCL on the ctx stream; with ranks sharing a GPU (test hook) the same
+        rule on the host through gloo (f1tenth_planning_amd.dist.argmin_allreduce), so that everything around the collective runs"""
+        if not self.oversubscribed:
+            ctx.comm_argmin_dev(d_cost, d_idx, E)
+            return
+        import numpy as np
+        from f1tenth_planning_amd.dist import argmin_allreduce
+        c, i = argmin_allreduce(d_cost.download(np.float64, (E,)), d_idx.download(np.int32, (E,)))
+        d_cost.upload(c); d_idx.upload(i)
+
+    def comm_info(self, ctx):
+        return (self.world, self.rank) if self.oversubscribed else ctx.comm_info()
+
     def init_rccl(self, ctx):
+        if self.oversubscribed:
+            return
         if self.dist:
             from f1tenth_planning_amd.dist import init_rccl
             init_rccl(ctx, self.rank, self.world)
@@ -258,11 +274,11 @@ def leg_candidate_sharded(rk, ctx, rl, steps, E=4096, C=512, S=50, timed=True):
     r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E),
                                                                   ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
     ctx.lattice_plan_dev(d_poses, E, cfg, r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj)     # the unsharded truth
-    nranks, myrank = ctx.comm_info()
+    nranks, myrank = rk.comm_info(ctx)
 
     def step():
         ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost)                                  # this rank's candidate slice
-        ctx.comm_argmin_dev(d_cost, d_idx, E)                                                            # RCCL, same stream
+        rk.exchange(ctx, d_cost, d_idx, E)                                                               # RCCL, same stream
         ctx.lattice_emit_dev(d_poses, E, cfg, d_idx, d_cost, d_steer, d_speed, d_status, d_near, d_traj)
 
     step(); ctx.sync()
@@ -279,9 +295,10 @@ def leg_candidate_sharded(rk, ctx, rl, steps, E=4096, C=512, S=50, timed=True):
         for _ in range(n):
             ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost)
             ctx.sync(); rk.barrier()
-            ctx.timer_begin(); ctx.comm_argmin_dev(d_cost, d_idx, E); ex.append(ctx.timer_end() * 1e3)
+            ctx.timer_begin(); rk.exchange(ctx, d_cost, d_idx, E); ex.append(ctx.timer_end() * 1e3)
         out.update({"exchange_us_p50": float(np.percentile(ex, 50)), "exchange_us_min": float(np.min(ex)), "exchange_bytes_per_rank": E * 12,
-                    "exchange": "all-reduce(min, u64 cost key) + all-reduce(min, i32 index among the holders), RCCL on the ctx stream"})
+                    "exchange": ("host stand-in through gloo (ranks share one GPU: test hook)" if rk.oversubscribed else
+                                 "all-reduce(min, u64 cost key) + all-reduce(min, i32 index among the holders), RCCL on the ctx stream")})
     if timed:
         elapsed, ms_total = timed_region(rk, ctx, step, 3, steps)
         out.update({"ms_per_plan": elapsed / steps * 1e3, "candidate_steps_per_s": float(E) * C * S * steps / elapsed})
@@ -301,7 +318,7 @@ def leg_exchange_selftest(rk, ctx, E=1024):
     cost = np.where(pick < len(special), special[np.minimum(pick, len(special) - 1)], cost)
     idx = (np.arange(W)[:, None] * 64 + rng.integers(0, 64, (W, E))).astype(np.int32)      # rank r holds indices [64 r, 64 r + 64)
     d_c, d_i = ctx.to_device(cost[rk.rank]), ctx.to_device(idx[rk.rank])
-    ctx.comm_argmin_dev(d_c, d_i, E)
+    rk.exchange(ctx, d_c, d_i, E)
     got_c, got_i = d_c.download(np.float64, (E,)), d_i.download(np.int32, (E,))
     # np.argmin over all ranks' candidates ordered by global index: first NaN, else first minimum
     want_i = np.empty(E, np.int32); want_c = np.empty(E)
@@ -394,7 +411,7 @@ def main_lattice(args):
         ctx.lattice_set_mode(0)
     rk.init()
     materialised = args.workload == "lattice-materialised"
-    secondary = not args.no_secondary and not materialised and args.generator == "clothoid" and not rk.oversubscribed
+    secondary = not args.no_secondary and not materialised and args.generator == "clothoid"
     if secondary or cand_sharded:
         rk.init_rccl(ctx)
 

@@ -153,3 +153,26 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
     if workload == "lattice":
         assert line["scaling"] == "weak" and line["config"]["egos_per_gpu"] == 4096
         assert abs(line["value"] - 2 * line["per_gpu_value"]) < 1e-6 * line["value"]
+        # the candidate-sharded leg with TWO real ranks (each evaluates its half of the 512 candidates, host stand-in for the collective):
+        # every rank's seven outputs bit-identical to the unsharded plan; the exchange rule against np.argmin incl. NaN costs
+        cs = line["candidate_sharded"]
+        assert cs["rccl_ranks"] == 2 and cs["candidates_per_rank"] == 256 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
+        assert line["exchange_selftest"]["matches_np_argmin_on_every_rank"] is True and line["exchange_selftest"]["nan_costs"] > 0
+        assert line["kmpc_c4"]["generated_in_kernel"]["rollout_steps_per_s"] > 0
+
+
+def test_candidate_sharded_mode_with_two_ranks_on_one_gpu():
+    """bench.py --shard candidates with two ranks sharing device 0 (host stand-in for the RCCL collective): the strong-scaling line"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["F1P_BENCH_OVERSUBSCRIBE"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "candidates", "--steps", "10",
+                        "--warmup", "2", "--egos", "600", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    cs = line["candidate_sharded"]
+    assert cs["rccl_ranks"] == 2 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
