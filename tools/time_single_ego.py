@@ -35,3 +35,16 @@ for label, groups, mode in (("one workgroup (round 1)", 1, 1), ("slices over wor
     ctx.lattice_set_split(groups); ctx.lattice_set_mode(mode)
     print("  %-52s p50 %.3f ms  p95 %.3f ms" % ((label,) + p50(lambda: lp.plan(pose[0], pose[1], pose[2], pose[3]))))
 ctx.lattice_set_split(0); ctx.lattice_set_mode(1)
+
+# the other reference-shaped classes, one vehicle each
+from f1tenth_planning.control.stanley.stanley import StanleyPlanner
+from f1tenth_planning.control.lqr.lqr import LQRPlanner
+from f1tenth_planning.control.kinematic_mpc.kinematic_mpc import KMPCPlanner, mpc_config
+sp = StanleyPlanner(waypoints=rl)
+print("stanley, 1 vehicle:                     p50 %.3f ms  p95 %.3f ms" % p50(lambda: sp.plan(pose[0], pose[1], pose[2], 3.0)))
+lq = LQRPlanner(waypoints=rl)
+print("lqr, 1 vehicle:                         p50 %.3f ms  p95 %.3f ms" % p50(lambda: lq.plan(pose[0], pose[1], pose[2], 3.0)))
+cl = synth.make_centerline(seed=2)
+km = KMPCPlanner(waypoints=[cl[:, 1], cl[:, 2], cl[:, 3], cl[:, 5]], config=mpc_config())
+st7 = np.array([cl[10, 1], cl[10, 2], 0.0, 3.0, cl[10, 3], 0.0, 0.0])
+print("kinematic MPC (shooting), 1 vehicle:    p50 %.3f ms  p95 %.3f ms" % p50(lambda: km.plan(st7)))
