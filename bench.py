@@ -110,6 +110,9 @@ def self_launch(args, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    # every rank, however it was launched (self-launch above, or the driver's own torchrun): dmabuf IPC before anything loads
+    # HIP -- RCCL across processes fails with `hipIpcGetMemHandle: invalid argument` on this pool without it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, argv))
     sys.path.insert(0, ROOT)
@@ -192,14 +195,33 @@ class Ranks:
     def comm_info(self, ctx):
         return (self.world, self.rank) if self.oversubscribed else ctx.comm_info()
 
-    def init_rccl(self, ctx):
+    def init_rccl(self, ctx, timeout_s=120.0):
+        """ncclCommInitRank under a watchdog: a rank whose communicator has not come up within timeout_s prints why and exits
+        non-zero (os._exit from a timer thread -- never a re-exec), so a wedged bootstrap fails the run instead of hanging it."""
         if self.oversubscribed:
             return
-        if self.dist:
-            from f1tenth_planning_amd.dist import init_rccl
-            init_rccl(ctx, self.rank, self.world)
-        else:
-            ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        import threading
+
+        def wedged():
+            sys.stderr.write(f"bench.py: rank {self.rank}/{self.world}: the RCCL communicator did not come up within {timeout_s:.0f} s "
+                             f"(HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}); giving up\n")
+            sys.stderr.flush()
+            os._exit(3)
+        dog = threading.Timer(float(os.environ.get("F1P_RCCL_INIT_TIMEOUT_S", timeout_s)), wedged)
+        dog.daemon = True
+        dog.start()
+        try:
+            if self.dist:
+                from f1tenth_planning_amd.dist import init_rccl
+                init_rccl(ctx, self.rank, self.world)
+            else:
+                ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        finally:
+            dog.cancel()
+
+    def env_ok(self):
+        """HSA_ENABLE_IPC_MODE_LEGACY=0 on EVERY rank (set by main() when the launcher did not)"""
+        return self.all_equal_int(1 if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" else 0) and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
 
     def close(self):
         if self.dist:
@@ -552,6 +574,7 @@ def main_lattice(args):
         acc /= max(10, min(args.steps, 50))
         mixed_ms = {"k_lattice_filter": float(acc[0]), "k_lattice_refine": float(acc[1]), "k_lattice_select": float(acc[2])}
 
+    env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
     if secondary and not cand_sharded:
         cs, _, _ = leg_candidate_sharded(rk, ctx, rl, max(10, min(args.steps, 100)))
@@ -620,6 +643,11 @@ def main_lattice(args):
             "all_fp64": fp64,
             "branch_and_bound": bnb,
             "candidate_sharded": cs,
+            # top level for multi-GPU runs: the communicator's own rank count and the exchange alone (HIP events around the two
+            # collectives + the two key kernels).  At one rank the "exchange" is a local self-reduce: no xGMI figure.
+            "rccl_ranks": None if cs is None else cs.get("rccl_ranks"),
+            "exchange_us_p50": None if cs is None else cs.get("exchange_us_p50"),
+            "multi_process_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "zero_on_every_rank": bool(env_ok)},
             "exchange_selftest": selftest,
             "kmpc_c4": kmpc_c4,
             "two_plans_in_flight": two_in_flight,
@@ -825,6 +853,7 @@ def main_kmpc(args):
             ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, d_bc if args.kmpc_cost else None)
     elapsed, ms_total = timed_region(rk, ctx, step, args.warmup, args.steps)
     kernel_ms = ms_total / args.steps
+    env_ok = rk.env_ok()
     if not stream and not args.no_cpu_baseline and rank == 0:      # parity leg: the last plan's controls, materialised, for the oracle
         ctx.kmpc_warm_reset()
         smp = _abi.kmpc_sampler(seed=2 + rank, call=12345, use_warm=False)
@@ -837,6 +866,7 @@ def main_kmpc(args):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 on f32 controls" if args.kmpc_f64 else "f32 filter + f64 refinement of the near-minimum set (decision in f64)",
                "data": "synthetic",
+               "multi_process_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "zero_on_every_rank": bool(env_ok)},
                "config": {"workload": f"kmpc shooting: {E_total} egos x {R} rollouts x {T} steps over {world} GPU(s), {E} egos per GPU (BASELINE configs[4])",
                           "controls": "streamed from HBM (f32 [E][T][2][R])" if stream else "generated in the kernel (Philox4x32-10 around the device-resident warm start)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

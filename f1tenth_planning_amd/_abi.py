@@ -203,6 +203,7 @@ PROTOTYPES = {
     "f1p_kmpc_warm_get": (C.c_int, [_P, _P, _I, _I]),
     "f1p_kmpc_warm_set": (C.c_int, [_P, _P, _I, _I]),
     "f1p_kmpc_set_groups": (C.c_int, [_P, _I]),
+    "f1p_kmpc_set_yaw_fixup": (C.c_int, [_P, _I]),
     "f1p_stmpc_cfg_default": (None, [C.POINTER(StmpcCfg)]),
     "f1p_stmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P]),
     "f1p_stmpc_ref_batch": (C.c_int, [_P, _P, _I, _I, _D, _D, _P]),
@@ -236,6 +237,9 @@ def load_library(path=None):
             f"libf1p.so not found at {p}: the HIP extension is required (there is no CPU fallback). "
             "Run `make -C f1tenth_planning_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
     mode = os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0)
+    # dmabuf IPC for multi-process GPU work (RCCL ranks, shared device memory): the host driver of this pool supports nothing
+    # else, and the HSA runtime reads the variable when it is loaded -- so it is defaulted HERE, before the library pulls it in
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         lib = C.CDLL(p, mode=mode)
     except OSError as e:  # pragma: no cover

@@ -58,6 +58,15 @@ class State:
     beta: float = 0.0
 
 
+def _fold_cyaw_inplace(cyaw, yaw):
+    """The reference's heading fix-up (kinematic_mpc.py:198-203) with its exact semantics: IN PLACE on the caller's course-heading
+    array, persistent across calls, the second mask evaluated after the first edit."""
+    m = cyaw - yaw > 4.5
+    cyaw[m] = np.abs(cyaw[m] - (2 * np.pi))
+    m = cyaw - yaw < -4.5
+    cyaw[m] = np.abs(cyaw[m] + (2 * np.pi))
+
+
 def _cfg_struct(c: mpc_config, n_rollouts=None):
     return _abi.kmpc_cfg(horizon=c.TK, n_rollouts=n_rollouts or c.N_ROLLOUTS, dt=c.DTK, wheelbase=c.WB, max_steer=c.MAX_STEER,
                          max_dsteer=c.MAX_DSTEER, max_speed=c.MAX_SPEED, min_speed=c.MIN_SPEED, max_accel=c.MAX_ACCEL,
@@ -94,7 +103,10 @@ class KMPCPlanner:
             self._ctx = Context(dev)
         return self._ctx
 
-    def _bind(self, waypoints):
+    def _bind(self, waypoints, fold_yaw=None):
+        """fold_yaw: the vehicle heading of a single-vehicle call -- the course headings are then folded in place on the caller's
+        array like the reference does (persistent state, :198-203) and the kernel's own stateless per-ego fold is switched off;
+        None (batches): the kernel folds the gathered values per ego and the caller's array is left alone."""
         if waypoints is not None:
             w = np.asarray(waypoints)
             if len(w.shape) != 2 or w.shape[1] < 3:
@@ -105,6 +117,9 @@ class KMPCPlanner:
         path = self.waypoints
         cx, cy, cyaw, sp = (np.asarray(path[k], dtype=np.float64) for k in range(4))             # :479-482
         ctx = self._context()
+        if fold_yaw is not None:
+            _fold_cyaw_inplace(cyaw, fold_yaw)                 # np.asarray of a float64 array is the caller's own array
+        ctx.kmpc_set_yaw_fixup(fold_yaw is None)
         ctx.set_waypoints_cached(np.column_stack([cx, cy, sp, cyaw]), cols=(0, 1, 2, 3))
         return ctx
 
@@ -119,7 +134,7 @@ class KMPCPlanner:
         states: [x, y, delta, v, yaw, yawrate, beta] (the 7-state of f110_gym, :139-147).
         Returns (steering_angle, speed).
         """
-        ctx = self._bind(waypoints)
+        ctx = self._bind(waypoints, fold_yaw=float(states[4]))
         vehicle_state = State(x=states[0], y=states[1], delta=states[2], v=states[3], yaw=states[4], yawrate=states[5],
                               beta=states[6])
         x0 = np.array([[vehicle_state.x, vehicle_state.y, vehicle_state.v, vehicle_state.yaw]], dtype=np.float64)   # :487
@@ -165,9 +180,26 @@ class KMPCPlanner:
                                             np.asarray(od, dtype=np.float64)[None, :], cfg)[0]
 
     def calc_ref_trajectory_kinematic(self, state, cx, cy, cyaw, sp):
-        """Reference trajectory [4, T+1] (rows x, y, v, yaw) along the course from the nearest point (:162-206).  Unlike the
-        reference, the caller's `cyaw` array is not modified (the +-2 pi fix-up of :198-203 is applied to the gathered values)."""
+        """Reference trajectory [4, T+1] (rows x, y, v, yaw) along the course from the nearest point (:162-206).  Like the
+        reference, a writable `cyaw` array is folded IN PLACE (:198-203) -- repeated calls with one array see the earlier
+        calls' edits (golden G15: a sequence whose heading representation jumps by +-2 pi)."""
         ctx = self._context()
+        if isinstance(cyaw, np.ndarray) and cyaw.dtype == np.float64 and cyaw.flags.writeable:
+            _fold_cyaw_inplace(cyaw, state.yaw)
+            ctx.kmpc_set_yaw_fixup(False)
+        else:                                                  # a list / read-only view: stateless fold on the device
+            ctx.kmpc_set_yaw_fixup(True)
         ctx.set_waypoints_cached(np.column_stack([cx, cy, sp, cyaw]), cols=(0, 1, 2, 3))
         c = self.config
         return ctx.kmpc_ref(np.array([[state.x, state.y, state.v, state.yaw]], dtype=np.float64), c.TK, c.DTK, c.dlk)[0]
+
+    def update_state_kinematic(self, state, a, delta):
+        """One explicit-Euler step of the kinematic bicycle (:223-243) on the GPU (k_kmpc_predict with a one-step horizon):
+        steering clamped to +-MAX_STEER, x / y / yaw advanced with the OLD speed and heading, then the speed, clamped to
+        [MIN_SPEED, MAX_SPEED]; `a` is not clamped.  Mutates and returns `state` like the reference."""
+        cfg = _cfg_struct(self.config)
+        cfg.horizon = 1
+        path = self._context().kmpc_predict(np.array([[state.x, state.y, state.v, state.yaw]], dtype=np.float64),
+                                            np.array([[a]], dtype=np.float64), np.array([[delta]], dtype=np.float64), cfg)[0]
+        state.x, state.y, state.v, state.yaw = (float(path[k, 1]) for k in range(4))
+        return state

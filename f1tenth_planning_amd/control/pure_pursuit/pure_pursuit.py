@@ -53,6 +53,24 @@ class PurePursuitPlanner():
         ctx.set_waypoints_cached(self.waypoints)
         return ctx
 
+    def _get_current_waypoint(self, lookahead_distance, position, theta):
+        """The waypoint plan() steers towards (pure_pursuit.py:56-83): [x, y of the vertex after the look-ahead circle's first
+        intersection, speed of the NEAREST vertex] when the path is within the look-ahead distance; the whole nearest row when it
+        is within max_reacquire; None otherwise.  One k_pure_pursuit launch: its (nearest index, look-ahead index, branch)
+        outputs are exactly the reference's (i, i2, branch); look-ahead index -1 is the last row, as in numpy."""
+        if self.waypoints is None:
+            raise ValueError('Please set waypoints to track during planner instantiation or when calling plan()')
+        ctx = self._context()
+        ctx.set_waypoints_cached(self.waypoints)
+        out = ctx.pure_pursuit(np.array([[position[0], position[1], theta]], dtype=np.float64), lookahead_distance,
+                               self.wheelbase, self.max_reacquire)
+        status, i, i2 = int(out["status"][0]), int(out["near_idx"][0]), int(out["la_idx"][0])
+        if status == _abi.ST_NO_LOOKAHEAD:
+            return None
+        if status == _abi.ST_REACQUIRE:
+            return self.waypoints[i, :]
+        return np.array([self.waypoints[i2, 0], self.waypoints[i2, 1], self.waypoints[i, 2]])
+
     def plan(self, pose_x, pose_y, pose_theta, lookahead_distance, waypoints=None):
         """
         Returns (steering_angle, speed) for one vehicle -- the order the reference code returns (:122).

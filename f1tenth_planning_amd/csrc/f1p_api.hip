@@ -444,7 +444,7 @@ static void drop_grid(f1p_ctx* ctx) {
     if (ctx->d_bits0) (void)hipFree(ctx->d_bits0);
     if (ctx->d_bits_clear) (void)hipFree(ctx->d_bits_clear);
     ctx->d_bits_clear = nullptr; ctx->clear_dist = 0.0;
-    ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0; ctx->n_disc = 0;
+    ctx->d_bits = nullptr; ctx->d_bits0 = nullptr; ctx->has_grid = false; ctx->inflate_radius = 0.0; ctx->user_inflate = 0.0; ctx->disc_radius = 0.0; ctx->n_disc = 0;
 }
 
 int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double res, double ox, double oy,
@@ -496,10 +496,9 @@ int f1p_grid_distance_batch(f1p_ctx* ctx, float* dist, int32_t cap_cells) {
     return rc;
 }
 
-int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
-    F1P_ENTER(ctx);
-    if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
-    if (!(radius >= 0.0) || !isfinite(radius)) return set_error(ctx, F1P_EINVAL, "inflation radius must be finite and >= 0");
+// the active bitmap = the uploaded grid dilated by ONE disc of radius user_inflate + disc_radius (exact Euclidean distance
+// transform, k_grid.hip): the user's inflation and the footprint's disc radius add, neither replaces the other
+static int apply_dilation(f1p_ctx* ctx, double radius) {
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->clear_dist = 0.0;                                  // the active bitmap changes: its clearance map is stale
     if (radius == 0.0) {
@@ -517,14 +516,26 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
     return rc;
 }
 
+int f1p_inflate_grid(f1p_ctx* ctx, double radius) {
+    F1P_ENTER(ctx);
+    if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
+    if (!(radius >= 0.0) || !isfinite(radius)) return set_error(ctx, F1P_EINVAL, "inflation radius must be finite and >= 0");
+    const int rc = apply_dilation(ctx, radius + ctx->disc_radius);
+    if (rc == F1P_OK) ctx->user_inflate = radius;
+    return rc;
+}
+
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius) {
     F1P_ENTER(ctx);
     if (n_discs < 0 || n_discs > 4 || (n_discs > 0 && !offsets)) return set_error(ctx, F1P_EINVAL, "between 0 and 4 footprint discs are supported");
     if (!ctx->has_grid) return set_error(ctx, F1P_ESTATE, "occupancy grid not set: call f1p_set_grid first");
+    if (n_discs > 0 && (!(radius >= 0.0) || !isfinite(radius))) return set_error(ctx, F1P_EINVAL, "footprint disc radius must be finite and >= 0");
     for (int d = 0; d < n_discs; ++d)
         if (!isfinite(offsets[d]) || fabs(offsets[d]) > 100.0) return set_error(ctx, F1P_EINVAL, "footprint offsets must be finite and within +-100 m");
-    int rc = f1p_inflate_grid(ctx, n_discs > 0 ? radius : 0.0);       // the disc radius becomes the dilation of the bitmap
+    const double disc = n_discs > 0 ? radius : 0.0;
+    int rc = apply_dilation(ctx, ctx->user_inflate + disc);           // the disc radius adds to the user's inflation; n_discs = 0 restores it
     if (rc) return rc;
+    ctx->disc_radius = disc;
     ctx->n_disc = n_discs;
     for (int d = 0; d < 4; ++d) ctx->disc_off[d] = d < n_discs ? offsets[d] : 0.0;
     return F1P_OK;
@@ -949,6 +960,12 @@ int f1p_kmpc_warm_set(f1p_ctx* ctx, const float* warm, int32_t E, int32_t T) {
     F1P_HIP(ctx, hipMemcpyAsync(ctx->d_kmpc_warm, warm, sizeof(float) * 2 * (size_t)E * T, hipMemcpyHostToDevice, ctx->stream));
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->kmpc_warm_valid = true;
+    return F1P_OK;
+}
+
+int f1p_kmpc_set_yaw_fixup(f1p_ctx* ctx, int32_t on) {
+    F1P_ENTER(ctx);
+    ctx->kmpc_yaw_fixup = on ? 1 : 0;
     return F1P_OK;
 }
 

@@ -28,7 +28,9 @@ struct f1p_ctx {
     bool has_grid = false;
     uint32_t* d_bits = nullptr;    // active collision bitmap (the uploaded grid, or its inflation by f1p_inflate_grid)
     uint32_t* d_bits0 = nullptr;   // the grid as uploaded
-    double inflate_radius = 0.0;
+    double inflate_radius = 0.0;   // dilation of the active bitmap = user_inflate + disc_radius
+    double user_inflate = 0.0;     // f1p_inflate_grid's radius (kept across f1p_set_footprint)
+    double disc_radius = 0.0;      // f1p_set_footprint's disc radius (0 without a footprint)
     uint32_t* d_bits_clear = nullptr;   // clearance map of d_bits for the f32 lattice filter (k_grid.hip ensure_clear_map); null / clear_dist 0 = stale
     double clear_dist = 0.0;            // centre distance [cells] it was built for
     int lattice_clear_r = 1;            // stations proved free on each side of a tested one (0 = test every station against d_bits)
@@ -53,6 +55,7 @@ struct f1p_ctx {
     bool kmpc_warm_valid = false;
     char* d_kmpc_scratch = nullptr;    // split-rollout mode: per-ego tickets [cap_E] | [cap_E][cap_R] filter costs (layout by capacity)
     int kmpc_cap_E = 0, kmpc_cap_R = 0;
+    int kmpc_yaw_fixup = 1;            // k_kmpc_ref folds gathered course headings (kinematic_mpc.py:198-203); 0: the caller maintains the array
     int kmpc_groups = 0;               // 0 = automatic number of workgroups per ego; > 0 forces it (tests, A/B runs)
 
     // two-kernel branch and bound of the lattice planner: bounds and clothoids handed from the fit kernel to the evaluation kernel
@@ -63,6 +66,7 @@ struct f1p_ctx {
     int lattice_mixed = 1;
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;
+    bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
     hipEvent_t ev_prof[4] = {};
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null

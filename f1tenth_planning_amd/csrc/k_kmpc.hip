@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_kmpc_predict(const double* __restrict__
 __global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
                                                   const double* __restrict__ wx, const double* __restrict__ wy,
                                                   const double* __restrict__ wv, const double* __restrict__ wpsi,
-                                                  const double* __restrict__ wbox, int n,
+                                                  const double* __restrict__ wbox, int n, int yaw_fixup,
                                                   double* __restrict__ ref) {
     __shared__ double sd[4];
     __shared__ int si[4];
@@ -812,8 +812,10 @@ __global__ __launch_bounds__(256) void k_kmpc_ref(const double* __restrict__ sta
         if (il >= n) il -= n;             // :194 single wrap
         if (il < 0 || il >= n) il = il < 0 ? 0 : n - 1;   // the reference would raise IndexError; clamp instead
         double cyw = wpsi[il];            // in-place fix-up of :198-203 applied to the gathered view
-        if (cyw - yaw > 4.5) cyw = fabs(cyw - (2 * F1P_PI));
-        if (cyw - yaw < -4.5) cyw = fabs(cyw + (2 * F1P_PI));
+        if (yaw_fixup) {                  // (0: the caller folds its array itself, persistently, like the reference)
+            if (cyw - yaw > 4.5) cyw = fabs(cyw - (2 * F1P_PI));
+            if (cyw - yaw < -4.5) cyw = fabs(cyw + (2 * F1P_PI));
+        }
         double* r = ref + (size_t)e * 4 * (T + 1);
         r[0 * (T + 1) + j] = wx[il];
         r[1 * (T + 1) + j] = wy[il];
@@ -983,7 +985,7 @@ int launch_kmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, co
 int launch_kmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, double dt, double dl, double* d_ref) {
     if (E <= 0) return F1P_OK;
     hipLaunchKernelGGL(k_kmpc_ref, dim3(E), dim3(256), 0, ctx->stream, d_states, E, horizon, dt, dl, ctx->d_wx, ctx->d_wy,
-                       ctx->d_wv, ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, d_ref);
+                       ctx->d_wv, ctx->d_wpsi, ctx->d_wbox, ctx->n_wp, ctx->kmpc_yaw_fixup, d_ref);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_ref launch");
 }
 

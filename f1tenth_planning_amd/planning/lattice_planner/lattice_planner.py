@@ -59,6 +59,7 @@ class LatticePlanner():
         self._device = device
         self._ctx = None
         self._map = None
+        self._map_gen = 0            # bumped by every set_map: the multi-GPU replicas key on it (id() can be reused)
         self._inflate = 0.0
         self._foot = None
 
@@ -124,6 +125,7 @@ class LatticePlanner():
         occupied_below = int(np.ceil(255.0 * (1.0 - occupied_thresh)))      # v < 255 (1 - thresh)  <=>  p > thresh
         self._map = (np.ascontiguousarray(img), float(resolution), (float(origin[0]), float(origin[1])), occupied_below)
         self._inflate = float(inflate)
+        self._map_gen += 1
         self._foot = None                                    # a new map clears the footprint (f1p_set_grid does)
         if self._ctx is not None:
             self._ctx.set_grid(*self._map)
@@ -143,6 +145,9 @@ class LatticePlanner():
             self._foot = (tuple(offsets), float(np.hypot(0.5 * seg, 0.5 * width)))
         if self._ctx is not None and self._map is not None:
             self._ctx.set_footprint(*self._foot)
+        if getattr(self, "_mc", None) is not None and self._map is not None and self._mc_map is not None and self._mc_map[0] == self._map_gen:
+            self._mc.set_footprint(*self._foot)              # the multi-GPU replicas follow
+            self._mc_map = (self._map_gen, self._inflate, self._foot)
         return self._foot
 
     def load_map(self, yaml_path, inflate=0.0):
@@ -312,11 +317,14 @@ class LatticePlanner():
                 self._mc.close()
             self._mc = MultiContext(None if key == "all" else key)
             self._mc_key, self._mc_map = key, None
-        if self._map is not None and self._mc_map != (id(self._map), self._inflate):
-            self._mc.set_grid(*self._map)
+        want = (self._map_gen, self._inflate, self._foot)
+        if self._map is not None and self._mc_map != want:
+            self._mc.set_grid(*self._map)                    # (clears inflation and footprint on every replica)
             if self._inflate > 0.0:
                 self._mc.inflate_grid(self._inflate)
-            self._mc_map = (id(self._map), self._inflate)
+            if self._foot:
+                self._mc.set_footprint(*self._foot)          # same collision test as the single-GPU context
+            self._mc_map = want
         return self._mc
 
 

@@ -197,14 +197,16 @@ int f1p_set_grid(f1p_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, double 
 int f1p_grid_distance_batch(f1p_ctx* ctx, float* dist, int32_t cap_cells);
 /* Make the collision test footprint-aware: the active bitmap becomes the uploaded grid dilated by a disc of `radius`
  * metres (a cell is occupied iff its distance to an occupied cell is < radius), so the point test of every station is a
- * disc test.  radius = 0 restores the uploaded grid.  Planning kernels are unchanged. */
+ * disc test.  radius = 0 restores the uploaded grid.  Planning kernels are unchanged.  With a footprint installed
+ * (f1p_set_footprint) the dilation is radius + the footprint's disc radius: the two add, neither replaces the other. */
 int f1p_inflate_grid(f1p_ctx* ctx, double radius);
 
 /* Oriented vehicle footprint (the reference's vehicle is LENGTH 0.58 m x WIDTH 0.31 m, kinematic_mpc.py:60-61; its collision hook
  * map_collision, utils/utils.py:297-301, is a stub): the footprint is covered by n_discs discs of `radius` whose centres sit at
- * longitudinal `offsets` [m] from the pose along its heading.  The bitmap is dilated by `radius` (f1p_inflate_grid) and every
+ * longitudinal `offsets` [m] from the pose along its heading.  The bitmap is dilated by `radius` ON TOP OF the inflation the caller
+ * configured with f1p_inflate_grid (one exact dilation by the sum of the two radii) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
- * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the un-dilated grid.  Needs the grid;
+ * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the grid with the caller's inflation alone.  Needs the grid;
  * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 512 egos with device-sampled goals --
  * the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0); outputs are bit-identical either way. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
@@ -403,6 +405,12 @@ int f1p_kmpc_warm_set(f1p_ctx* ctx, const float* warm, int32_t E, int32_t T);
  * re-emission run with the time steps across lanes); > 0 forces the count -- each workgroup filters a slice of the rollouts, the
  * last one to finish reduces (tests, A/B runs) */
 int f1p_kmpc_set_groups(f1p_ctx* ctx, int32_t groups);
+/* The reference extraction's heading fix-up (calc_ref_trajectory_kinematic, kinematic_mpc.py:198-203: course headings more than
+ * 4.5 rad from the vehicle's are folded by abs(. -+ 2 pi), IN PLACE and persistently on the caller's array).  on = 1 (default):
+ * applied per ego to the gathered values, the course array is never modified (batches of egos with different headings).
+ * on = 0: the course heading is used as uploaded -- for a caller that maintains the array itself exactly like the reference
+ * (the single-vehicle KMPCPlanner class does, so that repeated plan() calls see the reference's persistent state). */
+int f1p_kmpc_set_yaw_fixup(f1p_ctx* ctx, int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8f rank 2 -- the dynamic single-track model as a second model for shooting MPC

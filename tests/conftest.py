@@ -36,9 +36,16 @@ def golden():
 
 
 @pytest.fixture(scope="session")
-def tracks(golden):
+def _tracks_data(golden):
     t = golden("tracks.npz")
     return {"spielberg": t["spielberg"], "levine": t["levine"]}
+
+
+@pytest.fixture()
+def tracks(_tracks_data):
+    """fresh copies per test: like the reference, KMPCPlanner.plan() folds the caller's course-heading array IN PLACE
+    (kinematic_mpc.py:198-203), so a test that hands it views of these arrays must not leak the edit into the next test"""
+    return {k: v.copy() for k, v in _tracks_data.items()}
 
 
 @pytest.fixture(scope="session")

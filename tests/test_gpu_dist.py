@@ -139,7 +139,8 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
     RCCL legs are skipped -- RCCL refuses two ranks on one device; test_real_rccl_ranks covers them where N devices exist)"""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # launched by a FOREIGN torchrun (as the driver does for N > 1), without HSA_ENABLE_IPC_MODE_LEGACY: every rank must set it itself
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
     env["F1P_BENCH_OVERSUBSCRIBE"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
@@ -150,7 +151,9 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
+    assert line["multi_process_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "zero_on_every_rank": True}
     if workload == "lattice":
+        assert line["rccl_ranks"] == 2 and line["exchange_us_p50"] > 0
         assert line["scaling"] == "weak" and line["config"]["egos_per_gpu"] == 4096
         assert abs(line["value"] - 2 * line["per_gpu_value"]) < 1e-6 * line["value"]
         # the candidate-sharded leg with TWO real ranks (each evaluates its half of the 512 candidates, host stand-in for the collective):

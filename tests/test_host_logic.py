@@ -103,3 +103,30 @@ def test_synthetic_scene_is_seeded_and_shaped():
     assert eg.shape == (100, 4) and (eg[:, 3] >= 0.5).all()
     c = synth.make_controls(3, 30, 16, seed=3)
     assert c.shape == (3, 30, 2, 16) and c.dtype == np.float32 and np.abs(c[:, :, 1]).max() <= np.float32(0.4189)
+
+
+@pytest.mark.parametrize("use_xxhash", [True, False])
+def test_waypoint_fingerprint_sees_in_place_edits(monkeypatch, use_xxhash):
+    """the cached-upload fingerprint must change under the in-place edits a caller can make to the live raceline the
+    reference keeps a reference to (pure_pursuit.py:103): reversal, column swap, mirror (sign flips on an even number of words),
+    permutations -- round 2's XOR + plain sum missed all of these."""
+    from f1tenth_planning_amd import runtime
+    if not use_xxhash:
+        monkeypatch.setattr(runtime, "_xxhash", None)
+    elif runtime._xxhash is None:
+        pytest.skip("xxhash not importable")
+    rl = synth.make_raceline(seed=0)
+    base = runtime._content_signature(rl)
+    assert base == runtime._content_signature(rl.copy())
+    edits = {
+        "reversed": lambda a: a.__setitem__(slice(None), a[::-1].copy()),
+        "mirrored": lambda a: a.__setitem__((slice(None), 1), -a[:, 1]),
+        "columns swapped": lambda a: a.__setitem__((slice(None), [0, 1]), a[:, [1, 0]]),
+        "two signs": lambda a: (a.__setitem__((3, 1), -a[3, 1]), a.__setitem__((7, 2), -a[7, 2])),
+        "rows rolled": lambda a: a.__setitem__(slice(None), np.roll(a, 1, axis=0)),
+        "one ulp": lambda a: a.__setitem__((100, 0), np.nextafter(a[100, 0], np.inf)),
+    }
+    for name, edit in edits.items():
+        b = rl.copy()
+        edit(b)
+        assert runtime._content_signature(b) != base, name

@@ -433,6 +433,57 @@ def main():
         def YDD(self, s): return 0.5 * np.cos(0.5 * s)
     np.savez_compressed(os.path.join(OUT, "g13_utils_host.npz"), speeds=speeds, A=np.array(As), B=np.array(Bs), K=np.array(Ks),
                         quats=quats, rpy=rpy, arc_traj7=U.sample_traj(Arc(), 7), arc_traj1=U.sample_traj(Arc(), 1))
+    # ---- G15 (round 3): the two reference methods a caller can reach besides plan() -----------------------------------------
+    #   PurePursuitPlanner._get_current_waypoint (pure_pursuit.py:56-83), all three branches, and
+    #   calc_ref_trajectory_kinematic called REPEATEDLY with the same cyaw array (kinematic_mpc.py:198-203 mutates it in place,
+    #   persistently): a sequence whose yaw representation jumps by +-2 pi, so that later calls see the earlier calls' edits
+    rng = np.random.default_rng(15)
+    g = {}
+    pp = PurePursuitPlanner(waypoints=spl)
+    n = 160
+    poses = np.zeros((n, 3))
+    poses[0] = [0.0, -0.84, 3.40]; poses[1] = [30.0, 30.0, 0.0]; poses[2] = [300.0, 300.0, 0.0]
+    k = rng.integers(0, spl.shape[0] - 1, n)
+    for j in range(3, n):
+        base = spl[k[j]]
+        if j < 110:
+            poses[j] = [base[0] + rng.normal(0, 0.3), base[1] + rng.normal(0, 0.3), base[3] + rng.normal(0, 0.2)]
+        elif j < 140:
+            poses[j] = [base[0] + rng.uniform(-12, 12), base[1] + rng.uniform(-12, 12), rng.uniform(-3.2, 3.2)]
+        else:
+            poses[j] = [rng.uniform(150, 400), rng.uniform(150, 400), rng.uniform(-3.2, 3.2)]
+    for j, kback in enumerate(range(0, 6)):                               # the loop seam: look-ahead index -1 / 0
+        base = spl[spl.shape[0] - 2 - kback]
+        poses[100 + j] = [base[0] + rng.normal(0, 0.01), base[1] + rng.normal(0, 0.01), base[3]]
+    Ls = np.where(np.arange(n) % 4 == 3, 1.5, 0.8)
+    kind = np.zeros(n, np.int32); wp = np.full((n, spl.shape[1]), np.nan)
+    for j in range(n):
+        r = pp._get_current_waypoint(Ls[j], poses[j, :2].copy(), poses[j, 2])
+        if r is None:
+            kind[j] = 2
+        else:
+            kind[j] = 0 if r.shape[0] == 3 and spl.shape[1] != 3 else 1
+            wp[j, :r.shape[0]] = r
+    g["gcw_poses"] = poses; g["gcw_lookahead"] = Ls; g["gcw_kind"] = kind; g["gcw_wp"] = wp
+    plk = K.KMPCPlanner.__new__(K.KMPCPlanner)
+    plk.config = K.mpc_config()
+    cx, cy, cyaw0, sp = lev[:, 1].copy(), lev[:, 2].copy(), lev[:, 3].copy(), lev[:, 5].copy()
+    m = 72
+    kk = np.sort(rng.integers(0, lev.shape[0] - 1, m))
+    sx = lev[kk, 1] + rng.normal(0, 0.1, m); sy = lev[kk, 2] + rng.normal(0, 0.1, m)
+    sv = rng.uniform(0.5, 6, m)
+    shift = np.where(np.arange(m) < 24, 0.0, np.where(np.arange(m) < 48, 2 * np.pi, -2 * np.pi))   # the yaw representation jumps
+    syaw = lev[kk, 3] + rng.normal(0, 0.2, m) + shift
+    cyaw = cyaw0.copy()                                                   # ONE array for the whole sequence, like self.waypoints[2]
+    refs = np.zeros((m, 4, plk.config.TK + 1)); changed = np.zeros(m, np.int32)
+    for j in range(m):
+        before = cyaw.copy()
+        s_ = K.State(x=sx[j], y=sy[j], v=sv[j], yaw=syaw[j])
+        refs[j] = plk.calc_ref_trajectory_kinematic(s_, cx, cy, cyaw, sp)
+        changed[j] = int(np.sum(before != cyaw))
+    g["seq_state"] = np.column_stack([sx, sy, sv, syaw]); g["seq_ref"] = refs; g["seq_changed"] = changed
+    g["seq_cyaw_final"] = cyaw; g["seq_cyaw_initial"] = cyaw0
+    np.savez_compressed(os.path.join(OUT, "g15_class_surface.npz"), **g)
     print("golden vectors written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print("  ", f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,4 +1,7 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+#!/bin/bash
+# Run ON THE GPU BOX: VALU / SALU / LDS / transcendental instruction counts of k_lattice_filter for the ablated builds libf1p_ab<N>.so
+set -eu
+cd "${GRAFT_REPO_ROOT:?run via gpurun}"; export TMPDIR=/tmp
 for a in 0 8 1 3 7; do
   if [ $a = 0 ]; then unset F1P_LIBRARY; else export F1P_LIBRARY=$PWD/f1tenth_planning_amd/csrc/libf1p_ab$a.so; fi
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS -f csv -d gpurun_out/abl_$a -o run -- python3 tools/time_mixed.py > gpurun_out/abl_$a.log 2>&1
