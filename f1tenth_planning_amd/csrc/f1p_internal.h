@@ -66,6 +66,8 @@ struct f1p_ctx {
     int lattice_mixed = 1;
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;
+    char* d_rec_scratch = nullptr;     // per-ego records of k_lattice_prologue
+    size_t rec_scratch_bytes = 0;
     bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
     hipEvent_t ev_prof[4] = {};

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock breakdown of k_lattice_prologue (needs the -DF1P_PRO_PHASES build:
+   make -C f1tenth_planning_amd/csrc LIB=libf1p_pph.so OBJDIR=build_pph EXTRA=-DF1P_PRO_PHASES;  F1P_LIBRARY=.../libf1p_pph.so)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from f1tenth_planning_amd import synth
+from f1tenth_planning_amd.runtime import Context
+E, C, S = 4096, 256, 50
+rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+poses = synth.make_egos(rl, E, seed=1)
+names = ["pose load + sincos(theta)", "nearest scan", "argmin + seg_project", "look-ahead centres", "goal frames", "record (lane 0)"]
+with Context(0) as ctx:
+    ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    d_poses = ctx.to_device(poses)
+    b = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
+    d_c, d_s = ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+    ctx.lattice_set_mode(2, d_c, d_s)
+    for _ in range(5): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+    ph = d_c.download(np.float32, (E, C))[:, 32:32 + len(names)]
+    t0 = d_c.download(np.float32, (E, C))[:, 31]
+    tot = ph.sum(1).mean()
+    for k, nm in enumerate(names): print(f"{nm:30s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %   (max {ph[:, k].max():.0f})")
+    print(f"wave lifetime {tot:.0f} ticks mean, {ph.sum(1).max():.0f} max; start-time spread {np.ptp(t0):.0f} ticks (mod 2^24)")
