@@ -292,6 +292,8 @@ void f1p_destroy(f1p_ctx* ctx) {
     for (auto& ev : ctx->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->ev_prof) if (ev) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (auto& st : ctx->pipe_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto& ev : ctx->ev_pipe) if (ev) (void)hipEventDestroy(ev);
     if (ctx->rccl_lib) dlclose(ctx->rccl_lib);
     delete ctx;
 }
@@ -737,6 +739,13 @@ int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side) {
     if (!ctx) return F1P_EINVAL;
     if (stations_each_side < 0 || stations_each_side > 2) return set_error(ctx, F1P_EINVAL, "stations_each_side must be 0, 1 or 2");
     ctx->lattice_clear_r = stations_each_side;
+    return F1P_OK;
+}
+
+int f1p_lattice_set_pipeline(f1p_ctx* ctx, int32_t chunks) {
+    if (!ctx) return F1P_EINVAL;
+    if (chunks < 0 || chunks > 8) return set_error(ctx, F1P_EINVAL, "chunks must be in [0, 8]");
+    ctx->lattice_chunks = chunks;
     return F1P_OK;
 }
 

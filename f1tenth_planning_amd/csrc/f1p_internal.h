@@ -68,6 +68,9 @@ struct f1p_ctx {
     size_t mix_scratch_bytes = 0;
     char* d_rec_scratch = nullptr;     // per-ego records of k_lattice_prologue
     size_t rec_scratch_bytes = 0;
+    int lattice_chunks = 0;            // pipeline chunks of a mixed plan: 0 = automatic, 1 = off (f1p_lattice_set_pipeline)
+    hipStream_t pipe_stream[2] = {};   // the pipeline's two internal streams
+    hipEvent_t ev_pipe[4] = {};        // done (x2), start, stagger
     bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
     hipEvent_t ev_prof[4] = {};

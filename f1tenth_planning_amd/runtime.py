@@ -381,6 +381,10 @@ class Context:
         """f32 filter's occupancy test: one station in 2 r + 1 against the clearance map (r > 0) or every station against the bitmap (0)"""
         self._check(self.lib.f1p_lattice_set_clearance(self.h, int(stations_each_side)))
 
+    def lattice_set_pipeline(self, chunks=0):
+        """chunks of egos a mixed plan is pipelined in over two internal streams (0 = automatic, 1 = off)"""
+        self._check(self.lib.f1p_lattice_set_pipeline(self.h, int(chunks)))
+
     def lattice_profile(self, enable=True, read=False):
         """HIP-event timing between the three kernels of the mixed schedule; read=True returns (filter, refine, select) ms of the
         last profiled plan"""

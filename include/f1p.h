@@ -304,6 +304,13 @@ int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
  * Range 0..2. */
 int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side);
 
+/* Pipelining of one mixed-schedule plan: the ego batch is cut into `chunks` contiguous chunks whose kernels (prologue, candidate
+ * filter, fp64 refinement, selection) run on two internal streams, the second one stage behind the first, so one chunk's
+ * latency-bound kernels overlap the other's VALU-bound filter.  The caller's stream is joined before and after: the call keeps
+ * its in-order semantics and every output is unchanged (egos are independent).  0 = automatic (2 chunks from 2048 egos),
+ * 1 = off, up to 8. */
+int f1p_lattice_set_pipeline(f1p_ctx* ctx, int32_t chunks);
+
 /* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream between k_lattice_filter,
  * k_lattice_refine and k_lattice_select of every following plan; kernel_ms (nullable) receives the three durations of the LAST
  * profiled plan (synchronises on it).  bench.py takes the dominant kernel's duration for `roofline` from here. */

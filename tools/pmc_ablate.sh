@@ -21,6 +21,10 @@ for r in rows:
     if "lattice_filter" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 t=[l.strip() for l in open("gpurun_out/abl_$a.time") if "filter" in l or " ms" in l]
 print("ablate $a:", " | ".join(t))
+dur=collections.defaultdict(list)
+for f in glob.glob("gpurun_out/abl_$a/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)): dur[r["Kernel_Name"].split("(")[0][-28:]].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+print("    kernel us (under the profiler):", {k: round(sum(v)/len(v), 1) for k,v in dur.items() if "lattice" in k})
 print("    per wave:", {k: round(sum(v)/len(v)/16384, 1) for k,v in sorted(agg.items())})
 PY
 done

@@ -22,4 +22,9 @@ with Context(0) as ctx:
     t0 = d_c.download(np.float32, (E, C))[:, 31]
     tot = ph.sum(1).mean()
     for k, nm in enumerate(names): print(f"{nm:30s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %   (max {ph[:, k].max():.0f})")
+    st = d_c.download(np.float32, (E, C))[:, 40:44]
+    print(f"look-ahead: general scans per ego mean {st[:, 0].mean():.3f} max {st[:, 0].max():.0f} (egos with any: {(st[:, 0] > 0).mean() * 100:.1f} %), fast path {st[:, 1].mean() * 100:.1f} %, "
+          f"pairs mean {st[:, 2].mean():.1f} max {st[:, 2].max():.0f}, surely-none radii mean {st[:, 3].mean():.2f}")
+    slow = ph[:, 3] > 2 * np.median(ph[:, 3])
+    print(f"slow look-ahead waves: {slow.mean() * 100:.1f} %; of those: general scans mean {st[slow, 0].mean():.2f}, fast {st[slow, 1].mean() * 100:.0f} %")
     print(f"wave lifetime {tot:.0f} ticks mean, {ph.sum(1).max():.0f} max; start-time spread {np.ptp(t0):.0f} ticks (mod 2^24)")
