@@ -749,12 +749,12 @@ int f1p_lattice_set_pipeline(f1p_ctx* ctx, int32_t chunks) {
     return F1P_OK;
 }
 
-int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[3]) {
+int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[4]) {
     F1P_ENTER(ctx);
     if (kernel_ms) {
         if (!ctx->lattice_profile || !ctx->lattice_profile_valid) return set_error(ctx, F1P_ESTATE, "no profiled mixed-schedule plan has run");
-        F1P_HIP(ctx, hipEventSynchronize(ctx->ev_prof[3]));
-        for (int k = 0; k < 3; ++k) F1P_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_prof[k], ctx->ev_prof[k + 1]));
+        F1P_HIP(ctx, hipEventSynchronize(ctx->ev_prof[4]));
+        for (int k = 0; k < 4; ++k) F1P_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_prof[k], ctx->ev_prof[k + 1]));
     }
     if (enable && !ctx->ev_prof[0])
         for (auto& ev : ctx->ev_prof) F1P_HIP(ctx, hipEventCreate(&ev));

@@ -386,9 +386,9 @@ class Context:
         self._check(self.lib.f1p_lattice_set_pipeline(self.h, int(chunks)))
 
     def lattice_profile(self, enable=True, read=False):
-        """HIP-event timing between the three kernels of the mixed schedule; read=True returns (filter, refine, select) ms of the
-        last profiled plan"""
-        ms = (C.c_float * 3)()
+        """HIP-event timing around the kernels of the mixed schedule; read=True returns (prologue, filter, refine, select) ms of the
+        last profiled plan (prologue = 0 when the one-kernel filter ran)"""
+        ms = (C.c_float * 4)()
         self._check(self.lib.f1p_lattice_profile(self.h, 1 if enable else 0, ms if read else None))
         return tuple(ms) if read else None
 

@@ -307,14 +307,16 @@ int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side);
 /* Pipelining of one mixed-schedule plan: the ego batch is cut into `chunks` contiguous chunks whose kernels (prologue, candidate
  * filter, fp64 refinement, selection) run on two internal streams, the second one stage behind the first, so one chunk's
  * latency-bound kernels overlap the other's VALU-bound filter.  The caller's stream is joined before and after: the call keeps
- * its in-order semantics and every output is unchanged (egos are independent).  0 = automatic (2 chunks from 2048 egos),
- * 1 = off, up to 8. */
+ * its in-order semantics and every output is unchanged (egos are independent).  0 = automatic (currently 1: measured slower than
+ * unpipelined on one MI355X -- the candidate kernel fills every wave slot and each cross-stream edge costs ~10 us), 1 = off, up to 8. */
 int f1p_lattice_set_pipeline(f1p_ctx* ctx, int32_t chunks);
 
-/* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream between k_lattice_filter,
- * k_lattice_refine and k_lattice_select of every following plan; kernel_ms (nullable) receives the three durations of the LAST
- * profiled plan (synchronises on it).  bench.py takes the dominant kernel's duration for `roofline` from here. */
-int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[3]);
+/* Per-kernel timing of the mixed schedule: enable = 1 records HIP events on the ctx stream around the kernels of every following
+ * plan (which then runs unpipelined); kernel_ms (nullable) receives the four durations of the LAST profiled plan (synchronises
+ * on it): [0] k_lattice_prologue (0 when the one-kernel filter ran), [1] the f32 candidate filter, [2] k_lattice_refine,
+ * [3] k_lattice_select.  bench.py takes the dominant kernel's duration for `roofline` from here.  (Round 3: four values, the
+ * prologue is its own kernel.) */
+int f1p_lattice_profile(f1p_ctx* ctx, int32_t enable, float kernel_ms[4]);
 
 /* Re-generate candidate `cand_idx[e]` of each ego and track it: the "emit" half of plan(), used after a
  * cross-rank argmin when one ego's candidates are sharded over several GPUs. */

@@ -3,7 +3,7 @@
 # Kernel trace + separate PMC passes (never combined with other trace domains), outputs under gpurun_out/<tag>_*; the markdown
 # summary and the machine-readable <tag>_pmc.json (parsed by bench.py at run time) are what gets copied into profiles/.
 set -u
-TAG=${1:-r03}; HEAD=${2:-k_lattice_filter}; SCHED=${3:-mixed}
+TAG=${1:-r03}; HEAD=${2:-k_lattice_filter3}; SCHED=${3:-mixed}
 shift $(( $# < 3 ? $# : 3 ))      # (a bare `shift 3` with fewer arguments shifts nothing and the tag would reach bench.py)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out

@@ -31,9 +31,9 @@ with Context(0) as ctx:
             ctx.sync(); ctx.timer_begin()
             for _ in range(100): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
             ms = ctx.timer_end() / 100
-            ctx.lattice_profile(True); acc = np.zeros(3)
+            ctx.lattice_profile(True); acc = np.zeros(4)
             for _ in range(30):
                 ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
             ctx.lattice_profile(False)
-            print(f"sigma {sigma} r {r}: {ms:.4f} ms  filter/refine/select {np.round(acc / 30, 4)}  free {float((st == 0).mean()):.3f} hit {float((st == 1).mean()):.4f} unsure {float((st == 2).mean()):.3f}  identical {same}")
+            print(f"sigma {sigma} r {r}: {ms:.4f} ms  prologue/filter/refine/select {np.round(acc / 30, 4)}  free {float((st == 0).mean()):.3f} hit {float((st == 1).mean()):.4f} unsure {float((st == 2).mean()):.3f}  identical {same}")
         ctx.lattice_set_clearance(1)

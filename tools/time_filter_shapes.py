@@ -13,8 +13,8 @@ with Context(0) as ctx:
     for nl, nw in ((16, 16), (4, 64), (1, 64), (1, 1), (16, 1)):
         cfg = _abi.lattice_cfg(lookaheads=np.linspace(0.6, 3.0, nl) if nl > 1 else [1.8], widths=np.linspace(-1, 1, nw) if nw > 1 else [0.0], n_stations=S, weights=(0.25,) * 4)
         ctx.lattice_set_mode(2); ctx.lattice_profile(True)
-        acc = np.zeros(3)
+        acc = np.zeros(4)
         for _ in range(10): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
         for _ in range(30):
             ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
-        print(f"n_l {nl:2d} n_w {nw:2d} C {nl*nw:4d}: filter {acc[0]/30*1e3:7.1f} us  refine {acc[1]/30*1e3:6.1f}  select {acc[2]/30*1e3:6.1f}")
+        print(f"n_l {nl:2d} n_w {nw:2d} C {nl*nw:4d}: prologue {acc[0]/30*1e3:6.1f} us  filter {acc[1]/30*1e3:7.1f}  refine {acc[2]/30*1e3:6.1f}  select {acc[3]/30*1e3:6.1f}")

@@ -16,8 +16,8 @@ with Context(0) as ctx:
     for _ in range(100): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
     print(os.environ.get("F1P_LIBRARY", "default"), "%.4f ms" % (ctx.timer_end() / 100))
     ctx.lattice_profile(True)
-    acc = np.zeros(3)
+    acc = np.zeros(4)
     for _ in range(50):
         ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
     ctx.lattice_profile(False)
-    print("   filter %.4f  refine %.4f  select %.4f ms (HIP events between the kernels)" % tuple(acc / 50))
+    print("   prologue %.4f  filter %.4f  refine %.4f  select %.4f ms (HIP events between the kernels)" % tuple(acc / 50))
