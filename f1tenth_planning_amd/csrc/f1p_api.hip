@@ -139,8 +139,8 @@ struct Stage {
     }
 };
 
-#ifndef F1P_PLAN_CHUNKS
-#define F1P_PLAN_CHUNKS 2
+#ifndef F1P_TRAJ_ZEROCOPY
+#define F1P_TRAJ_ZEROCOPY 1
 #endif
 #define F1P_PLAN_CHUNK_MIN_EGOS 2048
 #define F1P_PLAN_CHUNKS_MAX 8          // = number of slice events in f1p_ctx
@@ -646,17 +646,33 @@ int f1p_lqr_batch(f1p_ctx* ctx, const double* states, double* err, int32_t E, do
 }
 
 // ---------------------------------------------------------------------------------------------------
-int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
-                         int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
-                         int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
-                         double* d_best_traj, double* d_all_cost, double* d_all_traj) {
-    F1P_ENTER(ctx);
+static int lattice_plan_dev_impl(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                                 int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                                 int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
+                                 double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32) {
     int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_best_idx && (cfg && cfg->cand_count > 0 ? true : (d_steer && d_speed))));
     if (rc) return rc;
     // a candidate shard evaluates only (cost + index); the emit half runs after the cross-rank argmin
     const int mode = cfg->cand_count > 0 ? LATTICE_EVAL : LATTICE_FULL;
     return launch_lattice(ctx, mode, d_poses, d_goals, d_prev_theta, E, cfg, nullptr, nullptr, d_steer, d_speed, d_best_idx,
-                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj);
+                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj, d_best_traj32);
+}
+
+int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                         int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                         int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
+                         double* d_best_traj, double* d_all_cost, double* d_all_traj) {
+    F1P_ENTER(ctx);
+    return lattice_plan_dev_impl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
+                                 d_best_traj, d_all_cost, d_all_traj, nullptr);
+}
+
+int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                             int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                             int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx, float* d_best_traj32) {
+    F1P_ENTER(ctx);
+    return lattice_plan_dev_impl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
+                                 nullptr, nullptr, nullptr, d_best_traj32);
 }
 
 int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,
@@ -669,11 +685,14 @@ int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
                           nullptr, nullptr, d_status, d_near_idx, d_best_traj, nullptr, nullptr);
 }
 
-int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
-                           int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
-                           double* best_cost, int32_t* status, int32_t* near_idx, double* best_traj,
-                           double* all_cost, double* all_traj) {
-    F1P_ENTER(ctx);
+// TRAJ = double (the reference's fp64 rows) or float (f1p_lattice_plan_batch_f32: the same rows rounded once on the device)
+extern "C++" {
+template <typename TRAJ>
+static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                                   int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
+                                   double* best_cost, int32_t* status, int32_t* near_idx, TRAJ* best_traj,
+                                   double* all_cost, double* all_traj) {
+    constexpr bool F32 = sizeof(TRAJ) == 4;
     int rc = validate_lattice(ctx, cfg, E, goals == nullptr, E == 0 || (poses && best_idx && ((cfg && cfg->cand_count > 0) || (steer && speed))));
     if (rc) return rc;
     if (cfg->cand_count > 0 && (steer || speed || status || best_traj))
@@ -683,7 +702,7 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
     Stage s(ctx);
     s.need(8 * 4 * e); s.need(8 * e * C * 3, goals); s.need(8 * e * S, prev_theta);
     s.need(8 * e, steer); s.need(8 * e, speed); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
-    s.need(8 * e * S * 4, best_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
+    s.need(sizeof(TRAJ) * e * S * 4, best_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
     if ((rc = s.begin())) return rc;
     const double *d_poses, *d_goals, *d_prev;
     if ((rc = s.in(poses, 4 * e, &d_poses))) return rc;
@@ -691,32 +710,57 @@ int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goal
     if ((rc = s.in(prev_theta, e * S, &d_prev))) return rc;
     double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
     double* d_bc = s.out(best_cost, e); int32_t* d_st = s.out(status, e); int32_t* d_ni = s.out(near_idx, e);
-    double* d_bt = s.out(best_traj, e * S * 4); double* d_ac = s.out(all_cost, e * C); double* d_at = s.out(all_traj, e * C * S * 4);
-    // Large winner-only batches are planned in F1P_PLAN_CHUNKS slices: the results of slice k travel to the host on a
-    // second stream while slice k + 1 is being planned, so only the last slice's D2H is exposed in the call's latency.
-    // Only when the trajectories go to PAGE-LOCKED host memory (f1p_host_alloc / hipHostRegister): copies into pageable
-    // memory block the calling thread and would serialise the slices (measured: 0.58 -> 0.72 ms at 4096 egos).
-    // Two slices up to 8191 egos (a slice of 2048 is two full waves of workgroups over the chip), slices of >= 4096 egos beyond.
-    const int k_big = E >= 8192 ? (E / 4096 < F1P_PLAN_CHUNKS_MAX ? E / 4096 : F1P_PLAN_CHUNKS_MAX) : F1P_PLAN_CHUNKS;
-    const int K = (!all_cost && !all_traj && best_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS && is_pinned_host(best_traj)) ? k_big : 1;
+    // Trajectories into PAGE-LOCKED host memory (f1p_host_alloc / hipHostRegister), 2048 <= E < 8192: the selection kernel writes
+    // them straight into the caller's array (it is device-visible), so the PCIe writes stream while the kernel still runs and no
+    // copy is submitted at all -- measured at 4096 egos, p50 host to host: fp64 rows 0.277 ms (0.287 with one hipMemcpyAsync behind
+    // the plan, 0.294 with the plan in two slices and the copies on a second stream, the round-2 scheme), f32 rows 0.214 (0.230 /
+    // 0.233); slicing only the selection kernel was worse still (0.30 / 0.24: every cross-stream edge costs ~10 us).
+    // From 8192 egos the batch is planned in slices of >= 4096 egos whose results travel on a second stream while the next slice
+    // is planned (only into page-locked memory: copies into pageable memory block the calling thread and would serialise the slices).
+    const bool pinned = best_traj && !all_cost && !all_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS && is_pinned_host(best_traj);
+    const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
+    TRAJ* d_bt = zero_copy_traj ? best_traj : s.out(best_traj, e * S * 4);
+    double* d_ac = s.out(all_cost, e * C); double* d_at = s.out(all_traj, e * C * S * 4);
+    auto plan = [&](size_t e0, size_t n) {
+        double* bt64 = nullptr; float* bt32 = nullptr;
+        if (d_bt) { if (F32) bt32 = reinterpret_cast<float*>(d_bt) + e0 * S * 4; else bt64 = reinterpret_cast<double*>(d_bt) + e0 * S * 4; }
+        return lattice_plan_dev_impl(ctx, d_poses + 4 * e0, d_goals ? d_goals + e0 * C * 3 : nullptr, d_prev ? d_prev + e0 * S : nullptr,
+                                     (int32_t)n, cfg, d_steer ? d_steer + e0 : nullptr, d_speed ? d_speed + e0 : nullptr, d_bi + e0, d_bc ? d_bc + e0 : nullptr,
+                                     d_st ? d_st + e0 : nullptr, d_ni ? d_ni + e0 : nullptr, bt64, e0 == 0 && n == e ? d_ac : nullptr,
+                                     e0 == 0 && n == e ? d_at : nullptr, bt32);
+    };
+    const int K = (pinned && E >= 8192) ? (E / 4096 < F1P_PLAN_CHUNKS_MAX ? E / 4096 : F1P_PLAN_CHUNKS_MAX) : 1;
     if (K > 1 && (rc = ensure_copy_stream(ctx))) return rc;
     if (K == 1) {
-        if ((rc = f1p_lattice_plan_dev(ctx, d_poses, d_goals, d_prev, E, cfg, d_steer, d_speed, d_bi, d_bc, d_st, d_ni, d_bt, d_ac, d_at))) return rc;
+        if ((rc = plan(0, e))) return rc;
         return s.finish();
     }
     for (int k = 0; k < K; ++k) {
         const size_t e0 = e * k / K, e1 = e * (k + 1) / K, n = e1 - e0;
-        if ((rc = f1p_lattice_plan_dev(ctx, d_poses + 4 * e0, d_goals ? d_goals + e0 * C * 3 : nullptr, d_prev ? d_prev + e0 * S : nullptr,
-                                       (int32_t)n, cfg, d_steer + e0, d_speed + e0, d_bi + e0, d_bc ? d_bc + e0 : nullptr,
-                                       d_st ? d_st + e0 : nullptr, d_ni ? d_ni + e0 : nullptr, d_bt ? d_bt + e0 * S * 4 : nullptr,
-                                       nullptr, nullptr))) return rc;
+        if ((rc = plan(e0, n))) return rc;
         F1P_HIP(ctx, hipEventRecord(ctx->ev_chunk[k], ctx->stream));
         F1P_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk[k], 0));
-        F1P_HIP(ctx, hipMemcpyAsync(best_traj + e0 * S * 4, d_bt + e0 * S * 4, n * S * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+        F1P_HIP(ctx, hipMemcpyAsync(best_traj + e0 * S * 4, d_bt + e0 * S * 4, n * S * 4 * sizeof(TRAJ), hipMemcpyDeviceToHost, ctx->copy_stream));
     }
     rc = s.gather(best_traj);                                  // the per-ego scalars of every slice: one copy + scatter, on the planning stream
     F1P_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return rc;
+}
+}  // extern "C++"
+
+int f1p_lattice_plan_batch(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                           int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
+                           double* best_cost, int32_t* status, int32_t* near_idx, double* best_traj,
+                           double* all_cost, double* all_traj) {
+    F1P_ENTER(ctx);
+    return lattice_plan_batch_impl<double>(ctx, poses, goals, prev_theta, E, cfg, steer, speed, best_idx, best_cost, status, near_idx, best_traj, all_cost, all_traj);
+}
+
+int f1p_lattice_plan_batch_f32(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                               int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed, int32_t* best_idx,
+                               double* best_cost, int32_t* status, int32_t* near_idx, float* best_traj32) {
+    F1P_ENTER(ctx);
+    return lattice_plan_batch_impl<float>(ctx, poses, goals, prev_theta, E, cfg, steer, speed, best_idx, best_cost, status, near_idx, best_traj32, nullptr, nullptr);
 }
 
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state) {

@@ -123,7 +123,7 @@ enum LatticeMode { LATTICE_FULL = 0, LATTICE_EVAL = 1, LATTICE_EMIT = 2 };
 int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                    int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
                    double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
-                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj);
+                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32 = nullptr);
 int launch_clothoid_sample(f1p_ctx* ctx, const double* d_params, int n, int S, double* d_rows);
 int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok);
 

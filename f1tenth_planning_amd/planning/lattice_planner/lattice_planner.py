@@ -296,18 +296,19 @@ class LatticePlanner():
                     b.free()
         return steer, speed, status, traj
 
-    def plan_batch(self, poses, waypoints=None, prev_theta=None, want_traj=True, devices=None):
+    def plan_batch(self, poses, waypoints=None, prev_theta=None, want_traj=True, devices=None, traj_dtype=np.float64):
         """poses [E, 4] = (x, y, theta, velocity) -> dict(steer, speed, best_idx, best_cost, status, near_idx[, best_traj]).
         Fused device path only (Python callables cannot run per ego on the GPU).
         devices: list of GPU indices (or "all") -- the egos are cut into contiguous ranges, one per GPU, each planned by its own
         context on its own host thread (runtime.MultiContext; egos are independent, so there is no collective and the result
-        is identical to the single-GPU plan)."""
+        is identical to the single-GPU plan).
+        traj_dtype=np.float32: best_traj as f32 rows (the fp64 rows rounded once on the device; half the bytes across PCIe)."""
         ctx = self._bind(waypoints)
         if devices is None:
-            return ctx.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj)
+            return ctx.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj, traj_dtype=traj_dtype)
         mc = self._multi(devices)
         mc.set_waypoints_cached(self.waypoints)
-        return mc.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj)
+        return mc.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj, traj_dtype=traj_dtype)
 
     def _multi(self, devices):
         from ...runtime import MultiContext

@@ -327,9 +327,14 @@ class Context:
 
     # ---- lattice -------------------------------------------------------------------------------------------
     def lattice_plan(self, poses, cfg: LatticeCfg, goals=None, prev_theta=None, want_traj=True, want_all=False,
-                     reuse_outputs=False):
+                     reuse_outputs=False, traj_dtype=np.float64):
         """reuse_outputs: results land in page-locked arrays owned by the context (no bounce buffers, no fresh pages per
-        call); they are overwritten by the next call with the same batch shape."""
+        call); they are overwritten by the next call with the same batch shape.
+        traj_dtype=np.float32: best_traj comes back as f32 rows (f1p_lattice_plan_batch_f32: the fp64 rows rounded once on the
+        device, half the PCIe bytes); everything else is unchanged."""
+        f32 = np.dtype(traj_dtype) == np.float32
+        if f32 and want_all:
+            raise ValueError("traj_dtype=float32 is a winner-only mode (no all_cost / all_traj)")
         poses = _f64(poses, (-1, 4)); E = poses.shape[0]; Cn = cfg.n_cand; S = cfg.n_stations
         g = None if goals is None else _f64(goals, (E, Cn, 3))
         pt = None if prev_theta is None else _f64(prev_theta, (E, S))
@@ -340,17 +345,23 @@ class Context:
                        best_idx=pin("lat_bidx", E, np.int32), best_cost=pin("lat_bcost", E, np.float64),
                        status=pin("lat_status", E, np.int32), near_idx=pin("lat_near", E, np.int32))
             if want_traj:
-                out["best_traj"] = pin("lat_traj", (E, S, 4), np.float64)
+                out["best_traj"] = pin("lat_traj32" if f32 else "lat_traj", (E, S, 4), np.float32 if f32 else np.float64)
         else:
             out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
                        status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
             if want_traj:
-                out["best_traj"] = np.empty((E, S, 4))
+                out["best_traj"] = np.empty((E, S, 4), np.float32 if f32 else np.float64)
         if want_all:
             out["all_cost"] = np.empty((E, Cn)); out["all_traj"] = np.empty((E, Cn, S, 4))
         if cfg.cand_count > 0:            # a candidate shard only evaluates: (best_idx, best_cost, near_idx)
             for k in ("steer", "speed", "status", "best_traj"):
                 out.pop(k, None)
+        if f32:
+            self._check(self.lib.f1p_lattice_plan_batch_f32(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
+                                                            _ptr(out.get("steer")), _ptr(out.get("speed")), _ptr(out["best_idx"]),
+                                                            _ptr(out["best_cost"]), _ptr(out.get("status")), _ptr(out["near_idx"]),
+                                                            _ptr(out.get("best_traj"))))
+            return out
         self._check(self.lib.f1p_lattice_plan_batch(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
                                                     _ptr(out.get("steer")), _ptr(out.get("speed")), _ptr(out["best_idx"]),
                                                     _ptr(out["best_cost"]), _ptr(out.get("status")), _ptr(out["near_idx"]),
@@ -636,12 +647,12 @@ class MultiContext:
             return call(self.ctxs[0], 0, 0)
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
 
-    def lattice_plan(self, poses, cfg, goals=None, prev_theta=None, want_traj=True):
+    def lattice_plan(self, poses, cfg, goals=None, prev_theta=None, want_traj=True, traj_dtype=np.float64):
         poses = _f64(poses, (-1, 4)); E = poses.shape[0]
         g = None if goals is None else _f64(goals, (E, cfg.n_cand, 3))
         pt = None if prev_theta is None else _f64(prev_theta, (E, cfg.n_stations))
         return self._sharded(E, lambda c, lo, hi: c.lattice_plan(poses[lo:hi], cfg, None if g is None else g[lo:hi],
-                                                                   None if pt is None else pt[lo:hi], want_traj=want_traj))
+                                                                   None if pt is None else pt[lo:hi], want_traj=want_traj, traj_dtype=traj_dtype))
 
     def pure_pursuit(self, poses, lookahead, wheelbase=0.33, max_reacquire=20.0):
         poses = _f64(poses, (-1, 3))

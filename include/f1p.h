@@ -280,6 +280,17 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
                          int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                          int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
                          double* d_best_traj, double* d_all_cost, double* d_all_traj);
+/* The same plan with the winner's trajectory as f32 rows [E][S][4] (x, y, theta, |kappa|): the fp64 rows of f1p_lattice_plan_*
+ * rounded ONCE on the device, everything else unchanged (steer / speed / cost stay fp64, indices exact).  BASELINE's tolerance for
+ * best_traj is 1e-4; a 4 m trajectory in f32 is good to 2.4e-7 m.  Half the bytes across PCIe: at 4096 egos x 50 stations the
+ * trajectories are 3.3 MB instead of 6.6 MB of a 6.7 MB result (SURVEY 8b proposed float outputs).  Winner-only (no all_cost /
+ * all_traj). */
+int f1p_lattice_plan_batch_f32(f1p_ctx* ctx, const double* poses, const double* goals, const double* prev_theta,
+                               int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                               int32_t* best_idx, double* best_cost, int32_t* status, int32_t* near_idx, float* best_traj32);
+int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                             int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                             int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx, float* d_best_traj32);
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
  *   mixed = 1 (default): batches of >= 512 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the

@@ -404,3 +404,29 @@ def test_candidate_slices_over_several_workgroups(ctx, scene):
         ctx.lattice_set_split(0); many = ctx.lattice_plan(poses, cfg)
         for k in one:
             np.testing.assert_array_equal(many[k], one[k], err_msg=f"{k} E={E}")
+
+
+@pytest.mark.parametrize("E", [300, 4096])
+def test_f32_trajectory_output_mode(ctx, orc, scene, E):
+    """f1p_lattice_plan_batch_f32: the winner's rows as f32 = the fp64 rows rounded ONCE (bit for bit), every other
+    output unchanged; against the oracle at BASELINE.md's best_traj tolerance (1e-4), with both schedules (all fp64 below 512
+    egos, the mixed one above), pageable and page-locked destinations (the latter takes the sliced copy path at 4096 egos)."""
+    rl, img, origin = scene
+    cfg = synth.bench_lattice_cfg(n_cand=128 if E < 1000 else 256, n_stations=50)
+    poses = synth.make_egos(rl, E, seed=77)
+    ref = ctx.lattice_plan(poses, cfg)
+    got = ctx.lattice_plan(poses, cfg, traj_dtype=np.float32)
+    assert got["best_traj"].dtype == np.float32 and got["best_traj"].shape == (E, 50, 4)
+    np.testing.assert_array_equal(got["best_traj"], ref["best_traj"].astype(np.float32))
+    for k in ("steer", "speed", "best_idx", "best_cost", "status", "near_idx"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    pinned = ctx.lattice_plan(poses, cfg, traj_dtype=np.float32, reuse_outputs=True)
+    np.testing.assert_array_equal(pinned["best_traj"], got["best_traj"])
+    np.testing.assert_array_equal(pinned["best_idx"], got["best_idx"])
+    n = 128
+    want = orc.lattice_plan_batch(poses[:n], rl, cfg, grid=(img, 0.058, origin[0], origin[1], 206), nthreads=8)
+    np.testing.assert_array_equal(got["best_idx"][:n], want["best_idx"])
+    np.testing.assert_allclose(got["best_traj"][:n], want["best_traj"], rtol=0, atol=1e-4)      # BASELINE.md tolerance
+    assert np.abs(got["best_traj"][:n] - want["best_traj"]).max() < 2e-6                          # what f32 actually gives on a 4 m path
+    with pytest.raises(ValueError):
+        ctx.lattice_plan(poses[:4], cfg, traj_dtype=np.float32, want_all=True)
