@@ -283,7 +283,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_audit, ctx->d_audit_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -783,6 +783,32 @@ int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side) {
     if (!ctx) return F1P_EINVAL;
     if (stations_each_side < 0 || stations_each_side > 2) return set_error(ctx, F1P_EINVAL, "stations_each_side must be 0, 1 or 2");
     ctx->lattice_clear_r = stations_each_side;
+    return F1P_OK;
+}
+
+int f1p_lattice_debug_margins(f1p_ctx* ctx, int32_t enable, float margin_rel, float margin_abs) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->dbg_margins = enable != 0; ctx->dbg_margin_rel = margin_rel; ctx->dbg_margin_abs = margin_abs;
+    return F1P_OK;
+}
+
+int f1p_lattice_set_audit(f1p_ctx* ctx, int32_t every_n, int32_t n_egos) {
+    if (!ctx) return F1P_EINVAL;
+    if (every_n < 0 || n_egos < 0 || (every_n > 0 && n_egos < 1)) return set_error(ctx, F1P_EINVAL, "every_n >= 0 and, when auditing, n_egos >= 1");
+    ctx->audit_every = every_n; ctx->audit_egos = n_egos;
+    return F1P_OK;
+}
+
+int f1p_lattice_audit_read(f1p_ctx* ctx, uint64_t out[3], int32_t reset) {
+    F1P_ENTER(ctx);
+    if (!out) return set_error(ctx, F1P_EINVAL, "out is NULL");
+    out[0] = out[1] = out[2] = 0;
+    if (!ctx->d_audit) return F1P_OK;
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[3];
+    F1P_HIP(ctx, hipMemcpy(h, ctx->d_audit, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    if (reset) F1P_HIP(ctx, hipMemset(ctx->d_audit, 0, sizeof(h)));
     return F1P_OK;
 }
 

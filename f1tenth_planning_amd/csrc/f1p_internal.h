@@ -68,6 +68,15 @@ struct f1p_ctx {
     size_t mix_scratch_bytes = 0;
     char* d_rec_scratch = nullptr;     // per-ego records of k_lattice_prologue
     size_t rec_scratch_bytes = 0;
+    // runtime audit of the mixed schedule (f1p_lattice_set_audit): every audit_every-th mixed plan re-plans a random window of
+    // audit_egos egos with the all-fp64 exhaustive kernel and counts the egos whose outputs differ in any bit
+    float dbg_margin_rel = 0.f, dbg_margin_abs = 0.f; bool dbg_margins = false;   // f1p_lattice_debug_margins: a test hook that can BREAK the filter
+    int audit_every = 0, audit_egos = 0;
+    bool auditing = false;
+    unsigned long long audit_plans = 0;          // mixed plans seen (the window's position is drawn from it)
+    unsigned long long* d_audit = nullptr;       // [3] plans audited, egos audited, egos with a mismatch
+    char* d_audit_buf = nullptr;
+    size_t audit_buf_bytes = 0;
     int lattice_chunks = 0;            // pipeline chunks of a mixed plan: 0 = automatic, 1 = off (f1p_lattice_set_pipeline)
     hipStream_t pipe_stream[2] = {};   // the pipeline's two internal streams
     hipEvent_t ev_pipe[4] = {};        // done (x2), start, stagger

@@ -392,6 +392,16 @@ class Context:
         """f32 filter's occupancy test: one station in 2 r + 1 against the clearance map (r > 0) or every station against the bitmap (0)"""
         self._check(self.lib.f1p_lattice_set_clearance(self.h, int(stations_each_side)))
 
+    def lattice_set_audit(self, every_n=0, n_egos=64):
+        """every every_n-th mixed plan is re-planned on a moving window of n_egos egos by the all-fp64 kernel and compared bit for bit"""
+        self._check(self.lib.f1p_lattice_set_audit(self.h, int(every_n), int(n_egos)))
+
+    def lattice_audit_read(self, reset=False):
+        """dict(plans, egos, mismatching_egos) of the runtime audit since the last reset"""
+        out = (C.c_uint64 * 3)()
+        self._check(self.lib.f1p_lattice_audit_read(self.h, out, 1 if reset else 0))
+        return dict(plans=int(out[0]), egos=int(out[1]), mismatching_egos=int(out[2]))
+
     def lattice_set_pipeline(self, chunks=0):
         """chunks of egos a mixed plan is pipelined in over two internal streams (0 = automatic, 1 = off)"""
         self._check(self.lib.f1p_lattice_set_pipeline(self.h, int(chunks)))

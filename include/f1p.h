@@ -315,6 +315,21 @@ int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
  * Range 0..2. */
 int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side);
 
+/* Runtime audit of the mixed-precision schedule.  every_n > 0: every every_n-th f1p_lattice_plan_* call that runs the mixed
+ * schedule (device-sampled goals, full plan) is followed, on the same stream, by the all-fp64 exhaustive kernel (cfg.prune = 0,
+ * f1p_lattice_set_mode 0's kernel) on a window of n_egos consecutive egos whose position moves with every audited plan, and by a
+ * comparison of EVERY output of those egos -- steer, speed, best_idx, best_cost, status, near_idx, best_traj (fp64 rows bit for bit,
+ * f32 rows against the fp64 rows rounded once).  f1p_lattice_audit_read returns {plans audited, egos audited, egos with any
+ * mismatch} since the last reset (synchronises the stream).  The mixed schedule's exactness rests on error margins that are
+ * derived in DESIGN.md and measured in the tests; this is the belt to those braces: a production caller can keep every_n = 64
+ * (a 64-ego window costs ~40 us, i.e. < 1 us per plan amortised) and alarm on a non-zero third counter.  every_n = 0: off. */
+int f1p_lattice_set_audit(f1p_ctx* ctx, int32_t every_n, int32_t n_egos);
+int f1p_lattice_audit_read(f1p_ctx* ctx, uint64_t out[3], int32_t reset);
+/* TEST HOOK, not for production: replaces the f32 filter's cost margins (|cost64 - cost32| <= margin_rel * sum|terms| + margin_abs)
+ * while enable != 0.  Margins below the filter's real error (e.g. negative ones) make the mixed schedule return WRONG winners:
+ * that is what tests/test_gpu_audit.py uses it for -- to show that the audit above fires.  enable = 0 restores the defaults. */
+int f1p_lattice_debug_margins(f1p_ctx* ctx, int32_t enable, float margin_rel, float margin_abs);
+
 /* Pipelining of one mixed-schedule plan: the ego batch is cut into `chunks` contiguous chunks whose kernels (prologue, candidate
  * filter, fp64 refinement, selection) run on two internal streams, the second one stage behind the first, so one chunk's
  * latency-bound kernels overlap the other's VALU-bound filter.  The caller's stream is joined before and after: the call keeps

@@ -1,0 +1,67 @@
+"""Runtime audit of the mixed-precision lattice schedule (f1p_lattice_set_audit, VERDICT r2 "next" #2b): every n-th plan is re-planned
+on a moving window of egos by the all-fp64 exhaustive kernel and every output is compared bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from f1tenth_planning_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    rl = synth.make_raceline(seed=0)
+    img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+    return rl, img, origin
+
+
+def test_audit_counts_and_stays_at_zero(scene):
+    from f1tenth_planning_amd.runtime import Context
+    rl, img, origin = scene
+    E, S = 2048, 50
+    cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=S)
+    with Context(0) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        assert ctx.lattice_audit_read() == dict(plans=0, egos=0, mismatching_egos=0)
+        ctx.lattice_set_audit(every_n=2, n_egos=96)
+        for sigma, seed in ((0.3, 5), (0.8, 6)):                              # centred and wall-hugging egos (blocked ones included)
+            poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sigma)
+            prev = np.random.default_rng(seed).normal(0, 0.3, (E, S))
+            for k in range(6):
+                ctx.lattice_plan(poses, cfg, prev_theta=prev if k % 2 else None, traj_dtype=np.float32 if k >= 3 else np.float64)
+        a = ctx.lattice_audit_read(reset=True)
+        assert a["plans"] == 6 and a["egos"] == 6 * 96 and a["mismatching_egos"] == 0, a
+        assert ctx.lattice_audit_read()["plans"] == 0
+        ctx.lattice_set_audit(0)
+        ctx.lattice_plan(poses, cfg)
+        assert ctx.lattice_audit_read()["plans"] == 0
+        # below the mixed schedule's batch size the plan IS the fp64 kernel: nothing to audit
+        ctx.lattice_set_audit(1, 32)
+        ctx.lattice_plan(poses[:100], cfg)
+        assert ctx.lattice_audit_read()["plans"] == 0
+
+
+def test_audit_fires_when_the_filter_is_broken(scene):
+    """the test hook replaces the filter's margins by NEGATIVE ones: brackets that exclude the true cost prune real winners, and the
+    audit must see it"""
+    from f1tenth_planning_amd.runtime import Context
+    rl, img, origin = scene
+    E = 2048
+    cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50)
+    poses = synth.make_egos(rl, E, seed=9)
+    with Context(0) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        good = ctx.lattice_plan(poses, cfg)
+        ctx.lattice_set_audit(1, E)
+        ctx._check(ctx.lib.f1p_lattice_debug_margins(ctx.h, 1, C.c_float(-3e-2), C.c_float(-1e-3)))
+        bad = ctx.lattice_plan(poses, cfg)
+        a = ctx.lattice_audit_read(reset=True)
+        wrong = int((bad["best_idx"] != good["best_idx"]).sum())
+        assert wrong > 0, "the hook did not break the filter: the test proves nothing"
+        assert a["plans"] == 1 and a["egos"] == E and a["mismatching_egos"] >= wrong, (a, wrong)
+        ctx._check(ctx.lib.f1p_lattice_debug_margins(ctx.h, 0, C.c_float(0), C.c_float(0)))
+        again = ctx.lattice_plan(poses, cfg)
+        np.testing.assert_array_equal(again["best_idx"], good["best_idx"])
+        assert ctx.lattice_audit_read()["mismatching_egos"] == 0
