@@ -93,7 +93,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "s"(m0), "v"(c0) : "vcc");
         asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "s"(m1), "v"(c2) : "vcc");
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;          // (gfx950 has no v_xor3_b32: two xors per word)
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
@@ -107,9 +107,12 @@ struct SrcGen {
         const float za = ((float)(int)__builtin_amdgcn_sad_u8(xa, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;   // sum of the word's 4 bytes
         const float zd = ((float)(int)__builtin_amdgcn_sad_u8(xd, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;
         const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
-        const float ga = __builtin_fmaf(sig_a, za, wa), gd = __builtin_fmaf(sig_d, zd, wd);
-        a = r == 0 ? wa : (r == 1 ? 0.0f : ga);                       // selects, not branches: r differs per lane
-        d = r == 0 ? wd : (r == 1 ? 0.0f : gd);
+        // rollout 0 = the warm start itself, rollout 1 = all zero, as per-lane FACTORS instead of two compares + two selects per
+        // control (r is fixed per lane for the whole rollout, so the factors fold into loop-invariant registers): sigma -> 0 for
+        // r < 2, warm -> 0 for r = 1.  fma(0, z, w) = w and fma(0, z, w * 0) = +-0 exactly: the same controls, bit for bit in value.
+        const float fs = r < 2 ? 0.0f : 1.0f, fw = r == 1 ? 0.0f : 1.0f;
+        a = __builtin_fmaf(sig_a * fs, za, wa * fw);
+        d = __builtin_fmaf(sig_d * fs, zd, wd * fw);
     }
     __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
         uint32_t x0, x1, x2, x3;
