@@ -786,6 +786,12 @@ int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side) {
     return F1P_OK;
 }
 
+int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->d_dbg_lat_bound = d_bound;
+    return F1P_OK;
+}
+
 int f1p_lattice_debug_margins(f1p_ctx* ctx, int32_t enable, float margin_rel, float margin_abs) {
     if (!ctx) return F1P_EINVAL;
     ctx->dbg_margins = enable != 0; ctx->dbg_margin_rel = margin_rel; ctx->dbg_margin_abs = margin_abs;

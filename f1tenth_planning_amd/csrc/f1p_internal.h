@@ -83,6 +83,7 @@ struct f1p_ctx {
     bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
     hipEvent_t ev_prof[5] = {};        // before the prologue | before the filter | before the refinement | before the selection | after it
+    float* d_dbg_lat_bound = nullptr;  // [E][C] per-candidate a-priori cost error bounds (test hook: f1p_lattice_debug_bound), or null
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
     int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
 

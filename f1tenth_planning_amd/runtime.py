@@ -392,6 +392,10 @@ class Context:
         """f32 filter's occupancy test: one station in 2 r + 1 against the clearance map (r > 0) or every station against the bitmap (0)"""
         self._check(self.lib.f1p_lattice_set_clearance(self.h, int(stations_each_side)))
 
+    def lattice_debug_bound(self, d_bound=None):
+        """test hook: [E][C] f32 device buffer for the f32 filter's per-candidate a-priori cost error bounds (None = off)"""
+        self._check(self.lib.f1p_lattice_debug_bound(self.h, None if d_bound is None else d_bound.ptr))
+
     def lattice_set_audit(self, every_n=0, n_egos=64):
         """every every_n-th mixed plan is re-planned on a moving window of n_egos egos by the all-fp64 kernel and compared bit for bit"""
         self._check(self.lib.f1p_lattice_set_audit(self.h, int(every_n), int(n_egos)))

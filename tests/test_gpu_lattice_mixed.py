@@ -103,22 +103,29 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sigma)
         d_poses = ctx.to_device(poses)
         out = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
-        d_all, d_c32, d_st = ctx.alloc(8 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+        d_all, d_c32, d_st, d_bd = ctx.alloc(8 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+        prev = None if sigma < 0.5 else ctx.to_device(np.random.default_rng(seed).normal(0, 0.3, (E, S)))   # the similarity term's bound too
         ctx.lattice_set_mode(0)
-        ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_all_cost=d_all)
+        ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_all_cost=d_all, d_prev_theta=prev)
         c64 = d_all.download(np.float64, (E, C))
-        ctx.lattice_set_mode(2, d_c32, d_st)
-        ctx.lattice_plan_dev(d_poses, E, cfg, *out)
-        ctx.lattice_set_mode(1)
+        ctx.lattice_set_mode(2, d_c32, d_st); ctx.lattice_debug_bound(d_bd)
+        ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_prev_theta=prev)
+        ctx.lattice_set_mode(1); ctx.lattice_debug_bound(None)
         c32 = d_c32.download(np.float32, (E, C)).astype(np.float64); st = d_st.download(np.int32, (E, C))
+        bound = d_bd.download(np.float32, (E, C)).astype(np.float64)
         fin = np.isfinite(c64)
         assert not ((st == 0) & ~fin).any(), "a FREE candidate collides in fp64"
         assert not ((st == 1) & fin).any(), "a HIT candidate is collision-free in fp64"
         assert not ((st == 3) & fin).any(), "a BAD candidate is feasible in fp64"
         both = fin & (st < 3) & np.isfinite(c32)
         worst = max(worst, float((np.abs(c32 - c64)[both] / np.abs(c64[both])).max()))
+        # round 3: every candidate's bracket is at least its own A-PRIORI error bound -- and the bound holds, candidate by
+        # candidate (measured: >= 140x above the actual error; it is a worst-case first-order bound)
+        err = np.abs(c32 - c64)[both]
+        assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())
+        assert np.median(bound[both] / np.abs(c64[both])) < 1e-3                   # ... without being vacuous
         assert 0.02 < ((st == 2) | (st >= 4)).mean() < 0.25                        # the uncertain share stays small
-        for b in out + [d_all, d_c32, d_st, d_poses]:
+        for b in out + [d_all, d_c32, d_st, d_bd, d_poses] + ([prev] if prev is not None else []):
             b.free()
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
 

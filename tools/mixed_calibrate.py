@@ -32,13 +32,14 @@ for sigma in (0.3, 0.8):
         all64 = d_all.download(np.float64, (E, C))
         ctx.lattice_plan_dev(d_poses, E, cfg, *b0)                       # winner-only exhaustive (the r01 kernel)
         ref = {n: b.download(t, s) for n, b, t, s in zip(names, b0, types, shapes)}
-        d_c32, d_st = ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
-        ctx.lattice_set_mode(2, d_c32, d_st)
+        d_c32, d_st, d_bd = ctx.alloc(4 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+        ctx.lattice_set_mode(2, d_c32, d_st); ctx.lattice_debug_bound(d_bd)
         b1 = bufs()
         ctx.lattice_plan_dev(d_poses, E, cfg, *b1)
         got = {n: b.download(t, s) for n, b, t, s in zip(names, b1, types, shapes)}
         c32 = d_c32.download(np.float32, (E, C)).astype(np.float64); st = d_st.download(np.int32, (E, C))
-        ctx.lattice_set_mode(2)
+        bd = d_bd.download(np.float32, (E, C)).astype(np.float64)
+        ctx.lattice_set_mode(2); ctx.lattice_debug_bound(None)
         same = {n: bool(np.array_equal(ref[n], got[n], equal_nan=True)) for n in names}
         fin = np.isfinite(all64)
         ok = (st != 3) & (st < 40) & np.isfinite(c32)
@@ -51,6 +52,10 @@ for sigma in (0.3, 0.8):
         need = ((st == 0) | (st == 2) | (st >= 4)) & ~(lo > T[:, None])
         print(f"   refined per ego (recomputed on the host): mean {need.sum(1).mean():.2f}  max {need.sum(1).max()}  total {need.sum()}")
         print(f"   cost32 vs cost64 (finite in both, {both.sum()} candidates): max rel err {rel.max():.3e}  p99.9 {np.percentile(rel, 99.9):.3e}  median {np.median(rel):.3e}")
+        err = np.abs(c32 - all64)[both]; b = bd[both]; cal = 3e-5 * np.abs(all64[both]) + 1e-6
+        print(f"   a-priori bound vs actual error: violations (bound < error) {int((b < err).sum())}; bound / error median {np.median(b / np.maximum(err, 1e-300)):.1f}  min {np.min(b / np.maximum(err, 1e-300)):.2f}; "
+              f"bound / cost: median {np.median(b / np.abs(all64[both])):.2e} p99 {np.percentile(b / np.abs(all64[both]), 99):.2e} max {np.max(b / np.abs(all64[both])):.2e}; "
+              f"brackets widened beyond the calibrated margin: {100 * float((b > cal).mean()):.2f} %")
         print(f"   FREE but fp64 says +inf: {int(((st == 0) & ~fin).sum())}   HIT but fp64 finite: {int(((st == 1) & fin).sum())}   BAD but fp64 finite: {int(((st == 3) & fin).sum())}")
         print(f"   outputs bit-identical to the all-fp64 kernel: {same}   blocked egos {(ref['status'] == 3).sum()}")
         for mode, label in ((0, "all fp64"), (2, "mixed")):
