@@ -587,6 +587,20 @@ def main_lattice(args):
         acc /= max(10, min(args.steps, 50))
         mixed_ms = {"k_lattice_prologue": float(acc[0]), "k_lattice_filter3": float(acc[1]), "k_lattice_refine": float(acc[2]), "k_lattice_select": float(acc[3])}
 
+    # runtime audit of the mixed schedule (f1p_lattice_set_audit): the timed plan again, every plan followed by the all-fp64 exhaustive
+    # kernel on a moving window of 256 egos and a bit-for-bit comparison of every output; outside the timed region
+    audit = None
+    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 512:
+        ctx.lattice_audit_read(reset=True)
+        ctx.lattice_set_audit(1, min(256, E))
+        n_aud = max(20, min(args.steps, 64))
+        for _ in range(n_aud):
+            step()
+        audit = ctx.lattice_audit_read(reset=True)
+        ctx.lattice_set_audit(0)
+        audit["note"] = ("every audited plan: all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs compared bit for bit; "
+                         "mismatching_egos must be 0")
+
     env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
     if secondary and not cand_sharded:
@@ -683,6 +697,7 @@ def main_lattice(args):
             "exchange_selftest": selftest,
             "kmpc_c4": kmpc_c4,
             "two_plans_in_flight": two_in_flight,
+            "audit": audit,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": pmc["source"] if traffic is not None else None,
