@@ -210,6 +210,7 @@ PROTOTYPES = {
     "f1p_kmpc_warm_get": (C.c_int, [_P, _P, _I, _I]),
     "f1p_kmpc_warm_set": (C.c_int, [_P, _P, _I, _I]),
     "f1p_kmpc_set_groups": (C.c_int, [_P, _I]),
+    "f1p_stmpc_set_mode": (C.c_int, [_P, _I, _P, _P]),
     "f1p_kmpc_set_yaw_fixup": (C.c_int, [_P, _I]),
     "f1p_stmpc_cfg_default": (None, [C.POINTER(StmpcCfg)]),
     "f1p_stmpc_predict_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(StmpcCfg), _P]),

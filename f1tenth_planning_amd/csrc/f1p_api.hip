@@ -283,7 +283,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_audit, ctx->d_audit_buf};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1238,6 +1238,13 @@ int f1p_stmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t h
     double* d_ref = s.out(ref, (size_t)E * 7 * (horizon + 1));
     if ((rc = launch_stmpc_ref(ctx, d_s, E, horizon, dt, dl, d_ref))) return rc;
     return s.finish();
+}
+
+int f1p_stmpc_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_n_refined) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->stmpc_mixed = mixed != 0;
+    ctx->d_dbg_st_cost32 = d_cost32; ctx->d_dbg_st_nref = d_n_refined;
+    return F1P_OK;
 }
 
 int f1p_stmpc_shoot_dev(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int32_t E,

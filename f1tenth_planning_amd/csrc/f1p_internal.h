@@ -49,6 +49,14 @@ struct f1p_ctx {
     float* d_dbg_cost32 = nullptr;     // [E][R] filter costs of the next launch (test hook), or null
     int32_t* d_dbg_nref = nullptr;     // [E] size of the refined set (-1 = fp64 fallback), or null
 
+    // dynamic single-track shooting: f32 filter + fp64 refinement (default) or plain fp64 (f1p_stmpc_set_mode); test hooks
+    bool stmpc_mixed = true;
+    float* d_dbg_st_cost32 = nullptr;  // [E][R] filter costs (-inf = untrusted) of the next launches, or null
+    int32_t* d_dbg_st_nref = nullptr;  // [E] refined rollouts (-1 = all-fp64 fallback), or null
+    char* d_st_scratch = nullptr;      // k_stmpc_filter -> refine -> decide: queue counter | per-ego counts | lists | queue | refined costs
+    size_t st_scratch_bytes = 0;
+    bool st_q_dirty = true;
+
     // in-kernel control generation of the shooting MPC (f1p_kmpc_plan_*): the warm start lives here, on the device
     float* d_kmpc_warm = nullptr;      // [E][T][2] f32: previous plan's applied winner shifted by one step
     int kmpc_warm_E = 0, kmpc_warm_T = 0;

@@ -162,6 +162,264 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
     }
 }
 
+// ===================================================================================================================
+// Round 3: f32 filter + fp64 decision for the dynamic single-track shooting (the pattern of k_kmpc_shoot_mixed / the lattice
+// filter; VERDICT r2 "next" #8).  Outputs are bit-identical to k_stmpc_shoot.
+//   pass A (f32, every rollout): the step of dyn_step in ego-relative coordinates (x - x0, y - y0, yaw - yaw0: the map-frame
+//     magnitudes would cost the cost terms their digits), hardware sin / cos of the relative heading + slip angle rotated by the start
+//     heading, tan(delta) by its odd polynomial (|delta| <= 0.45) or sin / cos, the five divisions by v as ONE v_rcp_f32.
+//   TRUST: the yaw-rate equation is yr' = ... - A3 yr / v, integrated by explicit Euler with dt A3 / v ~ 2.8 / v for the reference's
+//     vehicle: below v ~ 1.5 m/s the REFERENCE'S OWN integration is unstable (|1 - dt A3 / v| > 1) and beta / yr grow chaotically --
+//     in fp64 as in f32, but differently, so an f32 cost of such a rollout says nothing about its fp64 cost (and beta enters x, y
+//     through cos / sin, so those costs are moderate, not huge: they can be near the minimum).  A rollout is trusted only while
+//     v >= v_trust at every step, v_trust = 1.05 dt max(A3, 2 A5) / 1.8 from the configuration (both modes contractive with margin);
+//     everything else -- and every non-finite f32 cost -- is refined.
+//   near-minimum set: trusted rollouts within the margin of the trusted f32 minimum + all untrusted ones; more than 64 (or none
+//     trusted) -> the ego falls back to the all-fp64 loop.
+//   pass B (fp64): the listed rollouts by stmpc_rollouts' own arithmetic, one thread each, np.argmin's rule over THOSE costs.
+// Exactness: the fp64 minimiser r* has cost64(r*) <= cost64(r32), so if trusted cost32(r*) <= cost32(r32) + 2 err <= min32 + margin
+// (margin >= 2 err, measured by tools/stmpc_filter_error.py and sized 40x above it); untrusted r* is listed by construction.
+// ===================================================================================================================
+#ifndef F1P_ST_MARGIN_REL
+#define F1P_ST_MARGIN_REL 2.0e-5f     // per time step of the horizon, relative to the minimum (measured error <= 3e-7 T, tools/stmpc_filter_error.py)
+#endif
+#ifndef F1P_ST_MARGIN_ABS
+#define F1P_ST_MARGIN_ABS 2.0e-2f
+#endif
+#define F1P_ST_MAX_REFINE 64
+
+struct DynF32 {
+    float KF, KR, Klf2cf, Klr2cr, M, N, Nlr, Mlf, glr, glf, h, dt, inv_wb, c0, s0;
+    float max_steer, max_steer_v, max_accel, max_speed, min_speed, v_trust;
+    float q[7], qf[7], r[2], rd[2];
+};
+
+// fp64 cost of ONE rollout: the body of stmpc_rollouts for a given r (same operations, same order)
+template <bool FAST>
+__device__ __forceinline__ double stmpc_one_rollout(const float* __restrict__ ce, const double* sref, const f1p_stmpc_cfg& cfg, const DynConst& k,
+                                                    const DynState& s0, int r) {
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    DynState s = s0;
+    double cost = 0.0, pdv = 0.0, pa = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double dv = clampd2((double)ce[((size_t)t * 2 + 0) * R + r], -cfg.max_steer_v, cfg.max_steer_v);
+        double a = clampd2((double)ce[((size_t)t * 2 + 1) * R + r], -cfg.max_accel, cfg.max_accel);
+        if (t > 0) dv = clampd2(dv, pdv - cfg.max_steer_v, pdv + cfg.max_steer_v);
+        const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
+        double q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + t]; q += cfg.q[j] * er * er; }
+        cost += q;
+        cost += cfg.r[0] * dv * dv + cfg.r[1] * a * a;
+        if (t > 0) { const double d0 = dv - pdv, d1 = a - pa; cost += cfg.rd[0] * d0 * d0 + cfg.rd[1] * d1 * d1; }
+        dyn_step<FAST>(s, a, dv, cfg, k);
+        pdv = dv; pa = a;
+    }
+    const double sv[7] = {s.x, s.y, s.delta, s.v, s.yaw, s.yr, s.beta};
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const double er = sv[j] - sref[j * (T + 1) + T]; q += cfg.qf[j] * er * er; }
+    cost += q;
+    return cost;
+}
+
+// f32 cost of one rollout in ego-relative coordinates; trusted = the speed stayed in the stable range of the reference's integrator
+template <bool POLY>
+__device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce, const float* sref32, const DynF32& k, int T, int R, int r,
+                                                   float delta0, float v0, float yr0, float beta0, bool& trusted) {
+#pragma clang fp contract(fast)
+    float x = 0.f, y = 0.f, delta = delta0, v = v0, yaw = 0.f, yr = yr0, beta = beta0;
+    float cost = 0.f, pdv = 0.f, pa = 0.f;
+    trusted = true;
+    const float* cp = ce + r;                                              // [t][2][R]: two loads per step, fetched one step ahead
+    float n_dv = cp[0], n_a = cp[R];
+    for (int t = 0; t < T; ++t) {
+        float dv = __builtin_amdgcn_fmed3f(n_dv, -k.max_steer_v, k.max_steer_v);
+        const float a = __builtin_amdgcn_fmed3f(n_a, -k.max_accel, k.max_accel);
+        cp += 2 * (size_t)R;
+        if (t + 1 < T) { n_dv = cp[0]; n_a = cp[R]; }
+        if (t > 0) dv = __builtin_amdgcn_fmed3f(dv, pdv - k.max_steer_v, pdv + k.max_steer_v);
+        const float e0 = x - sref32[0 * (T + 1) + t], e1 = y - sref32[1 * (T + 1) + t], e2 = delta - sref32[2 * (T + 1) + t];
+        const float e3 = v - sref32[3 * (T + 1) + t], e4 = yaw - sref32[4 * (T + 1) + t], e5 = yr - sref32[5 * (T + 1) + t], e6 = beta - sref32[6 * (T + 1) + t];
+        cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.q[4] * e4 * e4 + k.q[5] * e5 * e5 + k.q[6] * e6 * e6;
+        cost += k.r[0] * dv * dv + k.r[1] * a * a;
+        if (t > 0) { const float d0 = dv - pdv, d1 = a - pa; cost += k.rd[0] * d0 * d0 + k.rd[1] * d1 * d1; }
+        trusted &= v >= k.v_trust;
+        // the step (dynamic_mpc.py:317-404) from the OLD state
+        const float Tz = k.glr - a * k.h, Vz = k.glf + a * k.h;
+        const float A1 = k.KF * Tz, A2 = k.KR * Vz - k.KF * Tz, A3 = k.Klf2cf * Tz + k.Klr2cr * Vz;
+        const float A4 = k.M * Tz, A5 = k.N * Vz + k.M * Tz, A6 = k.Nlr * Vz - k.Mlf * Tz;
+        const float ang = (yaw + beta) * 0.15915494309189535f;              // revolutions
+        const float sn_r = __builtin_amdgcn_sinf(ang), cs_r = __builtin_amdgcn_cosf(ang);
+        const float cs = k.c0 * cs_r - k.s0 * sn_r, sn = k.s0 * cs_r + k.c0 * sn_r;
+        float tn;
+        if (POLY) {
+            const float d2 = delta * delta;
+            tn = delta * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
+        } else {
+            const float dr = delta * 0.15915494309189535f;
+            tn = __builtin_amdgcn_sinf(dr) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(dr));
+        }
+        const float iv = __builtin_amdgcn_rcpf(v);
+        const float vdt = v * k.dt;
+        const float x_new = x + vdt * cs, y_new = y + vdt * sn;
+        const float delta_new = __builtin_amdgcn_fmed3f(delta + dv * k.dt, -k.max_steer, k.max_steer);
+        const float v_new = __builtin_amdgcn_fmed3f(v + a * k.dt, k.min_speed, k.max_speed);
+        const float yaw_new = yaw + vdt * k.inv_wb * tn;
+        const float yri = yr * iv;
+        const float yr_new = yr + (A1 * delta + A2 * beta - A3 * yri) * k.dt;
+        const float beta_new = beta + (A4 * (delta * iv) - A5 * (beta * iv) + A6 * (yri * iv) - yr) * k.dt;
+        x = x_new; y = y_new; delta = delta_new; v = v_new; yaw = yaw_new; yr = yr_new; beta = beta_new;
+        pdv = dv; pa = a;
+    }
+    const float e0 = x - sref32[0 * (T + 1) + T], e1 = y - sref32[1 * (T + 1) + T], e2 = delta - sref32[2 * (T + 1) + T];
+    const float e3 = v - sref32[3 * (T + 1) + T], e4 = yaw - sref32[4 * (T + 1) + T], e5 = yr - sref32[5 * (T + 1) + T], e6 = beta - sref32[6 * (T + 1) + T];
+    cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3 + k.qf[4] * e4 * e4 + k.qf[5] * e5 * e5 + k.qf[6] * e6 * e6;
+    return cost;
+}
+
+// ---- K-A: f32 filter, one workgroup per ego; no fp64 rollout code in this kernel (registers for 8 waves per SIMD) ----------------
+// nlist[e] = listed rollouts (<= 64) or -1 (this ego is decided by the all-fp64 loop in k_stmpc_decide); the listed rollouts go to
+// rl[e][slot] and, as (e * 64 + slot, r), onto the global queue that k_stmpc_refine packs into full waves across egos.
+struct StItem { int es, r; };
+
+__global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__ x0, const double* __restrict__ ref,
+                                                      const float* __restrict__ controls, int E, int T, int R, double max_steer_d, DynF32 kf,
+                                                      unsigned int* __restrict__ qcount, StItem* __restrict__ items, int32_t* __restrict__ nlist,
+                                                      int32_t* __restrict__ rl, float* __restrict__ dbg_cost32) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    float* sref32 = reinterpret_cast<float*>(lds_raw);               // [7][T+1] relative to the ego state
+    float* c32 = sref32 + 7 * (T + 1);                                // [R] filter costs (-inf = untrusted)
+    float* red_f = c32 + R;                                           // [4]
+    int* list = reinterpret_cast<int*>(red_f + 4);                    // [F1P_ST_MAX_REFINE]
+    int* cnt = list + F1P_ST_MAX_REFINE;                              // [2]: listed, queue base
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    const double sx = x0[7 * e], sy = x0[7 * e + 1], sdelta = x0[7 * e + 2], sv = x0[7 * e + 3], syaw = x0[7 * e + 4], syr = x0[7 * e + 5], sbeta = x0[7 * e + 6];
+    const bool in_range = fabs(syaw) <= 1.0e4 && fabs(max_steer_d) <= 1.0e4 && fabs(sbeta) <= 100.0 && fabs(sdelta) <= 100.0;   // workgroup-uniform
+    if (!in_range) { if (tid == 0) nlist[e] = -1; return; }
+    for (int q = tid; q < 7 * (T + 1); q += blockDim.x) {
+        const double rv = ref[(size_t)e * 7 * (T + 1) + q];
+        const int row = q / (T + 1);
+        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 4 ? rv - syaw : rv)));
+    }
+    if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    const float* ce = controls + (size_t)e * T * 2 * R;
+    DynF32 kk = kf;
+    double s0d, c0d;
+    sincos_core(syaw, &s0d, &c0d);
+    kk.c0 = (float)c0d; kk.s0 = (float)s0d;
+    const bool poly = kk.max_steer <= 0.45f;
+    float tmin = __builtin_huge_valf();
+    for (int r = tid; r < R; r += blockDim.x) {
+        bool trusted;
+        float c = poly ? stmpc_rollout_f32<true>(ce, sref32, kk, T, R, r, (float)sdelta, (float)sv, (float)syr, (float)sbeta, trusted)
+                       : stmpc_rollout_f32<false>(ce, sref32, kk, T, R, r, (float)sdelta, (float)sv, (float)syr, (float)sbeta, trusted);
+        if (!trusted || !(c == c) || !(fabsf(c) < 1e30f)) c = -__builtin_huge_valf();      // untrusted / non-finite: fp64 decides
+        else tmin = fminf(tmin, c);
+        c32[r] = c;
+        if (dbg_cost32) dbg_cost32[(size_t)e * R + r] = c;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, m, 64));
+    if (lane == 0) red_f[wave] = tmin;
+    __syncthreads();
+    tmin = red_f[0];
+    for (int w = 1; w < nwaves; ++w) tmin = fminf(tmin, red_f[w]);
+    // (no trusted rollout: tmin = +inf, thr = +inf and every rollout is listed -> fallback)
+    const float thr = tmin + (fabsf(tmin) * fminf(F1P_ST_MARGIN_REL * (float)T, 0.5f) + F1P_ST_MARGIN_ABS);
+    for (int r = tid; r < R; r += blockDim.x) {
+        if (!(c32[r] > thr)) {
+            const int pos = atomicAdd(cnt, 1);
+            if (pos < F1P_ST_MAX_REFINE) list[pos] = r;
+        }
+    }
+    __syncthreads();
+    const int n = cnt[0];
+    const bool fallback = n > F1P_ST_MAX_REFINE || n < 1 || !(tmin < __builtin_huge_valf());
+    if (fallback) { if (tid == 0) nlist[e] = -1; return; }
+    if (tid == 0) { cnt[1] = (int)atomicAdd(qcount, (unsigned int)n); nlist[e] = n; }
+    __syncthreads();
+    if (tid < n) {
+        const int r = list[tid];
+        rl[(size_t)e * F1P_ST_MAX_REFINE + tid] = r;
+        StItem it; it.es = e * F1P_ST_MAX_REFINE + tid; it.r = r;
+        items[(size_t)cnt[1] + tid] = it;
+    }
+}
+
+// ---- K-B: fp64 costs of the queued rollouts, one lane each, packed across egos (stmpc_rollouts' own arithmetic) ----------------
+__global__ __launch_bounds__(64) void k_stmpc_refine(const double* __restrict__ x0, const double* __restrict__ ref, const float* __restrict__ controls,
+                                                     f1p_stmpc_cfg cfg, const unsigned int* __restrict__ qcount, const StItem* __restrict__ items,
+                                                     double* __restrict__ rc) {
+    const unsigned int count = *qcount;
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    const DynConst k = dyn_const(cfg);
+    for (unsigned int i = blockIdx.x * 64u + threadIdx.x; i < count; i += gridDim.x * 64u) {
+        const StItem it = items[i];
+        const int e = it.es / F1P_ST_MAX_REFINE;
+        DynState s0;
+        s0.x = x0[7 * e]; s0.y = x0[7 * e + 1]; s0.delta = x0[7 * e + 2]; s0.v = x0[7 * e + 3]; s0.yaw = x0[7 * e + 4];
+        s0.yr = x0[7 * e + 5]; s0.beta = x0[7 * e + 6];
+        rc[it.es] = stmpc_one_rollout<true>(controls + (size_t)e * T * 2 * R, ref + (size_t)e * 7 * (T + 1), cfg, k, s0, it.r);
+    }
+}
+
+// ---- K-C: np.argmin's rule over the refined costs (or the all-fp64 loop for the egos the filter gave up on), outputs -------------
+__global__ __launch_bounds__(256) void k_stmpc_decide(const double* __restrict__ x0, const double* __restrict__ ref,
+                                                      const float* __restrict__ controls, int E, f1p_stmpc_cfg cfg,
+                                                      unsigned int* __restrict__ qcount, const int32_t* __restrict__ nlist, const int32_t* __restrict__ rl,
+                                                      const double* __restrict__ rc,
+                                                      double* __restrict__ steer, double* __restrict__ speed,
+                                                      int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
+                                                      double* __restrict__ best_seq, int32_t* __restrict__ dbg_nref) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x;
+    double* sref = reinterpret_cast<double*>(lds_raw);                // [7][T+1] (fallback only)
+    double* red_d = sref + 7 * (T + 1);                               // [4]
+    int* red_i = reinterpret_cast<int*>(red_d + 4);                   // [4]
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    if (e == 0 && tid == 0) *qcount = 0u;                             // re-arm the queue for the next plan (k_stmpc_refine has finished)
+    const int n = nlist[e];
+    DynState s0;
+    s0.x = x0[7 * e]; s0.y = x0[7 * e + 1]; s0.delta = x0[7 * e + 2]; s0.v = x0[7 * e + 3]; s0.yaw = x0[7 * e + 4];
+    s0.yr = x0[7 * e + 5]; s0.beta = x0[7 * e + 6];
+    const float* ce = controls + (size_t)e * T * 2 * R;
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff;
+    if (n < 0) {                                                      // workgroup-uniform
+        for (int q = tid; q < 7 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 7 * (T + 1) + q];
+        __syncthreads();
+        const DynConst k = dyn_const(cfg);
+        if (fabs(cfg.max_steer) <= 1.0e4) stmpc_rollouts<true>(ce, sref, cfg, k, s0, tid, bc, bi);
+        else stmpc_rollouts<false>(ce, sref, cfg, k, s0, tid, bc, bi);
+    } else if (tid < n) {
+        bc = rc[(size_t)e * F1P_ST_MAX_REFINE + tid];
+        bi = rl[(size_t)e * F1P_ST_MAX_REFINE + tid];
+    }
+    block_argmin(bc, bi, red_d, red_i);
+    if (tid == 0) {
+        double pdv = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double dv = clampd2((double)ce[((size_t)t * 2 + 0) * R + bi], -cfg.max_steer_v, cfg.max_steer_v);
+            const double a = clampd2((double)ce[((size_t)t * 2 + 1) * R + bi], -cfg.max_accel, cfg.max_accel);
+            if (t > 0) dv = clampd2(dv, pdv - cfg.max_steer_v, pdv + cfg.max_steer_v);
+            if (t == 0) {
+                steer[e] = s0.delta + dv * cfg.dt;   // :1112
+                speed[e] = s0.v + a * cfg.dt;        // :1117
+            }
+            if (best_seq) { best_seq[((size_t)e * T + t) * 2] = dv; best_seq[((size_t)e * T + t) * 2 + 1] = a; }
+            else if (t == 0) break;
+            pdv = dv;
+        }
+        best_idx[e] = bi;
+        if (best_cost) best_cost[e] = bc;
+        if (dbg_nref) dbg_nref[e] = n;
+    }
+}
+
 // calc_ref_trajectory :195-233; states [E][4] = (x, y, v, yaw); ref [E][7][T+1] rows x, y, 0, v, yaw, 0, 0
 __global__ __launch_bounds__(256) void k_stmpc_ref(const double* __restrict__ states, int E, int T, double dt, double dl,
                                                    const double* __restrict__ wx, const double* __restrict__ wy,
@@ -203,10 +461,72 @@ int launch_stmpc_predict(f1p_ctx* ctx, const double* d_x0, const double* d_oa, c
     return check_hip(ctx, hipGetLastError(), "k_stmpc_predict launch");
 }
 
+static DynF32 make_dyn_f32(const f1p_stmpc_cfg* cfg) {
+    const double* p = cfg->params;
+    const double mass = p[0], l_f = p[1], l_r = p[2], h_cog = p[3], c_f = p[4], c_r = p[5], iz = p[6], mu = p[7], g = 9.81;
+    const double K = (mu * mass) / ((l_f + l_r) * iz), F = l_f * c_f, Rr = l_r * c_r, M = (mu * c_f) / (l_f + l_r), N = (mu * c_r) / (l_f + l_r);
+    DynF32 k;
+    k.KF = (float)(K * F); k.KR = (float)(K * Rr); k.Klf2cf = (float)(K * l_f * l_f * c_f); k.Klr2cr = (float)(K * l_r * l_r * c_r);
+    k.M = (float)M; k.N = (float)N; k.Nlr = (float)(N * l_r); k.Mlf = (float)(M * l_f);
+    k.glr = (float)(g * l_r); k.glf = (float)(g * l_f); k.h = (float)h_cog; k.dt = (float)cfg->dt; k.inv_wb = (float)(1.0 / cfg->wheelbase);
+    k.c0 = 1.f; k.s0 = 0.f;
+    k.max_steer = (float)cfg->max_steer; k.max_steer_v = (float)cfg->max_steer_v; k.max_accel = (float)cfg->max_accel;
+    k.max_speed = (float)cfg->max_speed; k.min_speed = (float)cfg->min_speed;
+    // trust speed: both Euler modes contractive with margin (|1 - dt A3 / v| and |1 - dt A5 / v| <= 0.9 ...) for |a| <= max_accel
+    const double am = fabs(cfg->max_accel) * h_cog;
+    const double A3max = K * (l_f * l_f * c_f * (g * l_r + am) + l_r * l_r * c_r * (g * l_f + am));
+    const double A5max = N * (g * l_f + am) + M * (g * l_r + am);
+    k.v_trust = (float)(1.05 * cfg->dt * fmax(A3max, 2.0 * A5max) / 1.8);
+    for (int j = 0; j < 7; ++j) { k.q[j] = (float)cfg->q[j]; k.qf[j] = (float)cfg->qf[j]; }
+    for (int j = 0; j < 2; ++j) { k.r[j] = (float)cfg->r[j]; k.rd[j] = (float)cfg->rd[j]; }
+    return k;
+}
+
 int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E, const f1p_stmpc_cfg* cfg,
                        double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, double* d_best_seq) {
     if (E <= 0) return F1P_OK;
-    const size_t lds = sizeof(double) * (7 * (size_t)(cfg->horizon + 1) + 4) + sizeof(int) * 4;
+    const size_t T1 = (size_t)cfg->horizon + 1;
+    if (ctx->stmpc_mixed) {
+        const DynF32 kf = make_dyn_f32(cfg);
+        const size_t lds_a = sizeof(float) * (7 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_ST_MAX_REFINE + 2);
+        const size_t lds_c = sizeof(double) * (7 * T1 + 4) + sizeof(int) * 4;
+        if (lds_a <= (size_t)ctx->prop.sharedMemPerBlock && lds_c <= (size_t)ctx->prop.sharedMemPerBlock && kf.v_trust == kf.v_trust &&
+            (size_t)E * F1P_ST_MAX_REFINE < ((size_t)1 << 31)) {
+            // scratch: queue counter (256 B) | nlist [E] | rl [E][64] | items [E][64] | rc [E][64]
+            const size_t n_off = 256, rl_off = (n_off + 4 * (size_t)E + 255) & ~(size_t)255;
+            const size_t it_off = (rl_off + 4 * (size_t)E * F1P_ST_MAX_REFINE + 255) & ~(size_t)255;
+            const size_t rc_off = (it_off + sizeof(StItem) * (size_t)E * F1P_ST_MAX_REFINE + 255) & ~(size_t)255;
+            const size_t need = rc_off + 8 * (size_t)E * F1P_ST_MAX_REFINE;
+            if (need > ctx->st_scratch_bytes) {
+                F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->d_st_scratch) (void)hipFree(ctx->d_st_scratch);
+                ctx->d_st_scratch = nullptr; ctx->st_scratch_bytes = 0;
+                F1P_HIP(ctx, hipMalloc((void**)&ctx->d_st_scratch, need));
+                ctx->st_scratch_bytes = need;
+                ctx->st_q_dirty = true;
+            }
+            unsigned int* qcount = reinterpret_cast<unsigned int*>(ctx->d_st_scratch);
+            int32_t* nlist = reinterpret_cast<int32_t*>(ctx->d_st_scratch + n_off);
+            int32_t* rl = reinterpret_cast<int32_t*>(ctx->d_st_scratch + rl_off);
+            StItem* items = reinterpret_cast<StItem*>(ctx->d_st_scratch + it_off);
+            double* rc = reinterpret_cast<double*>(ctx->d_st_scratch + rc_off);
+            if (ctx->st_q_dirty) F1P_HIP(ctx, hipMemsetAsync(qcount, 0, 256, ctx->stream));   // new scratch, or a plan failed between its kernels
+            ctx->st_q_dirty = true;
+            hipLaunchKernelGGL(k_stmpc_filter, dim3(E), dim3(256), (lds_a + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, cfg->horizon,
+                               cfg->n_rollouts, cfg->max_steer, kf, qcount, items, nlist, rl, ctx->d_dbg_st_cost32);
+            int rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_filter launch");
+            if (rcode != F1P_OK) return rcode;
+            hipLaunchKernelGGL(k_stmpc_refine, dim3(E), dim3(64), 0, ctx->stream, d_x0, d_ref, d_controls, *cfg, qcount, items, rc);
+            rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_refine launch");
+            if (rcode != F1P_OK) return rcode;
+            hipLaunchKernelGGL(k_stmpc_decide, dim3(E), dim3(256), (lds_c + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, qcount,
+                               nlist, rl, rc, d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_st_nref);
+            rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_decide launch");
+            if (rcode == F1P_OK) ctx->st_q_dirty = false;
+            return rcode;
+        }
+    }
+    const size_t lds = sizeof(double) * (7 * T1 + 4) + sizeof(int) * 4;
     hipLaunchKernelGGL(k_stmpc_shoot, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg,
                        d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq);
     return check_hip(ctx, hipGetLastError(), "k_stmpc_shoot launch");

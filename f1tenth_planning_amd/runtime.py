@@ -524,6 +524,11 @@ class Context:
         self._check(self.lib.f1p_stmpc_ref_batch(self.h, _ptr(st), E, int(horizon), float(dt), float(dl), _ptr(ref)))
         return ref
 
+    def stmpc_set_mode(self, mixed=True, d_cost32=None, d_n_refined=None):
+        """f32 filter + fp64 decision (default) or plain fp64 for the dynamic single-track shooting; the buffers are test hooks"""
+        self._check(self.lib.f1p_stmpc_set_mode(self.h, 1 if mixed else 0, None if d_cost32 is None else d_cost32.ptr,
+                                                None if d_n_refined is None else d_n_refined.ptr))
+
     def stmpc_shoot_dev(self, d_x0, d_ref, d_controls, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost=None, d_best_seq=None):
         """Asynchronous launch on HBM-resident buffers: x0 [E][7], ref [E][7][T+1], controls f32 [E][T][2][R]."""
         p = lambda b: None if b is None else b.ptr   # noqa: E731

@@ -59,6 +59,62 @@ def test_stmpc_shoot_vs_oracle(ctx, orc):
     assert (np.abs(got["best_seq"][:, :, 0]) <= 3.2).all() and (np.abs(got["best_seq"][:, :, 1]) <= 3.0).all()
 
 
+def _stmpc_case(ctx, seed, E, T, R, vlo, vhi, sigma_a):
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, len(cl) - 1, E)
+    x0 = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.normal(0, 0.05, E), rng.uniform(vlo, vhi, E),
+                          cl[k, 3] + rng.normal(0, 0.1, E), rng.normal(0, 0.2, E), rng.normal(0, 0.02, E)])
+    ref = ctx.stmpc_ref(x0[:, [0, 1, 3, 4]], T)
+    ctrl = np.empty((E, T, 2, R), np.float32)
+    ctrl[:, :, 0, :] = np.clip(rng.normal(0, 1.5, (E, T, R)), -3.2, 3.2)
+    ctrl[:, :, 1, :] = np.clip(rng.normal(0, sigma_a, (E, T, R)), -3.0, 3.0)
+    return x0, ref, ctrl
+
+
+@pytest.mark.parametrize("seed,E,T,R,vlo,vhi,sigma_a", [
+    (40, 96, 40, 512, 2.5, 5.5, 1.5),     # the bench's regime: every rollout trusted, 1-2 refined per ego
+    (41, 96, 40, 512, 2.0, 3.0, 3.0),     # hard braking: rollouts leave the integrator's stable speed range -> listed untrusted, fallbacks
+    (42, 64, 40, 512, 0.3, 1.5, 2.0),     # everything below the trust speed: every ego falls back to the all-fp64 loop
+    (43, 64, 20, 300, 3.0, 6.0, 1.5),     # R not a multiple of the workgroup
+    (44, 32, 60, 1024, 2.5, 5.5, 1.5),    # longer horizon, 4 rollouts per thread
+    (45, 1, 40, 512, 3.0, 3.0, 1.5),      # the single-vehicle call
+])
+def test_f32_filter_is_bit_identical_to_fp64(ctx, seed, E, T, R, vlo, vhi, sigma_a):
+    """k_stmpc_filter -> k_stmpc_refine -> k_stmpc_decide against the all-fp64 k_stmpc_shoot: every output bit for bit; and the f32
+    costs of the trusted rollouts against the fp64 minimum: the true minimiser must be inside the margin with room to spare."""
+    x0, ref, ctrl = _stmpc_case(ctx, seed, E, T, R, vlo, vhi, sigma_a)
+    x0[: min(E, 4), 4] += 2 * np.pi * np.arange(min(E, 4))             # map-frame headings of a few turns: the filter works ego-relative
+    cfg = _abi.stmpc_cfg(horizon=T, n_rollouts=R)
+    d_c32, d_n = ctx.alloc(4 * E * R), ctx.alloc(4 * E)
+    try:
+        ctx.stmpc_set_mode(True, d_c32, d_n)
+        got = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+        c32 = d_c32.download(np.float32, (E, R)); nref = d_n.download(np.int32, (E,))
+        ctx.stmpc_set_mode(False)
+        want = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+    finally:
+        ctx.stmpc_set_mode(True)
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    assert ((nref == -1) | ((nref >= 1) & (nref <= 64))).all()
+    if seed == 40:
+        assert (nref >= 1).all() and nref.mean() < 4 and np.isfinite(c32).all()
+    if seed == 42:
+        assert (nref == -1).all()
+    if seed == 41:
+        assert (nref == -1).any() and (nref >= 1).any() and np.isneginf(c32).any()
+    # the fp64 winner's f32 cost is within 1/10 of the margin of the f32 minimum wherever it was trusted
+    e_ok = np.nonzero(nref >= 1)[0]
+    cb = c32[e_ok, want["best_idx"][e_ok]]
+    tmin = np.where(np.isfinite(c32[e_ok]), c32[e_ok], np.inf).min(axis=1)
+    tr = np.isfinite(cb)
+    margin = np.abs(tmin) * min(2.0e-5 * T, 0.5) + 2.0e-2
+    assert ((cb - tmin)[tr] <= 0.1 * margin[tr]).all()
+    np.testing.assert_allclose(cb[tr], want["best_cost"][e_ok][tr], rtol=1e-5 * T / 40 + 2e-6, atol=1e-3)
+
+
 def test_planner_class_drop_in(golden, tracks):
     from f1tenth_planning.control.dynamic_mpc.dynamic_mpc import STMPCPlanner, State, mpc_config
     lev = tracks["levine"]
