@@ -851,14 +851,26 @@ def main_stmpc(args):
         ctx.stmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, d_bc)
     elapsed, ms_total = timed_region(rk, ctx, step, args.warmup, args.steps)
     kernel_ms = ms_total / args.steps
+    # the all-fp64 kernel (k_stmpc_shoot) on the same inputs: same outputs bit for bit (tests/test_gpu_stmpc.py), here only timed
+    bi_mixed = d_bi.download(np.int32, (E,))
+    ctx.stmpc_set_mode(False)
+    for _ in range(3): step()
+    ctx.sync(); ctx.timer_begin()
+    for _ in range(20): step()
+    fp64_ms = ctx.timer_end() / 20
+    same_idx = bool(np.array_equal(d_bi.download(np.int32, (E,)), bi_mixed))
+    ctx.stmpc_set_mode(True)
+    step(); ctx.sync()
     if rk.rank == 0:
         abytes = E * R * T * 8 + E * (T + 1) * 56 + E * 56 + E * 28
         out = {"metric": "rollout-steps/sec (dynamic single-track random shooting)", "value": float(E) * R * T * args.steps * rk.world / elapsed,
                "unit": "rollout-steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 on f32 controls", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 filter + f64 decision, f32 controls", "data": "synthetic",
                "config": {"workload": f"stmpc shooting: {E} egos x {R} rollouts x {T} steps per GPU (SURVEY.md 8f rank 2)"},
                "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_stmpc_shoot", "kernel_ms": kernel_ms}}
+                            "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "k_stmpc_filter + k_stmpc_refine + k_stmpc_decide (one plan)", "kernel_ms": kernel_ms},
+               "all_fp64": {"kernel": "k_stmpc_shoot", "kernel_ms": fp64_ms, "speedup": fp64_ms / kernel_ms, "same_best_idx": same_idx}}
         if not args.no_cpu_baseline:
             from oracle import oracle
             nthr = oracle.max_threads()

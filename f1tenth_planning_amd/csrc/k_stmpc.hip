@@ -187,12 +187,15 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 #define F1P_ST_MARGIN_ABS 2.0e-2f
 #endif
 #define F1P_ST_MAX_REFINE 64
-
 struct DynF32 {
-    float KF, KR, Klf2cf, Klr2cr, M, N, Nlr, Mlf, glr, glf, h, dt, inv_wb, c0, s0;
+    // dt A_i(a) = ap[i] + aq[i] a (i = 1..6 -> index 0..5): the six coefficients of update_state are affine in the acceleration
+    float ap[6], aq[6], dt, dt_inv_wb, c0, s0;
     float max_steer, max_steer_v, max_accel, max_speed, min_speed, v_trust;
     float q[7], qf[7], r[2], rd[2];
 };
+
+// a wave-uniform f32 in a VGPR: VALU instructions with an SGPR operand issue in 4.3 cycles instead of 2.5 (profiles/r03_valu_issue_cycles.txt)
+__device__ __forceinline__ float in_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 
 // fp64 cost of ONE rollout: the body of stmpc_rollouts for a given r (same operations, same order)
 template <bool FAST>
@@ -223,9 +226,10 @@ __device__ __forceinline__ double stmpc_one_rollout(const float* __restrict__ ce
     return cost;
 }
 
-// f32 cost of one rollout in ego-relative coordinates; trusted = the speed stayed in the stable range of the reference's integrator
+// f32 cost of one rollout in ego-relative coordinates; trusted = the speed stayed in the stable range of the reference's integrator.
+// sref8: [T+1][8] floats (x - x0, y - y0, delta, v, yaw - yaw0, yr, beta, -) so one step's reference is two ds_read_b128.
 template <bool POLY>
-__device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce, const float* sref32, const DynF32& k, int T, int R, int r,
+__device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce, const float* sref8, const DynF32& k, int T, int R, int r,
                                                    float delta0, float v0, float yr0, float beta0, bool& trusted) {
 #pragma clang fp contract(fast)
     float x = 0.f, y = 0.f, delta = delta0, v = v0, yaw = 0.f, yr = yr0, beta = beta0;
@@ -233,22 +237,22 @@ __device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce,
     trusted = true;
     const float* cp = ce + r;                                              // [t][2][R]: two loads per step, fetched one step ahead
     float n_dv = cp[0], n_a = cp[R];
+    const float4* sr = reinterpret_cast<const float4*>(sref8);
     for (int t = 0; t < T; ++t) {
         float dv = __builtin_amdgcn_fmed3f(n_dv, -k.max_steer_v, k.max_steer_v);
         const float a = __builtin_amdgcn_fmed3f(n_a, -k.max_accel, k.max_accel);
         cp += 2 * (size_t)R;
         if (t + 1 < T) { n_dv = cp[0]; n_a = cp[R]; }
         if (t > 0) dv = __builtin_amdgcn_fmed3f(dv, pdv - k.max_steer_v, pdv + k.max_steer_v);
-        const float e0 = x - sref32[0 * (T + 1) + t], e1 = y - sref32[1 * (T + 1) + t], e2 = delta - sref32[2 * (T + 1) + t];
-        const float e3 = v - sref32[3 * (T + 1) + t], e4 = yaw - sref32[4 * (T + 1) + t], e5 = yr - sref32[5 * (T + 1) + t], e6 = beta - sref32[6 * (T + 1) + t];
+        const float4 r0 = sr[2 * t], r1 = sr[2 * t + 1];
+        const float e0 = x - r0.x, e1 = y - r0.y, e2 = delta - r0.z, e3 = v - r0.w, e4 = yaw - r1.x, e5 = yr - r1.y, e6 = beta - r1.z;
         cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.q[4] * e4 * e4 + k.q[5] * e5 * e5 + k.q[6] * e6 * e6;
         cost += k.r[0] * dv * dv + k.r[1] * a * a;
         if (t > 0) { const float d0 = dv - pdv, d1 = a - pa; cost += k.rd[0] * d0 * d0 + k.rd[1] * d1 * d1; }
         trusted &= v >= k.v_trust;
-        // the step (dynamic_mpc.py:317-404) from the OLD state
-        const float Tz = k.glr - a * k.h, Vz = k.glf + a * k.h;
-        const float A1 = k.KF * Tz, A2 = k.KR * Vz - k.KF * Tz, A3 = k.Klf2cf * Tz + k.Klr2cr * Vz;
-        const float A4 = k.M * Tz, A5 = k.N * Vz + k.M * Tz, A6 = k.Nlr * Vz - k.Mlf * Tz;
+        // the step (dynamic_mpc.py:317-404) from the OLD state; B_i = dt A_i
+        const float B1 = k.ap[0] + k.aq[0] * a, B2 = k.ap[1] + k.aq[1] * a, B3 = k.ap[2] + k.aq[2] * a;
+        const float B4 = k.ap[3] + k.aq[3] * a, B5 = k.ap[4] + k.aq[4] * a, B6 = k.ap[5] + k.aq[5] * a;
         const float ang = (yaw + beta) * 0.15915494309189535f;              // revolutions
         const float sn_r = __builtin_amdgcn_sinf(ang), cs_r = __builtin_amdgcn_cosf(ang);
         const float cs = k.c0 * cs_r - k.s0 * sn_r, sn = k.s0 * cs_r + k.c0 * sn_r;
@@ -265,15 +269,15 @@ __device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce,
         const float x_new = x + vdt * cs, y_new = y + vdt * sn;
         const float delta_new = __builtin_amdgcn_fmed3f(delta + dv * k.dt, -k.max_steer, k.max_steer);
         const float v_new = __builtin_amdgcn_fmed3f(v + a * k.dt, k.min_speed, k.max_speed);
-        const float yaw_new = yaw + vdt * k.inv_wb * tn;
+        const float yaw_new = yaw + (v * k.dt_inv_wb) * tn;
         const float yri = yr * iv;
-        const float yr_new = yr + (A1 * delta + A2 * beta - A3 * yri) * k.dt;
-        const float beta_new = beta + (A4 * (delta * iv) - A5 * (beta * iv) + A6 * (yri * iv) - yr) * k.dt;
+        const float yr_new = yr + (B1 * delta + B2 * beta - B3 * yri);
+        const float beta_new = (beta - yr * k.dt) + (B4 * delta - B5 * beta + B6 * yri) * iv;
         x = x_new; y = y_new; delta = delta_new; v = v_new; yaw = yaw_new; yr = yr_new; beta = beta_new;
         pdv = dv; pa = a;
     }
-    const float e0 = x - sref32[0 * (T + 1) + T], e1 = y - sref32[1 * (T + 1) + T], e2 = delta - sref32[2 * (T + 1) + T];
-    const float e3 = v - sref32[3 * (T + 1) + T], e4 = yaw - sref32[4 * (T + 1) + T], e5 = yr - sref32[5 * (T + 1) + T], e6 = beta - sref32[6 * (T + 1) + T];
+    const float4 r0 = sr[2 * T], r1 = sr[2 * T + 1];
+    const float e0 = x - r0.x, e1 = y - r0.y, e2 = delta - r0.z, e3 = v - r0.w, e4 = yaw - r1.x, e5 = yr - r1.y, e6 = beta - r1.z;
     cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3 + k.qf[4] * e4 * e4 + k.qf[5] * e5 * e5 + k.qf[6] * e6 * e6;
     return cost;
 }
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
                                                       int32_t* __restrict__ rl, float* __restrict__ dbg_cost32) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    float* sref32 = reinterpret_cast<float*>(lds_raw);               // [7][T+1] relative to the ego state
-    float* c32 = sref32 + 7 * (T + 1);                                // [R] filter costs (-inf = untrusted)
+    float* sref32 = reinterpret_cast<float*>(lds_raw);               // [T+1][8] relative to the ego state
+    float* c32 = sref32 + 8 * (T + 1);                                // [R] filter costs (-inf = untrusted)
     float* red_f = c32 + R;                                           // [4]
     int* list = reinterpret_cast<int*>(red_f + 4);                    // [F1P_ST_MAX_REFINE]
     int* cnt = list + F1P_ST_MAX_REFINE;                              // [2]: listed, queue base
@@ -301,17 +305,26 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     if (!in_range) { if (tid == 0) nlist[e] = -1; return; }
     for (int q = tid; q < 7 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 7 * (T + 1) + q];
-        const int row = q / (T + 1);
-        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 4 ? rv - syaw : rv)));
+        const int row = q / (T + 1), t = q - row * (T + 1);
+        sref32[8 * t + row] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 4 ? rv - syaw : rv)));
     }
     if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
     __syncthreads();
     const float* ce = controls + (size_t)e * T * 2 * R;
-    DynF32 kk = kf;
+    DynF32 kk;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { kk.ap[j] = in_vgpr(kf.ap[j]); kk.aq[j] = in_vgpr(kf.aq[j]); }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { kk.q[j] = in_vgpr(kf.q[j]); kk.qf[j] = kf.qf[j]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { kk.r[j] = in_vgpr(kf.r[j]); kk.rd[j] = in_vgpr(kf.rd[j]); }
+    kk.dt = in_vgpr(kf.dt); kk.dt_inv_wb = in_vgpr(kf.dt_inv_wb);
+    kk.max_steer = in_vgpr(kf.max_steer); kk.max_steer_v = in_vgpr(kf.max_steer_v); kk.max_accel = in_vgpr(kf.max_accel);
+    kk.max_speed = in_vgpr(kf.max_speed); kk.min_speed = in_vgpr(kf.min_speed); kk.v_trust = in_vgpr(kf.v_trust);
     double s0d, c0d;
     sincos_core(syaw, &s0d, &c0d);
     kk.c0 = (float)c0d; kk.s0 = (float)s0d;
-    const bool poly = kk.max_steer <= 0.45f;
+    const bool poly = kf.max_steer <= 0.45f;
     float tmin = __builtin_huge_valf();
     for (int r = tid; r < R; r += blockDim.x) {
         bool trusted;
@@ -351,6 +364,11 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
 }
 
 // ---- K-B: fp64 costs of the queued rollouts, one lane each, packed across egos (stmpc_rollouts' own arithmetic) ----------------
+// ~1 rollout per ego survives the filter, so this kernel is a few dozen waves running 40 sequential fp64 steps: 1.3 us per step (34 us
+// for a single wave of 17 rollouts, 52 us at 1024 egos), latency of the dependent fp64 chain and not throughput.  Measured and NOT kept
+// (profiles/r03_stmpc_filter.md): splitting the step's independent chains over four waves with an LDS exchange per step, staging the
+// controls in LDS and batching the reference loads -- each left the time where it was.  What would cut it is taking tan(delta), the
+// A_i(a) and the quotients' denominators out of the recurrence (delta and v follow from the controls alone, only yr / beta are recurrent).
 __global__ __launch_bounds__(64) void k_stmpc_refine(const double* __restrict__ x0, const double* __restrict__ ref, const float* __restrict__ controls,
                                                      f1p_stmpc_cfg cfg, const unsigned int* __restrict__ qcount, const StItem* __restrict__ items,
                                                      double* __restrict__ rc) {
@@ -466,9 +484,11 @@ static DynF32 make_dyn_f32(const f1p_stmpc_cfg* cfg) {
     const double mass = p[0], l_f = p[1], l_r = p[2], h_cog = p[3], c_f = p[4], c_r = p[5], iz = p[6], mu = p[7], g = 9.81;
     const double K = (mu * mass) / ((l_f + l_r) * iz), F = l_f * c_f, Rr = l_r * c_r, M = (mu * c_f) / (l_f + l_r), N = (mu * c_r) / (l_f + l_r);
     DynF32 k;
-    k.KF = (float)(K * F); k.KR = (float)(K * Rr); k.Klf2cf = (float)(K * l_f * l_f * c_f); k.Klr2cr = (float)(K * l_r * l_r * c_r);
-    k.M = (float)M; k.N = (float)N; k.Nlr = (float)(N * l_r); k.Mlf = (float)(M * l_f);
-    k.glr = (float)(g * l_r); k.glf = (float)(g * l_f); k.h = (float)h_cog; k.dt = (float)cfg->dt; k.inv_wb = (float)(1.0 / cfg->wheelbase);
+    const double dt = cfg->dt, glr = g * l_r, glf = g * l_f, h = h_cog;
+    // A1 = K F T, A2 = K (R V - F T), A3 = K (lf^2 cf T + lr^2 cr V), A4 = M T, A5 = N V + M T, A6 = N V lr - M T lf;  T = glr - a h, V = glf + a h
+    const double cT[6] = {K * F, -K * F, K * l_f * l_f * c_f, M, M, -M * l_f}, cV[6] = {0.0, K * Rr, K * l_r * l_r * c_r, 0.0, N, N * l_r};
+    for (int i = 0; i < 6; ++i) { k.ap[i] = (float)(dt * (cT[i] * glr + cV[i] * glf)); k.aq[i] = (float)(dt * h * (cV[i] - cT[i])); }
+    k.dt = (float)dt; k.dt_inv_wb = (float)(dt / cfg->wheelbase);
     k.c0 = 1.f; k.s0 = 0.f;
     k.max_steer = (float)cfg->max_steer; k.max_steer_v = (float)cfg->max_steer_v; k.max_accel = (float)cfg->max_accel;
     k.max_speed = (float)cfg->max_speed; k.min_speed = (float)cfg->min_speed;
@@ -488,7 +508,7 @@ int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, co
     const size_t T1 = (size_t)cfg->horizon + 1;
     if (ctx->stmpc_mixed) {
         const DynF32 kf = make_dyn_f32(cfg);
-        const size_t lds_a = sizeof(float) * (7 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_ST_MAX_REFINE + 2);
+        const size_t lds_a = sizeof(float) * (8 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_ST_MAX_REFINE + 2);
         const size_t lds_c = sizeof(double) * (7 * T1 + 4) + sizeof(int) * 4;
         if (lds_a <= (size_t)ctx->prop.sharedMemPerBlock && lds_c <= (size_t)ctx->prop.sharedMemPerBlock && kf.v_trust == kf.v_trust &&
             (size_t)E * F1P_ST_MAX_REFINE < ((size_t)1 << 31)) {
