@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 //     everything else -- and every non-finite f32 cost -- is refined.
 //   near-minimum set: trusted rollouts within the margin of the trusted f32 minimum + all untrusted ones; more than 64 (or none
 //     trusted) -> the ego falls back to the all-fp64 loop.
-//   pass B (fp64): the listed rollouts by stmpc_rollouts' own arithmetic, one thread each, np.argmin's rule over THOSE costs.
+//   pass B (fp64): the listed rollouts by stmpc_rollouts' own arithmetic (k_stmpc_refine_tp: one wave each, lanes over the time steps),
+//     np.argmin's rule over THOSE costs (k_stmpc_decide).
 // Exactness: the fp64 minimiser r* has cost64(r*) <= cost64(r32), so if trusted cost32(r*) <= cost32(r32) + 2 err <= min32 + margin
 // (margin >= 2 err, measured by tools/stmpc_filter_error.py and sized 40x above it); untrusted r* is listed by construction.
 // ===================================================================================================================
@@ -187,6 +188,9 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 #define F1P_ST_MARGIN_ABS 2.0e-2f
 #endif
 #define F1P_ST_MAX_REFINE 64
+#ifndef F1P_ST_FILTER_NR
+#define F1P_ST_FILTER_NR 1             // rollouts per thread of k_stmpc_filter side by side (2: 154 VGPRs -> 3 waves per SIMD, or spills at 128: 58.8 us against 55)
+#endif
 struct DynF32 {
     // dt A_i(a) = ap[i] + aq[i] a (i = 1..6 -> index 0..5): the six coefficients of update_state are affine in the acceleration
     float ap[6], aq[6], dt, dt_inv_wb, c0, s0;
@@ -228,58 +232,70 @@ __device__ __forceinline__ double stmpc_one_rollout(const float* __restrict__ ce
 
 // f32 cost of one rollout in ego-relative coordinates; trusted = the speed stayed in the stable range of the reference's integrator.
 // sref8: [T+1][8] floats (x - x0, y - y0, delta, v, yaw - yaw0, yr, beta, -) so one step's reference is two ds_read_b128.
-template <bool POLY>
-__device__ __forceinline__ float stmpc_rollout_f32(const float* __restrict__ ce, const float* sref8, const DynF32& k, int T, int R, int r,
-                                                   float delta0, float v0, float yr0, float beta0, bool& trusted) {
+// NR rollouts of one thread side by side (r, r + stride, ...).  At 4 waves per SIMD one chain per wave leaves a third of the issue slots
+// empty (55 us against 36 us of instructions), but two chains need 154 VGPRs with the configuration held in registers: measured 58.8 us
+// (3 waves per SIMD, or spills under a 128-register cap), so NR = 1 is what runs.
+template <bool POLY, int NR>
+__device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, const float* sref8, const DynF32& k, int T, int R, const int (&rr)[NR],
+                                                  float delta0, float v0, float yr0, float beta0, float (&cost_out)[NR], bool (&trusted)[NR]) {
 #pragma clang fp contract(fast)
-    float x = 0.f, y = 0.f, delta = delta0, v = v0, yaw = 0.f, yr = yr0, beta = beta0;
-    float cost = 0.f, pdv = 0.f, pa = 0.f;
-    trusted = true;
-    const float* cp = ce + r;                                              // [t][2][R]: two loads per step, fetched one step ahead
-    float n_dv = cp[0], n_a = cp[R];
+    float x[NR], y[NR], delta[NR], v[NR], yaw[NR], yr[NR], beta[NR], cost[NR], pdv[NR], pa[NR], n_dv[NR], n_a[NR];
+    const float* cp[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        x[i] = 0.f; y[i] = 0.f; delta[i] = delta0; v[i] = v0; yaw[i] = 0.f; yr[i] = yr0; beta[i] = beta0; cost[i] = 0.f; pdv[i] = 0.f; pa[i] = 0.f;
+        trusted[i] = true;
+        cp[i] = ce + rr[i];                                                // [t][2][R]: two loads per step, fetched one step ahead
+        n_dv[i] = cp[i][0]; n_a[i] = cp[i][R];
+    }
     const float4* sr = reinterpret_cast<const float4*>(sref8);
     for (int t = 0; t < T; ++t) {
-        float dv = __builtin_amdgcn_fmed3f(n_dv, -k.max_steer_v, k.max_steer_v);
-        const float a = __builtin_amdgcn_fmed3f(n_a, -k.max_accel, k.max_accel);
-        cp += 2 * (size_t)R;
-        if (t + 1 < T) { n_dv = cp[0]; n_a = cp[R]; }
-        if (t > 0) dv = __builtin_amdgcn_fmed3f(dv, pdv - k.max_steer_v, pdv + k.max_steer_v);
         const float4 r0 = sr[2 * t], r1 = sr[2 * t + 1];
-        const float e0 = x - r0.x, e1 = y - r0.y, e2 = delta - r0.z, e3 = v - r0.w, e4 = yaw - r1.x, e5 = yr - r1.y, e6 = beta - r1.z;
-        cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.q[4] * e4 * e4 + k.q[5] * e5 * e5 + k.q[6] * e6 * e6;
-        cost += k.r[0] * dv * dv + k.r[1] * a * a;
-        if (t > 0) { const float d0 = dv - pdv, d1 = a - pa; cost += k.rd[0] * d0 * d0 + k.rd[1] * d1 * d1; }
-        trusted &= v >= k.v_trust;
-        // the step (dynamic_mpc.py:317-404) from the OLD state; B_i = dt A_i
-        const float B1 = k.ap[0] + k.aq[0] * a, B2 = k.ap[1] + k.aq[1] * a, B3 = k.ap[2] + k.aq[2] * a;
-        const float B4 = k.ap[3] + k.aq[3] * a, B5 = k.ap[4] + k.aq[4] * a, B6 = k.ap[5] + k.aq[5] * a;
-        const float ang = (yaw + beta) * 0.15915494309189535f;              // revolutions
-        const float sn_r = __builtin_amdgcn_sinf(ang), cs_r = __builtin_amdgcn_cosf(ang);
-        const float cs = k.c0 * cs_r - k.s0 * sn_r, sn = k.s0 * cs_r + k.c0 * sn_r;
-        float tn;
-        if (POLY) {
-            const float d2 = delta * delta;
-            tn = delta * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
-        } else {
-            const float dr = delta * 0.15915494309189535f;
-            tn = __builtin_amdgcn_sinf(dr) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(dr));
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float dv = __builtin_amdgcn_fmed3f(n_dv[i], -k.max_steer_v, k.max_steer_v);
+            const float a = __builtin_amdgcn_fmed3f(n_a[i], -k.max_accel, k.max_accel);
+            cp[i] += 2 * (size_t)R;
+            if (t + 1 < T) { n_dv[i] = cp[i][0]; n_a[i] = cp[i][R]; }
+            if (t > 0) dv = __builtin_amdgcn_fmed3f(dv, pdv[i] - k.max_steer_v, pdv[i] + k.max_steer_v);
+            const float e0 = x[i] - r0.x, e1 = y[i] - r0.y, e2 = delta[i] - r0.z, e3 = v[i] - r0.w, e4 = yaw[i] - r1.x, e5 = yr[i] - r1.y, e6 = beta[i] - r1.z;
+            cost[i] += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.q[4] * e4 * e4 + k.q[5] * e5 * e5 + k.q[6] * e6 * e6;
+            cost[i] += k.r[0] * dv * dv + k.r[1] * a * a;
+            if (t > 0) { const float d0 = dv - pdv[i], d1 = a - pa[i]; cost[i] += k.rd[0] * d0 * d0 + k.rd[1] * d1 * d1; }
+            trusted[i] &= v[i] >= k.v_trust;
+            // the step (dynamic_mpc.py:317-404) from the OLD state; B_i = dt A_i
+            const float B1 = k.ap[0] + k.aq[0] * a, B2 = k.ap[1] + k.aq[1] * a, B3 = k.ap[2] + k.aq[2] * a;
+            const float B4 = k.ap[3] + k.aq[3] * a, B5 = k.ap[4] + k.aq[4] * a, B6 = k.ap[5] + k.aq[5] * a;
+            const float ang = (yaw[i] + beta[i]) * 0.15915494309189535f;    // revolutions
+            const float sn_r = __builtin_amdgcn_sinf(ang), cs_r = __builtin_amdgcn_cosf(ang);
+            const float cs = k.c0 * cs_r - k.s0 * sn_r, sn = k.s0 * cs_r + k.c0 * sn_r;
+            float tn;
+            if (POLY) {
+                const float d2 = delta[i] * delta[i];
+                tn = delta[i] * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
+            } else {
+                const float dr = delta[i] * 0.15915494309189535f;
+                tn = __builtin_amdgcn_sinf(dr) * __builtin_amdgcn_rcpf(__builtin_amdgcn_cosf(dr));
+            }
+            const float iv = __builtin_amdgcn_rcpf(v[i]);
+            const float vdt = v[i] * k.dt;
+            const float x_new = x[i] + vdt * cs, y_new = y[i] + vdt * sn;
+            const float delta_new = __builtin_amdgcn_fmed3f(delta[i] + dv * k.dt, -k.max_steer, k.max_steer);
+            const float v_new = __builtin_amdgcn_fmed3f(v[i] + a * k.dt, k.min_speed, k.max_speed);
+            const float yaw_new = yaw[i] + (v[i] * k.dt_inv_wb) * tn;
+            const float yri = yr[i] * iv;
+            const float yr_new = yr[i] + (B1 * delta[i] + B2 * beta[i] - B3 * yri);
+            const float beta_new = (beta[i] - yr[i] * k.dt) + (B4 * delta[i] - B5 * beta[i] + B6 * yri) * iv;
+            x[i] = x_new; y[i] = y_new; delta[i] = delta_new; v[i] = v_new; yaw[i] = yaw_new; yr[i] = yr_new; beta[i] = beta_new;
+            pdv[i] = dv; pa[i] = a;
         }
-        const float iv = __builtin_amdgcn_rcpf(v);
-        const float vdt = v * k.dt;
-        const float x_new = x + vdt * cs, y_new = y + vdt * sn;
-        const float delta_new = __builtin_amdgcn_fmed3f(delta + dv * k.dt, -k.max_steer, k.max_steer);
-        const float v_new = __builtin_amdgcn_fmed3f(v + a * k.dt, k.min_speed, k.max_speed);
-        const float yaw_new = yaw + (v * k.dt_inv_wb) * tn;
-        const float yri = yr * iv;
-        const float yr_new = yr + (B1 * delta + B2 * beta - B3 * yri);
-        const float beta_new = (beta - yr * k.dt) + (B4 * delta - B5 * beta + B6 * yri) * iv;
-        x = x_new; y = y_new; delta = delta_new; v = v_new; yaw = yaw_new; yr = yr_new; beta = beta_new;
-        pdv = dv; pa = a;
     }
     const float4 r0 = sr[2 * T], r1 = sr[2 * T + 1];
-    const float e0 = x - r0.x, e1 = y - r0.y, e2 = delta - r0.z, e3 = v - r0.w, e4 = yaw - r1.x, e5 = yr - r1.y, e6 = beta - r1.z;
-    cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3 + k.qf[4] * e4 * e4 + k.qf[5] * e5 * e5 + k.qf[6] * e6 * e6;
-    return cost;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const float e0 = x[i] - r0.x, e1 = y[i] - r0.y, e2 = delta[i] - r0.z, e3 = v[i] - r0.w, e4 = yaw[i] - r1.x, e5 = yr[i] - r1.y, e6 = beta[i] - r1.z;
+        cost_out[i] = cost[i] + (k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3 + k.qf[4] * e4 * e4 + k.qf[5] * e5 * e5 + k.qf[6] * e6 * e6);
+    }
 }
 
 // ---- K-A: f32 filter, one workgroup per ego; no fp64 rollout code in this kernel (registers for 8 waves per SIMD) ----------------
@@ -326,14 +342,22 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     kk.c0 = (float)c0d; kk.s0 = (float)s0d;
     const bool poly = kf.max_steer <= 0.45f;
     float tmin = __builtin_huge_valf();
-    for (int r = tid; r < R; r += blockDim.x) {
-        bool trusted;
-        float c = poly ? stmpc_rollout_f32<true>(ce, sref32, kk, T, R, r, (float)sdelta, (float)sv, (float)syr, (float)sbeta, trusted)
-                       : stmpc_rollout_f32<false>(ce, sref32, kk, T, R, r, (float)sdelta, (float)sv, (float)syr, (float)sbeta, trusted);
-        if (!trusted || !(c == c) || !(fabsf(c) < 1e30f)) c = -__builtin_huge_valf();      // untrusted / non-finite: fp64 decides
-        else tmin = fminf(tmin, c);
-        c32[r] = c;
-        if (dbg_cost32) dbg_cost32[(size_t)e * R + r] = c;
+    constexpr int NR = F1P_ST_FILTER_NR;
+    for (int rb = tid; rb < R; rb += NR * blockDim.x) {
+        int rr[NR]; float c[NR]; bool trusted[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) rr[i] = rb + i * (int)blockDim.x < R ? rb + i * (int)blockDim.x : rb;   // past the end: a shadow of the first, not stored
+        if (poly) stmpc_rollout_f32<true, NR>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
+        else stmpc_rollout_f32<false, NR>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (i > 0 && rr[i] == rb) continue;
+            float ci = c[i];
+            if (!trusted[i] || !(ci == ci) || !(fabsf(ci) < 1e30f)) ci = -__builtin_huge_valf();      // untrusted / non-finite: fp64 decides
+            else tmin = fminf(tmin, ci);
+            c32[rr[i]] = ci;
+            if (dbg_cost32) dbg_cost32[(size_t)e * R + rr[i]] = ci;
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, m, 64));
@@ -365,10 +389,10 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
 
 // ---- K-B: fp64 costs of the queued rollouts, one lane each, packed across egos (stmpc_rollouts' own arithmetic) ----------------
 // ~1 rollout per ego survives the filter, so this kernel is a few dozen waves running 40 sequential fp64 steps: 1.3 us per step (34 us
-// for a single wave of 17 rollouts, 52 us at 1024 egos), latency of the dependent fp64 chain and not throughput.  Measured and NOT kept
+// for a single wave of 17 rollouts, 52 us at 1024 egos), latency of the dependent fp64 chain and not throughput.  This kernel now only
+// serves horizons > 63; k_stmpc_refine_tp below is what runs.  Measured and NOT kept
 // (profiles/r03_stmpc_filter.md): splitting the step's independent chains over four waves with an LDS exchange per step, staging the
-// controls in LDS and batching the reference loads -- each left the time where it was.  What would cut it is taking tan(delta), the
-// A_i(a) and the quotients' denominators out of the recurrence (delta and v follow from the controls alone, only yr / beta are recurrent).
+// controls in LDS and batching the reference loads -- each left the time where it was.
 __global__ __launch_bounds__(64) void k_stmpc_refine(const double* __restrict__ x0, const double* __restrict__ ref, const float* __restrict__ controls,
                                                      f1p_stmpc_cfg cfg, const unsigned int* __restrict__ qcount, const StItem* __restrict__ items,
                                                      double* __restrict__ rc) {
@@ -382,6 +406,199 @@ __global__ __launch_bounds__(64) void k_stmpc_refine(const double* __restrict__ 
         s0.x = x0[7 * e]; s0.y = x0[7 * e + 1]; s0.delta = x0[7 * e + 2]; s0.v = x0[7 * e + 3]; s0.yaw = x0[7 * e + 4];
         s0.yr = x0[7 * e + 5]; s0.beta = x0[7 * e + 6];
         rc[it.es] = stmpc_one_rollout<true>(controls + (size_t)e * T * 2 * R, ref + (size_t)e * 7 * (T + 1), cfg, k, s0, it.r);
+    }
+}
+
+// ---- K-B', time-parallel: ONE WAVE per queued rollout, lanes over the time steps (horizon <= 63) ---------------------------------
+// Of the 7 states only (yr, beta) are truly recurrent.  delta and v follow from the controls alone (clamped running sums), yaw from
+// (v, delta), x / y from (v, yaw + beta), and the cost from all of them -- so everything expensive (tan(delta), the six A_i(a), the
+// sincos of yaw + beta, the 7-term cost rows) is computed with lane = step, and what stays sequential are five short loops of additions,
+// clamps and the three quotients by v, fed from LDS one step ahead:
+//   1  dv_t (rate clamp), delta_t, v_t                      2  (lanes) A_i, tan delta_t, yaw increment, the yr / beta coefficients
+//   3  yr_t, beta_t, yaw_t  (3 divisions + 12 operations per step: the recurrence proper)
+//   4  (lanes) sincos(yaw_t + beta_t) -> x / y increments    5  x_t, y_t      6  (lanes) cost rows      7  the cost's running sum
+// Every operation is the one dyn_step / stmpc_rollouts performs on the same operands, and every running sum is formed in their order,
+// so the cost is bit-identical to stmpc_one_rollout's (tests/test_gpu_stmpc.py compares whole plans with k_stmpc_shoot).
+struct StS1 { double u, a; };
+struct StS3 { double P1, A2, A3, A4d, A5, A6, v, vv, w, pad; };
+struct StO3 { double yr, beta, yaw, pad; };
+struct StXY { double x, y; };
+struct StC { double q, r, rd, pad; };
+#define F1P_ST_TP_LDS_PER_WAVE (64 * (sizeof(StS1) + sizeof(StS3) + sizeof(StO3) + 2 * sizeof(StXY) + sizeof(StC)))
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS traffic is done
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void k_stmpc_refine_tp(const double* __restrict__ x0, const double* __restrict__ ref, const float* __restrict__ controls,
+                                                        f1p_stmpc_cfg cfg, const unsigned int* __restrict__ qcount, const StItem* __restrict__ items,
+                                                        double* __restrict__ rc, float* __restrict__ dbg_ticks) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef F1P_ST_PHASES
+    long long ph[12]; int nph = 0;
+#define F1P_STPH() do { ph[nph++] = clock64(); } while (0)
+#else
+#define F1P_STPH() do {} while (0)
+#endif
+    unsigned char* wl = lds_raw + (size_t)wave * F1P_ST_TP_LDS_PER_WAVE;
+    StS1* __restrict__ s1 = reinterpret_cast<StS1*>(wl);
+    StS3* __restrict__ s3 = reinterpret_cast<StS3*>(wl + 64 * sizeof(StS1));
+    StO3* __restrict__ o3 = reinterpret_cast<StO3*>(wl + 64 * (sizeof(StS1) + sizeof(StS3)));
+    StXY* __restrict__ s6 = reinterpret_cast<StXY*>(wl + 64 * (sizeof(StS1) + sizeof(StS3) + sizeof(StO3)));
+    StXY* __restrict__ o6 = reinterpret_cast<StXY*>(wl + 64 * (sizeof(StS1) + sizeof(StS3) + sizeof(StO3) + sizeof(StXY)));
+    StC* __restrict__ cr = reinterpret_cast<StC*>(wl + 64 * (sizeof(StS1) + sizeof(StS3) + sizeof(StO3) + 2 * sizeof(StXY)));
+    const unsigned int count = *qcount;
+    const int T = cfg.horizon, R = cfg.n_rollouts;
+    const DynConst k = dyn_const(cfg);
+    const unsigned int nw = gridDim.x * (blockDim.x >> 6);
+    for (unsigned int i = blockIdx.x * (blockDim.x >> 6) + wave; i < count; i += nw) {   // wave-uniform
+        F1P_STPH();
+        const StItem it = items[i];
+        const int e = it.es / F1P_ST_MAX_REFINE;
+        const int t = lane;
+        const bool act = t < T, act1 = t <= T;
+        const float* cp = controls + (size_t)e * T * 2 * R + it.r;        // [t][2][R]
+        const double* sref = ref + (size_t)e * 7 * (T + 1);
+        const float c_dv = act ? cp[(size_t)t * 2 * R] : 0.0f, c_a = act ? cp[(size_t)t * 2 * R + R] : 0.0f;
+        double rf[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rf[j] = act1 ? sref[j * (T + 1) + t] : 0.0;
+        DynState s0;
+        s0.x = x0[7 * e]; s0.y = x0[7 * e + 1]; s0.delta = x0[7 * e + 2]; s0.v = x0[7 * e + 3]; s0.yaw = x0[7 * e + 4];
+        s0.yr = x0[7 * e + 5]; s0.beta = x0[7 * e + 6];
+        // ---- 1. controls: the bounds in parallel, the rate clamp and the two clamped running sums in sequence ----------------------
+        const double my_a = clampd2((double)c_a, -cfg.max_accel, cfg.max_accel);         // :704-706
+        {
+            StS1 w1; w1.u = clampd2((double)c_dv, -cfg.max_steer_v, cfg.max_steer_v); w1.a = my_a;   // :701-703
+            s1[t] = w1;
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        double my_dv = 0.0, my_delta = 0.0, my_v = 0.0;
+        {
+            double dlt = s0.delta, v = s0.v, pdv = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < T; ++q) {
+                const StS1 cur = s1[q];
+                double dv = cur.u;
+                if (q > 0) dv = clampd2(dv, pdv - cfg.max_steer_v, pdv + cfg.max_steer_v);   // :685
+                if (lane == 0) { StO3 w; w.yr = dv; w.beta = dlt; w.yaw = v; w.pad = 0.0; o3[q] = w; }   // (o3 is free until phase 3: one LDS write instead of six selects)
+                const double delta_new = dlt + dv * cfg.dt;               // :360
+                const double v_new = v + cur.a * cfg.dt;                  // :361
+                v = v_new > cfg.max_speed ? cfg.max_speed : (v_new < cfg.min_speed ? cfg.min_speed : v_new);               // :393-396
+                dlt = delta_new >= cfg.max_steer ? cfg.max_steer : (delta_new <= -cfg.max_steer ? -cfg.max_steer : delta_new);   // :399-402
+                pdv = dv;
+            }
+            if (lane == 0) { StO3 w; w.yr = 0.0; w.beta = dlt; w.yaw = v; w.pad = 0.0; o3[T] = w; }
+        }
+        wave_lds_sync();
+        if (act1) { const StO3 w = o3[t]; my_dv = w.yr; my_delta = w.beta; my_v = w.yaw; }
+        wave_lds_sync();
+        F1P_STPH();
+        // ---- 2. per step: coefficients of the (yr, beta) recurrence and the yaw increment ----------------------------------------
+        if (act) {
+            const double Tz = k.gl_r - (my_a * k.h);                      // :343
+            const double Vz = k.gl_f + (my_a * k.h);                      // :344
+            const double A1 = k.K * k.F * Tz;                             // :350-355
+            const double A2 = k.K * (k.R * Vz - k.F * Tz);
+            const double A3 = k.K * (k.lf2cf * Tz + k.lr2cr * Vz);
+            const double A4 = k.M * Tz;
+            const double A5 = k.N * Vz + k.M * Tz;
+            const double A6 = k.N * Vz * k.l_r - k.M * Tz * k.l_f;
+            double sd, cd;
+            sincos_core(my_delta, &sd, &cd);
+            const double tn = sd / cd;
+            StS3 w3;
+            w3.P1 = A1 * my_delta; w3.A2 = A2; w3.A3 = A3; w3.A4d = A4 * (my_delta / my_v); w3.A5 = A5; w3.A6 = A6;
+            w3.v = my_v; w3.vv = my_v * my_v; w3.w = my_v / cfg.wheelbase * tn * cfg.dt; w3.pad = 0.0;
+            s3[t] = w3;
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        // ---- 3. the recurrence: yr, beta (and yaw's running sum beside them) ------------------------------------------------------
+        {
+            double yr = s0.yr, beta = s0.beta, yaw = s0.yaw;
+#pragma unroll 4
+            for (int q = 0; q < T; ++q) {
+                const StS3 cur = s3[q];
+                if (lane == 0) { StO3 w; w.yr = yr; w.beta = beta; w.yaw = yaw; w.pad = 0.0; o3[q] = w; }
+                const double yr_new = yr + (cur.P1 + cur.A2 * beta - cur.A3 * (yr / cur.v)) * cfg.dt;                       // :367-371
+                const double beta_new = beta + (cur.A4d - cur.A5 * (beta / cur.v) + cur.A6 * (yr / cur.vv) - yr) * cfg.dt;   // :372-381
+                yaw = yaw + cur.w;                                                                                          // :362-365
+                yr = yr_new; beta = beta_new;
+            }
+            if (lane == 0) { StO3 w; w.yr = yr; w.beta = beta; w.yaw = yaw; w.pad = 0.0; o3[T] = w; }
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        double my_yr = 0.0, my_beta = 0.0, my_yaw = 0.0;
+        if (act1) { const StO3 w = o3[t]; my_yr = w.yr; my_beta = w.beta; my_yaw = w.yaw; }
+        // ---- 4. x / y increments --------------------------------------------------------------------------------------------------
+        if (act) {
+            double sn, cs;
+            sincos_fast(my_yaw + my_beta, &sn, &cs);
+            StXY w; w.x = my_v * cs * cfg.dt; w.y = my_v * sn * cfg.dt;   // :358-359
+            s6[t] = w;
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        // ---- 5. x, y ---------------------------------------------------------------------------------------------------------------
+        {
+            double x = s0.x, y = s0.y;
+#pragma unroll 8
+            for (int q = 0; q < T; ++q) {
+                const StXY cur = s6[q];
+                if (lane == 0) { StXY w; w.x = x; w.y = y; o6[q] = w; }
+                x = x + cur.x; y = y + cur.y;
+            }
+            if (lane == 0) { StXY w; w.x = x; w.y = y; o6[T] = w; }
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        // ---- 6. cost rows ----------------------------------------------------------------------------------------------------------
+        {
+            const double p_dv = shfl_d(my_dv, lane > 0 ? lane - 1 : 0), p_a = shfl_d(my_a, lane > 0 ? lane - 1 : 0);
+            StC w; w.q = 0.0; w.r = 0.0; w.rd = 0.0; w.pad = 0.0;
+            if (act1) {
+                const StXY xy = o6[t];
+                const double sv[7] = {xy.x, xy.y, my_delta, my_v, my_yaw, my_yr, my_beta};
+                double q = 0.0;
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) { const double er = sv[j] - rf[j]; q += cfg.q[j] * er * er; }    // :619
+                    w.r = cfg.r[0] * my_dv * my_dv + cfg.r[1] * my_a * my_a;                                     // :616
+                    if (t > 0) { const double d0 = my_dv - p_dv, d1 = my_a - p_a; w.rd = cfg.rd[0] * d0 * d0 + cfg.rd[1] * d1 * d1; }   // :622
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) { const double er = sv[j] - rf[j]; q += cfg.qf[j] * er * er; }
+                }
+                w.q = q;
+                cr[t] = w;
+            }
+        }
+        wave_lds_sync();
+        F1P_STPH();
+        // ---- 7. the running sum, in stmpc_rollouts' order ---------------------------------------------------------------------------
+        {
+            double cost = 0.0;
+#pragma unroll 8
+            for (int q = 0; q < T; ++q) {
+                const StC cur = cr[q];
+                cost += cur.q;
+                cost += cur.r;
+                if (q > 0) cost += cur.rd;
+            }
+            cost += cr[T].q;                                              // the terminal row (Qf)
+            if (lane == 0) rc[it.es] = cost;
+        }
+        wave_lds_sync();
+#ifdef F1P_ST_PHASES
+        F1P_STPH();
+        if (dbg_ticks && lane == 0 && i < 4096u) { for (int q = 0; q + 1 < nph; ++q) dbg_ticks[i * 16u + q] = (float)(ph[q + 1] - ph[q]); dbg_ticks[i * 16u + 15] = (float)nph; }
+        nph = 0;
+#endif
     }
 }
 
@@ -536,7 +753,12 @@ int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, co
                                cfg->n_rollouts, cfg->max_steer, kf, qcount, items, nlist, rl, ctx->d_dbg_st_cost32);
             int rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_filter launch");
             if (rcode != F1P_OK) return rcode;
-            hipLaunchKernelGGL(k_stmpc_refine, dim3(E), dim3(64), 0, ctx->stream, d_x0, d_ref, d_controls, *cfg, qcount, items, rc);
+            if (cfg->horizon <= 63 && 4 * F1P_ST_TP_LDS_PER_WAVE <= (size_t)ctx->prop.sharedMemPerBlock) {
+                const int nb = E * F1P_ST_MAX_REFINE / 4 < 2 * ctx->prop.multiProcessorCount ? (E * F1P_ST_MAX_REFINE + 3) / 4 : 2 * ctx->prop.multiProcessorCount;
+                hipLaunchKernelGGL(k_stmpc_refine_tp, dim3(nb), dim3(256), 4 * F1P_ST_TP_LDS_PER_WAVE, ctx->stream, d_x0, d_ref, d_controls, *cfg, qcount, items, rc, ctx->d_dbg_st_cost32);
+            } else {
+                hipLaunchKernelGGL(k_stmpc_refine, dim3(E), dim3(64), 0, ctx->stream, d_x0, d_ref, d_controls, *cfg, qcount, items, rc);
+            }
             rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_refine launch");
             if (rcode != F1P_OK) return rcode;
             hipLaunchKernelGGL(k_stmpc_decide, dim3(E), dim3(256), (lds_c + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, qcount,

@@ -80,6 +80,8 @@ def _stmpc_case(ctx, seed, E, T, R, vlo, vhi, sigma_a):
     (43, 64, 20, 300, 3.0, 6.0, 1.5),     # R not a multiple of the workgroup
     (44, 32, 60, 1024, 2.5, 5.5, 1.5),    # longer horizon, 4 rollouts per thread
     (45, 1, 40, 512, 3.0, 3.0, 1.5),      # the single-vehicle call
+    (46, 24, 63, 256, 3.0, 5.5, 1.0),     # the longest horizon the time-parallel refinement takes (one lane per step + the terminal row)
+    (47, 24, 70, 256, 3.0, 5.5, 1.0),     # beyond it: k_stmpc_refine, one lane per queued rollout
 ])
 def test_f32_filter_is_bit_identical_to_fp64(ctx, seed, E, T, R, vlo, vhi, sigma_a):
     """k_stmpc_filter -> k_stmpc_refine -> k_stmpc_decide against the all-fp64 k_stmpc_shoot: every output bit for bit; and the f32
