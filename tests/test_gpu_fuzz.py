@@ -156,3 +156,45 @@ def test_random_footprints_under_the_mixed_schedule(ctx, seed):
                 np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"footprint, clearance {r}: mixed precision differs in {k}")
     finally:
         ctx.lattice_set_clearance(1); ctx.lattice_set_mode(1); ctx.set_footprint((), 0.0)
+
+
+@pytest.mark.parametrize("seed", range(max(8, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
+def test_random_stmpc_configurations(ctx, orc, seed):
+    """The dynamic-model shooting: f32 filter + time-parallel fp64 decision against the all-fp64 kernel (every output bit for bit) and,
+    on a few egos, against the oracle -- random horizons (both refinement kernels), rollout counts, speeds around the trust speed,
+    control spreads, step sizes, weights and limits."""
+    rng = np.random.default_rng(7000 + seed)
+    cl = synth.make_centerline(seed=2 + seed % 3)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    E = int(rng.integers(1, 48))
+    T = int(rng.choice([1, 2, 7, 20, 40, 40, 63, 64, 80]))
+    R = int(rng.choice([1, 2, 63, 64, 200, 256, 512, 700]))
+    dt = float(rng.choice([0.025, 0.025, 0.05, 0.01]))
+    vlo = float(rng.choice([0.3, 1.5, 2.0, 2.5, 3.5])); vhi = vlo + float(rng.uniform(0.0, 3.0))
+    kw = dict(horizon=T, n_rollouts=R, dt=dt)
+    if seed % 4 == 1: kw.update(max_speed=float(rng.uniform(4.0, 8.0)), min_speed=float(rng.uniform(0.0, 1.5)))
+    if seed % 5 == 2: kw.update(max_steer=float(rng.uniform(0.3, 0.9)))              # beyond 0.45: the sin / cos form of tan in the filter
+    if seed % 7 == 3: kw.update(q=tuple(rng.uniform(0.0, 20.0, 7)), qf=tuple(rng.uniform(0.0, 20.0, 7)))
+    cfg = _abi.stmpc_cfg(**kw)
+    k = rng.integers(0, len(cl) - 1, E)
+    x0 = np.column_stack([cl[k, 1] + rng.normal(0, 0.2, E), cl[k, 2] + rng.normal(0, 0.2, E), rng.normal(0, 0.1, E), rng.uniform(vlo, vhi, E),
+                          cl[k, 3] + rng.normal(0, 0.2, E), rng.normal(0, 0.4, E), rng.normal(0, 0.05, E)])
+    if seed % 6 == 0: x0[:, 5:] = 0.0                                                  # exact zeros in yaw rate / slip (the usual start state)
+    ref = ctx.stmpc_ref(x0[:, [0, 1, 3, 4]], T, cfg.dt)
+    ctrl = np.empty((E, T, 2, R), np.float32)
+    ctrl[:, :, 0, :] = np.clip(rng.normal(0, float(rng.uniform(0.2, 3.0)), (E, T, R)), -4.0, 4.0)
+    ctrl[:, :, 1, :] = np.clip(rng.normal(0, float(rng.uniform(0.2, 3.5)), (E, T, R)), -4.0, 4.0)
+    if seed % 9 == 4: ctrl[:, :, :, : max(1, R // 3)] = 0.0                          # tied rollouts: np.argmin's first-minimum rule
+    try:
+        ctx.stmpc_set_mode(True)
+        got = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+        ctx.stmpc_set_mode(False)
+        want = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+    finally:
+        ctx.stmpc_set_mode(True)
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=f"seed {seed}: {key} (E {E} T {T} R {R} v {vlo:.1f}-{vhi:.1f})")
+    n = min(E, 3)
+    o = orc.stmpc_shoot_batch(x0[:n], ref[:n], ctrl[:n], cfg, nthreads=4)
+    finite = np.isfinite(o["best_cost"])
+    np.testing.assert_array_equal(got["best_idx"][:n][finite], o["best_idx"][finite])

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:?run via gpurun}"
 OUT=gpurun_out/$TAG.txt
 {
   echo "long fuzz run: F1P_FUZZ_SEEDS=$SEEDS  tree=$HEAD (+ uncommitted changes at run time, if any)  $(date -u +%Y-%m-%dT%H:%M:%SZ)"
-  echo "tests: tests/test_gpu_fuzz.py (lattice: 3 schedules + shards + occupancy rules vs the oracle; kmpc: f32 filter / generated controls vs the oracle; footprint)"
+  echo "tests: tests/test_gpu_fuzz.py (lattice: 3 schedules + shards + occupancy rules vs the oracle; kmpc: f32 filter / generated controls vs the oracle; footprint; stmpc: f32 filter + time-parallel decision vs the all-fp64 kernel and the oracle)"
   F1P_FUZZ_SEEDS=$SEEDS python -m pytest tests/test_gpu_fuzz.py -q -p no:cacheprovider 2>&1 | tail -15
 } > $OUT 2>&1
 tail -5 $OUT
