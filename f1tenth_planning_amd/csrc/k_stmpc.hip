@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 #define F1P_ST_MARGIN_ABS 2.0e-2f
 #endif
 #define F1P_ST_MAX_REFINE 64
+#ifndef F1P_ST_FILTER_SGPR_CONST
+#define F1P_ST_FILTER_SGPR_CONST 0
+#endif
 #ifndef F1P_ST_FILTER_NR
 #define F1P_ST_FILTER_NR 1             // rollouts per thread of k_stmpc_filter side by side (2: 154 VGPRs -> 3 waves per SIMD, or spills at 128: 58.8 us against 55)
 #endif
@@ -328,6 +331,9 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     __syncthreads();
     const float* ce = controls + (size_t)e * T * 2 * R;
     DynF32 kk;
+#if F1P_ST_FILTER_SGPR_CONST
+    kk = kf;
+#else
 #pragma unroll
     for (int j = 0; j < 6; ++j) { kk.ap[j] = in_vgpr(kf.ap[j]); kk.aq[j] = in_vgpr(kf.aq[j]); }
 #pragma unroll
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     kk.dt = in_vgpr(kf.dt); kk.dt_inv_wb = in_vgpr(kf.dt_inv_wb);
     kk.max_steer = in_vgpr(kf.max_steer); kk.max_steer_v = in_vgpr(kf.max_steer_v); kk.max_accel = in_vgpr(kf.max_accel);
     kk.max_speed = in_vgpr(kf.max_speed); kk.min_speed = in_vgpr(kf.min_speed); kk.v_trust = in_vgpr(kf.v_trust);
+#endif
     double s0d, c0d;
     sincos_core(syaw, &s0d, &c0d);
     kk.c0 = (float)c0d; kk.s0 = (float)s0d;
