@@ -188,9 +188,6 @@ __global__ __launch_bounds__(256) void k_stmpc_shoot(const double* __restrict__ 
 #define F1P_ST_MARGIN_ABS 2.0e-2f
 #endif
 #define F1P_ST_MAX_REFINE 64
-#ifndef F1P_ST_FILTER_SGPR_CONST
-#define F1P_ST_FILTER_SGPR_CONST 0
-#endif
 #ifndef F1P_ST_FILTER_NR
 #define F1P_ST_FILTER_NR 1             // rollouts per thread of k_stmpc_filter side by side (2: 154 VGPRs -> 3 waves per SIMD, or spills at 128: 58.8 us against 55)
 #endif
@@ -237,7 +234,8 @@ __device__ __forceinline__ double stmpc_one_rollout(const float* __restrict__ ce
 // sref8: [T+1][8] floats (x - x0, y - y0, delta, v, yaw - yaw0, yr, beta, -) so one step's reference is two ds_read_b128.
 // NR rollouts of one thread side by side (r, r + stride, ...).  At 4 waves per SIMD one chain per wave leaves a third of the issue slots
 // empty (55 us against 36 us of instructions), but two chains need 154 VGPRs with the configuration held in registers: measured 58.8 us
-// (3 waves per SIMD, or spills under a 128-register cap), so NR = 1 is what runs.
+// (3 waves per SIMD, or spills under a 128-register cap); with the configuration left in SGPRs two chains fit in 90 VGPRs but measure
+// 0.105 ms per plan against 0.101 for one chain (and 0.090 with the configuration in VGPRs): NR = 1 is what runs.
 template <bool POLY, int NR>
 __device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, const float* sref8, const DynF32& k, int T, int R, const int (&rr)[NR],
                                                   float delta0, float v0, float yr0, float beta0, float (&cost_out)[NR], bool (&trusted)[NR]) {
@@ -331,9 +329,6 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     __syncthreads();
     const float* ce = controls + (size_t)e * T * 2 * R;
     DynF32 kk;
-#if F1P_ST_FILTER_SGPR_CONST
-    kk = kf;
-#else
 #pragma unroll
     for (int j = 0; j < 6; ++j) { kk.ap[j] = in_vgpr(kf.ap[j]); kk.aq[j] = in_vgpr(kf.aq[j]); }
 #pragma unroll
@@ -343,7 +338,6 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     kk.dt = in_vgpr(kf.dt); kk.dt_inv_wb = in_vgpr(kf.dt_inv_wb);
     kk.max_steer = in_vgpr(kf.max_steer); kk.max_steer_v = in_vgpr(kf.max_steer_v); kk.max_accel = in_vgpr(kf.max_accel);
     kk.max_speed = in_vgpr(kf.max_speed); kk.min_speed = in_vgpr(kf.min_speed); kk.v_trust = in_vgpr(kf.v_trust);
-#endif
     double s0d, c0d;
     sincos_core(syaw, &s0d, &c0d);
     kk.c0 = (float)c0d; kk.s0 = (float)s0d;
