@@ -379,7 +379,7 @@ class Context:
                                                   p(d_near_idx), p(d_best_traj), p(d_all_cost), p(d_all_traj)))
 
     def lattice_set_mode(self, mixed=1, d_cost32=None, d_state=None):
-        """0: all fp64; 1: f32 filter + fp64 decision from 512 egos (default); 2: always.  Optional device buffers [E][C] receive
+        """0: all fp64; 1: f32 filter + fp64 decision from 320 egos (default); 2: always.  Optional device buffers [E][C] receive
         the filter's costs (f32) and states (i32)."""
         self._check(self.lib.f1p_lattice_set_mode(self.h, int(mixed), None if d_cost32 is None else d_cost32.ptr,
                                                   None if d_state is None else d_state.ptr))

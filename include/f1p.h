@@ -207,7 +207,7 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius);
  * configured with f1p_inflate_grid (one exact dilation by the sum of the two radii) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
  * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the grid with the caller's inflation alone.  Needs the grid;
- * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 512 egos with device-sampled goals --
+ * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 320 egos with device-sampled goals --
  * the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0); outputs are bit-identical either way. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
 
@@ -292,7 +292,7 @@ int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* 
                              int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                              int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx, float* d_best_traj32);
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
- *   mixed = 1 (default): batches of >= 512 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
+ *   mixed = 1 (default): batches of >= 320 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
  *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
  *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;
