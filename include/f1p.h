@@ -463,7 +463,7 @@ int f1p_stmpc_predict_batch(f1p_ctx* ctx, const double* x0, const double* oa, co
 int f1p_stmpc_ref_batch(f1p_ctx* ctx, const double* states, int32_t E, int32_t horizon, double dt, double dl, double* ref);
 /* Evaluation mode of f1p_stmpc_shoot_*: mixed = 1 (default) an f32 filter over every rollout + fp64 re-evaluation of the rollouts
  * that can still be the minimum (those within the margin of the f32 minimum, and every rollout whose speed leaves the range in
- * which the reference's explicit-Euler step is stable: v < ~1.6 m/s for the default vehicle), decision on the fp64 costs -- outputs
+ * which the reference's explicit-Euler step is stable with margin: v < 1.88 m/s for the default vehicle), decision on the fp64 costs -- outputs
  * bit-identical to mixed = 0 (plain fp64).  d_cost32 [E][R] f32 (-inf = untrusted) and d_n_refined [E] i32 (-1 = the ego fell back
  * to all fp64): device pointers, nullable test hooks. */
 int f1p_stmpc_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_n_refined);
