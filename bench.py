@@ -871,6 +871,21 @@ def main_stmpc(args):
                             "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "kernel": "k_stmpc_filter + k_stmpc_refine + k_stmpc_decide (one plan)", "kernel_ms": kernel_ms},
                "all_fp64": {"kernel": "k_stmpc_shoot", "kernel_ms": fp64_ms, "speedup": fp64_ms / kernel_ms, "same_best_idx": same_idx}}
+        pmc = load_pmc({"workload": "stmpc", "egos": E, "rollouts": R, "horizon": T})
+        if pmc and pmc.get("SQ_INSTS_VALU") and pmc.get("avg_us"):
+            # the dominant kernel (k_stmpc_filter) against ITS OWN profiled duration: the plan's other two kernels are fp64 latency chains
+            tl = pmc["SQ_INSTS_VALU"] * 64.0 / (pmc["avg_us"] * 1e-6) / 1e12
+            out["roofline"]["valu"] = {"kernel": pmc["kernel"], "kernel_us_profiled": pmc["avg_us"], "achieved": tl, "peak": VALU_PEAK_F32_GUIDE,
+                                       "unit": "T lane-instr/s", "frac": tl / VALU_PEAK_F32_GUIDE,
+                                       "frac_of_measured_f32_issue_peak": tl / VALU_PEAK_F32_MEASURED,
+                                       "valu_instr_per_rollout_step": pmc["SQ_INSTS_VALU"] * 64.0 / (E * R * T), "source": pmc["source"]}
+            tr = 0
+            for kk in pmc.get("all_kernels", []):
+                if any(n in kk.get("kernel", "") for n in ("k_stmpc_filter", "k_stmpc_refine", "k_stmpc_decide")) and kk.get("FETCH_SIZE_KiB") is not None:
+                    tr += (kk["FETCH_SIZE_KiB"] * 2 + kk.get("WRITE_SIZE_KiB", 0.0)) * 1024
+            if tr:
+                out["roofline"]["traffic"] = int(tr)
+                out["roofline"]["traffic_source"] = pmc["source"]
         if not args.no_cpu_baseline:
             from oracle import oracle
             nthr = oracle.max_threads()
