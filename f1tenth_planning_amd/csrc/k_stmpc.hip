@@ -236,7 +236,9 @@ __device__ __forceinline__ double stmpc_one_rollout(const float* __restrict__ ce
 // empty (55 us against 36 us of instructions), but two chains need 154 VGPRs with the configuration held in registers: measured 58.8 us
 // (3 waves per SIMD, or spills under a 128-register cap); with the configuration left in SGPRs two chains fit in 90 VGPRs but measure
 // 0.105 ms per plan against 0.101 for one chain (and 0.090 with the configuration in VGPRs): NR = 1 is what runs.
-template <bool POLY, int NR>
+// QM: bit j set = row j of the state carries weight in q or qf (compile-time: the reference's own weights leave delta, yr and beta
+// unweighted, three of the seven terms of every step)
+template <bool POLY, int NR, int QM>
 __device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, const float* sref8, const DynF32& k, int T, int R, const int (&rr)[NR],
                                                   float delta0, float v0, float yr0, float beta0, float (&cost_out)[NR], bool (&trusted)[NR]) {
 #pragma clang fp contract(fast)
@@ -257,10 +259,15 @@ __device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, 
             float dv = __builtin_amdgcn_fmed3f(n_dv[i], -k.max_steer_v, k.max_steer_v);
             const float a = __builtin_amdgcn_fmed3f(n_a[i], -k.max_accel, k.max_accel);
             cp[i] += 2 * (size_t)R;
-            if (t + 1 < T) { n_dv[i] = cp[i][0]; n_a[i] = cp[i][R]; }
+            if (t + 1 < T) { n_dv[i] = cp[i][0]; n_a[i] = cp[i][R]; }   // (two steps ahead measured slower: 0.094 against 0.089 ms per plan)
             if (t > 0) dv = __builtin_amdgcn_fmed3f(dv, pdv[i] - k.max_steer_v, pdv[i] + k.max_steer_v);
-            const float e0 = x[i] - r0.x, e1 = y[i] - r0.y, e2 = delta[i] - r0.z, e3 = v[i] - r0.w, e4 = yaw[i] - r1.x, e5 = yr[i] - r1.y, e6 = beta[i] - r1.z;
-            cost[i] += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.q[4] * e4 * e4 + k.q[5] * e5 * e5 + k.q[6] * e6 * e6;
+            {
+                const float sv_[7] = {x[i], y[i], delta[i], v[i], yaw[i], yr[i], beta[i]}, rf_[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+                float qs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) if (QM & (1 << j)) { const float er = sv_[j] - rf_[j]; qs += k.q[j] * er * er; }
+                cost[i] += qs;
+            }
             cost[i] += k.r[0] * dv * dv + k.r[1] * a * a;
             if (t > 0) { const float d0 = dv - pdv[i], d1 = a - pa[i]; cost[i] += k.rd[0] * d0 * d0 + k.rd[1] * d1 * d1; }
             trusted[i] &= v[i] >= k.v_trust;
@@ -294,8 +301,11 @@ __device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, 
     const float4 r0 = sr[2 * T], r1 = sr[2 * T + 1];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const float e0 = x[i] - r0.x, e1 = y[i] - r0.y, e2 = delta[i] - r0.z, e3 = v[i] - r0.w, e4 = yaw[i] - r1.x, e5 = yr[i] - r1.y, e6 = beta[i] - r1.z;
-        cost_out[i] = cost[i] + (k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3 + k.qf[4] * e4 * e4 + k.qf[5] * e5 * e5 + k.qf[6] * e6 * e6);
+        const float sv_[7] = {x[i], y[i], delta[i], v[i], yaw[i], yr[i], beta[i]}, rf_[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+        float qs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) if (QM & (1 << j)) { const float er = sv_[j] - rf_[j]; qs += k.qf[j] * er * er; }
+        cost_out[i] = cost[i] + qs;
     }
 }
 
@@ -304,6 +314,7 @@ __device__ __forceinline__ void stmpc_rollout_f32(const float* __restrict__ ce, 
 // rl[e][slot] and, as (e * 64 + slot, r), onto the global queue that k_stmpc_refine packs into full waves across egos.
 struct StItem { int es, r; };
 
+template <int QM>
 __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__ x0, const double* __restrict__ ref,
                                                       const float* __restrict__ controls, int E, int T, int R, double max_steer_d, DynF32 kf,
                                                       unsigned int* __restrict__ qcount, StItem* __restrict__ items, int32_t* __restrict__ nlist,
@@ -320,13 +331,15 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     const double sx = x0[7 * e], sy = x0[7 * e + 1], sdelta = x0[7 * e + 2], sv = x0[7 * e + 3], syaw = x0[7 * e + 4], syr = x0[7 * e + 5], sbeta = x0[7 * e + 6];
     const bool in_range = fabs(syaw) <= 1.0e4 && fabs(max_steer_d) <= 1.0e4 && fabs(sbeta) <= 100.0 && fabs(sdelta) <= 100.0;   // workgroup-uniform
     if (!in_range) { if (tid == 0) nlist[e] = -1; return; }
+    int bad_ref = 0;                                                 // a non-finite reference in an UNWEIGHTED row makes every fp64 cost NaN (0 * NaN): fp64 decides
     for (int q = tid; q < 7 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 7 * (T + 1) + q];
         const int row = q / (T + 1), t = q - row * (T + 1);
         sref32[8 * t + row] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 4 ? rv - syaw : rv)));
+        if (!((QM >> row) & 1) && !(fabs(rv) < __builtin_huge_val())) bad_ref = 1;
     }
     if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
-    __syncthreads();
+    if (__syncthreads_or(bad_ref | ((QM != 0x7f && !(fabs(syr) < __builtin_huge_val())) ? 1 : 0))) { if (tid == 0) nlist[e] = -1; return; }
     const float* ce = controls + (size_t)e * T * 2 * R;
     DynF32 kk;
 #pragma unroll
@@ -348,8 +361,8 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
         int rr[NR]; float c[NR]; bool trusted[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) rr[i] = rb + i * (int)blockDim.x < R ? rb + i * (int)blockDim.x : rb;   // past the end: a shadow of the first, not stored
-        if (poly) stmpc_rollout_f32<true, NR>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
-        else stmpc_rollout_f32<false, NR>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
+        if (poly) stmpc_rollout_f32<true, NR, QM>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
+        else stmpc_rollout_f32<false, NR, QM>(ce, sref32, kk, T, R, rr, (float)sdelta, (float)sv, (float)syr, (float)sbeta, c, trusted);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (i > 0 && rr[i] == rb) continue;
@@ -750,8 +763,14 @@ int launch_stmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, co
             double* rc = reinterpret_cast<double*>(ctx->d_st_scratch + rc_off);
             if (ctx->st_q_dirty) F1P_HIP(ctx, hipMemsetAsync(qcount, 0, 256, ctx->stream));   // new scratch, or a plan failed between its kernels
             ctx->st_q_dirty = true;
-            hipLaunchKernelGGL(k_stmpc_filter, dim3(E), dim3(256), (lds_a + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, cfg->horizon,
-                               cfg->n_rollouts, cfg->max_steer, kf, qcount, items, nlist, rl, ctx->d_dbg_st_cost32);
+            int qm = 0;                                              // rows that carry weight in the stage or the terminal cost
+            for (int j = 0; j < 7; ++j) if (cfg->q[j] != 0.0 || cfg->qf[j] != 0.0) qm |= 1 << j;
+            if (qm == 0x1b)                                         // the reference's weights (x, y, v, yaw): the delta / yr / beta terms are not evaluated
+                hipLaunchKernelGGL(k_stmpc_filter<0x1b>, dim3(E), dim3(256), (lds_a + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, cfg->horizon,
+                                   cfg->n_rollouts, cfg->max_steer, kf, qcount, items, nlist, rl, ctx->d_dbg_st_cost32);
+            else
+                hipLaunchKernelGGL(k_stmpc_filter<0x7f>, dim3(E), dim3(256), (lds_a + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, cfg->horizon,
+                                   cfg->n_rollouts, cfg->max_steer, kf, qcount, items, nlist, rl, ctx->d_dbg_st_cost32);
             int rcode = check_hip(ctx, hipGetLastError(), "k_stmpc_filter launch");
             if (rcode != F1P_OK) return rcode;
             if (cfg->horizon <= 63 && 4 * F1P_ST_TP_LDS_PER_WAVE <= (size_t)ctx->prop.sharedMemPerBlock) {
