@@ -135,3 +135,25 @@ def test_planner_class_drop_in(golden, tracks):
     assert mpc_config().V_KS == 2.0 and mpc_config().T == 40
     with pytest.raises(ValueError):
         STMPCPlanner().plan(fast)
+
+
+def test_nonfinite_reference_in_an_unweighted_row_is_decided_in_fp64(ctx):
+    """The filter specialised on the reference's weights does not evaluate the delta / yr / beta rows; a NaN there makes every fp64 cost NaN
+    (0 * NaN), which only the all-fp64 loop reproduces: such an ego must fall back, and the outputs stay bit-identical."""
+    E, T, R = 12, 40, 256
+    x0, ref, ctrl = _stmpc_case(ctx, 51, E, T, R, 3.0, 5.0, 1.5)
+    ref[3, 2, 7] = np.nan; ref[5, 6, T] = np.inf; ref[8, 5, 0] = -np.inf
+    cfg = _abi.stmpc_cfg(horizon=T, n_rollouts=R)
+    d_n = ctx.alloc(4 * E)
+    try:
+        ctx.stmpc_set_mode(True, None, d_n)
+        got = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+        nref = d_n.download(np.int32, (E,))
+        ctx.stmpc_set_mode(False)
+        want = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+    finally:
+        ctx.stmpc_set_mode(True)
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    assert (nref[[3, 5, 8]] == -1).all() and (np.delete(nref, [3, 5, 8]) >= 1).all()
+    assert np.isnan(want["best_cost"][[3, 5, 8]]).all()
