@@ -388,7 +388,7 @@ class Context:
         """workgroups per ego of the single-kernel lattice schedules (0 = automatic)"""
         self._check(self.lib.f1p_lattice_set_split(self.h, int(groups)))
 
-    def lattice_set_clearance(self, stations_each_side=1):
+    def lattice_set_clearance(self, stations_each_side=2):
         """f32 filter's occupancy test: one station in 2 r + 1 against the clearance map (r > 0) or every station against the bitmap (0)"""
         self._check(self.lib.f1p_lattice_set_clearance(self.h, int(stations_each_side)))
 

@@ -306,7 +306,7 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
  * one to finish merges the partial winners, re-emits and tracks: no second launch); n > 0 forces n slices (tests, A/B runs). */
 int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
 
-/* Occupancy test of the f32 filter (mixed schedule, device-sampled goals).  stations_each_side = r > 0 (default 1): the filter
+/* Occupancy test of the f32 filter (mixed schedule, device-sampled goals).  stations_each_side = r > 0 (default 2; a smaller r is taken when the clearance zone of r would not fit the ego's tile): the filter
  * looks up one station in 2 r + 1 in a CLEARANCE map of the active bitmap (cells whose centre is within
  * r * ds_cap + (sqrt 2 + 1) cells of an occupied or off-map cell, ds_cap = 1.2 * hypot(max look-ahead, max width) / (S - 1);
  * built on the device at the first plan and whenever the bitmap changes): a tested station in a clear cell proves the r

@@ -155,7 +155,7 @@ def test_random_footprints_under_the_mixed_schedule(ctx, seed):
             for k in a:
                 np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"footprint, clearance {r}: mixed precision differs in {k}")
     finally:
-        ctx.lattice_set_clearance(1); ctx.lattice_set_mode(1); ctx.set_footprint((), 0.0)
+        ctx.lattice_set_clearance(); ctx.lattice_set_mode(1); ctx.set_footprint((), 0.0)
 
 
 @pytest.mark.parametrize("seed", range(max(8, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))

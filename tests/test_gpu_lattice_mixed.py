@@ -124,7 +124,7 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         err = np.abs(c32 - c64)[both]
         assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())
         assert np.median(bound[both] / np.abs(c64[both])) < 1e-3                   # ... without being vacuous
-        assert 0.02 < ((st == 2) | (st >= 4)).mean() < 0.25                        # the uncertain share stays small
+        assert 0.02 < ((st == 2) | (st >= 4)).mean() < 0.35                        # the uncertain share stays small (r = 2 clearance, the default since round 3: ~0.27; r = 1: ~0.13)
         for b in out + [d_all, d_c32, d_st, d_bd, d_poses] + ([prev] if prev is not None else []):
             b.free()
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
@@ -167,7 +167,7 @@ def test_clearance_mode_is_exact_and_follows_the_bitmap(ctx, scene):
                     if r > 0 and sigma < 0.5 and ci < 2:
                         assert (st == 0).mean() > 0.3                       # the mode still decides a good share of the candidates by itself
                     c.lattice_set_mode(2)
-                c.lattice_set_clearance(1)
+                c.lattice_set_clearance()
         # the bitmap changes under the cached clearance map: inflation, footprint, a different grid
         cfg = cfgs[0]
         poses = synth.make_egos(rl, 300, seed=3, pos_sigma=0.4)
@@ -211,7 +211,7 @@ def test_few_stations_untrusted_positions_never_decide(ctx, scene):
             st = d_s.download(np.int32, (E, C))
             assert not ((st == 1) & np.isfinite(c64)).any() and not ((st == 0) & ~np.isfinite(c64)).any(), (S, r)
             ctx.lattice_set_mode(2)
-        ctx.lattice_set_clearance(1)
+        ctx.lattice_set_clearance()
         _both(ctx, poses, cfg)
 
 
@@ -247,7 +247,7 @@ def test_oriented_footprint_under_the_mixed_schedule(scene):
                     assert not ((st == 0) & ~np.isfinite(c64)).any() and not ((st == 1) & np.isfinite(c64)).any()
                     assert (st == 0).mean() > 0.2                     # the filter did run and decided a good share by itself
                     c.lattice_set_mode(2)
-                c.lattice_set_clearance(1)
+                c.lattice_set_clearance()
             plain_first = want
         c.set_footprint((), 0.0)
         c.lattice_set_mode(2)
