@@ -145,6 +145,7 @@ class Ranks:
     """rank bookkeeping + the gloo group used for the barrier and the max-over-ranks of the elapsed time"""
 
     def __init__(self):
+        self.rccl_ok, self.rccl_hung, self.rccl_note = True, False, None
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,6 +212,32 @@ class Ranks:
         if self.oversubscribed:
             return
         import threading
+        if not self.dist:
+            # ONE rank: the communicator only serves the secondary legs (a local self-reduce), never the headline.  A bootstrap that hangs
+            # (seen on one box of this pool: ncclCommInitRank with nranks = 1 never returned) must not cost the run its line: the init
+            # runs in a daemon thread, and past the deadline the legs that need it are skipped and say so.
+            t_single = float(os.environ.get("F1P_RCCL_INIT_TIMEOUT_S", 30.0))
+            box = {}
+
+            def single():
+                try:
+                    ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+                    box["ok"] = True
+                except Exception as exc:   # noqa: BLE001 -- reported, not raised: the headline does not depend on it
+                    box["err"] = str(exc)
+            th = threading.Thread(target=single, daemon=True)
+            th.start()
+            th.join(t_single)
+            if th.is_alive():
+                self.rccl_ok = False
+                self.rccl_hung = True
+                self.rccl_note = f"ncclCommInitRank (1 rank) did not return within {t_single:.0f} s: candidate-sharded and exchange legs skipped"
+                sys.stderr.write("bench.py: " + self.rccl_note + "\n")
+            elif "err" in box:
+                self.rccl_ok = False
+                self.rccl_note = "communicator init failed at one rank (" + box["err"] + "): candidate-sharded and exchange legs skipped"
+                sys.stderr.write("bench.py: " + self.rccl_note + "\n")
+            return
 
         def wedged():
             sys.stderr.write(f"bench.py: rank {self.rank}/{self.world}: the RCCL communicator did not come up within {timeout_s:.0f} s "
@@ -480,6 +507,8 @@ def main_lattice(args):
     secondary = not args.no_secondary and not materialised and args.generator == "clothoid"
     if secondary or cand_sharded:
         rk.init_rccl(ctx)
+        if cand_sharded and not rk.rccl_ok:
+            raise SystemExit("bench.py --shard candidates: " + str(rk.rccl_note))
 
     d_poses = ctx.to_device(poses)
     d_steer, d_speed = ctx.alloc(8 * E), ctx.alloc(8 * E)
@@ -603,10 +632,12 @@ def main_lattice(args):
 
     env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
-    if secondary and not cand_sharded:
+    if secondary and not cand_sharded and rk.rccl_ok:
         cs, _, _ = leg_candidate_sharded(rk, ctx, rl, max(10, min(args.steps, 100)))
-    if secondary or cand_sharded:
+    if (secondary or cand_sharded) and rk.rccl_ok:
         selftest = leg_exchange_selftest(rk, ctx)
+    elif not rk.rccl_ok:
+        selftest = {"skipped": rk.rccl_note}
     if secondary and not cand_sharded:
         kmpc_c4 = leg_kmpc_c4(rk, args, max(10, min(args.steps, 100)))
     two_in_flight = None
@@ -743,7 +774,12 @@ def main_lattice(args):
                              "checked_outputs": "the timed exhaustive plan's (downloaded right after the timed region)"}
             if world == 1 and args.generator == "clothoid" and not materialised and os.path.exists(os.path.join(ROOT, "oracle", "numpy_lattice.py")):
                 out["cpu_baseline_numpy"] = numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer)
+        if rk.rccl_note:
+            out["rccl_init"] = rk.rccl_note
         print(json.dumps(out), flush=True)
+    if rk.rccl_hung:                                     # a thread is still inside ncclCommInitRank: no orderly teardown through it
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     rk.close()
     ctx.close()
 
