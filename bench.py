@@ -206,55 +206,47 @@ class Ranks:
     def comm_info(self, ctx):
         return (self.world, self.rank) if self.oversubscribed else ctx.comm_info()
 
-    def init_rccl(self, ctx, timeout_s=120.0):
-        """ncclCommInitRank under a watchdog: a rank whose communicator has not come up within timeout_s prints why and exits
-        non-zero (os._exit from a timer thread -- never a re-exec), so a wedged bootstrap fails the run instead of hanging it."""
+    def init_rccl(self, ctx, fatal=False):
+        """ncclCommInitRank off the critical path.  The communicator only serves the candidate-sharded / exchange legs -- the headline
+        (ego-sharded, no collective) never needs it -- so it is brought up in a daemon thread with a deadline (30 s at one rank, 120 s
+        with several; F1P_RCCL_INIT_TIMEOUT_S overrides) and the ranks agree on the outcome through the gloo group: if ANY rank's
+        communicator did not come up, EVERY rank skips the legs that need it, the line says why (`rccl_init`), and the processes leave
+        through os._exit after printing (a thread may still sit inside the bootstrap).  Seen this round: ncclCommInitRank with ONE
+        rank never returned on one box.  fatal = True (`--shard candidates`: the run IS the collective): the rank prints why and exits 3
+        -- a wedged bootstrap fails the run instead of hanging it.  Never a re-exec."""
         if self.oversubscribed:
             return
         import threading
-        if not self.dist:
-            # ONE rank: the communicator only serves the secondary legs (a local self-reduce), never the headline.  A bootstrap that hangs
-            # (seen on one box of this pool: ncclCommInitRank with nranks = 1 never returned) must not cost the run its line: the init
-            # runs in a daemon thread, and past the deadline the legs that need it are skipped and say so.
-            t_single = float(os.environ.get("F1P_RCCL_INIT_TIMEOUT_S", 30.0))
-            box = {}
+        t_lim = float(os.environ.get("F1P_RCCL_INIT_TIMEOUT_S", 120.0 if self.dist else 30.0))
+        box = {}
 
-            def single():
-                try:
+        def bring_up():
+            try:
+                if self.dist:
+                    from f1tenth_planning_amd.dist import init_rccl
+                    init_rccl(ctx, self.rank, self.world)
+                else:
                     ctx.comm_init(ctx.comm_unique_id(), 1, 0)
-                    box["ok"] = True
-                except Exception as exc:   # noqa: BLE001 -- reported, not raised: the headline does not depend on it
-                    box["err"] = str(exc)
-            th = threading.Thread(target=single, daemon=True)
-            th.start()
-            th.join(t_single)
-            if th.is_alive():
-                self.rccl_ok = False
-                self.rccl_hung = True
-                self.rccl_note = f"ncclCommInitRank (1 rank) did not return within {t_single:.0f} s: candidate-sharded and exchange legs skipped"
-                sys.stderr.write("bench.py: " + self.rccl_note + "\n")
-            elif "err" in box:
-                self.rccl_ok = False
-                self.rccl_note = "communicator init failed at one rank (" + box["err"] + "): candidate-sharded and exchange legs skipped"
-                sys.stderr.write("bench.py: " + self.rccl_note + "\n")
+                box["ok"] = True
+            except Exception as exc:   # noqa: BLE001 -- reported, not raised: the headline does not depend on it
+                box["err"] = str(exc)
+        th = threading.Thread(target=bring_up, daemon=True)
+        th.start()
+        th.join(t_lim)
+        mine = (not th.is_alive()) and box.get("ok", False)
+        everyone = self.all_equal_int(1 if mine else 0) and mine
+        if everyone:
             return
-
-        def wedged():
-            sys.stderr.write(f"bench.py: rank {self.rank}/{self.world}: the RCCL communicator did not come up within {timeout_s:.0f} s "
-                             f"(HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}); giving up\n")
-            sys.stderr.flush()
+        self.rccl_ok = False
+        self.rccl_hung = th.is_alive()
+        why = (f"ncclCommInitRank did not return within {t_lim:.0f} s" if th.is_alive() else
+               ("communicator init failed: " + box["err"]) if "err" in box else "another rank's communicator did not come up")
+        self.rccl_note = (f"rank {self.rank}/{self.world}: {why} (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+                          f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}): candidate-sharded and exchange legs skipped")
+        sys.stderr.write("bench.py: " + self.rccl_note + "\n")
+        sys.stderr.flush()
+        if fatal:
             os._exit(3)
-        dog = threading.Timer(float(os.environ.get("F1P_RCCL_INIT_TIMEOUT_S", timeout_s)), wedged)
-        dog.daemon = True
-        dog.start()
-        try:
-            if self.dist:
-                from f1tenth_planning_amd.dist import init_rccl
-                init_rccl(ctx, self.rank, self.world)
-            else:
-                ctx.comm_init(ctx.comm_unique_id(), 1, 0)
-        finally:
-            dog.cancel()
 
     def env_ok(self):
         """HSA_ENABLE_IPC_MODE_LEGACY=0 on EVERY rank (set by main() when the launcher did not)"""
@@ -506,9 +498,7 @@ def main_lattice(args):
     materialised = args.workload == "lattice-materialised"
     secondary = not args.no_secondary and not materialised and args.generator == "clothoid"
     if secondary or cand_sharded:
-        rk.init_rccl(ctx)
-        if cand_sharded and not rk.rccl_ok:
-            raise SystemExit("bench.py --shard candidates: " + str(rk.rccl_note))
+        rk.init_rccl(ctx, fatal=cand_sharded)
 
     d_poses = ctx.to_device(poses)
     d_steer, d_speed = ctx.alloc(8 * E), ctx.alloc(8 * E)
@@ -778,6 +768,7 @@ def main_lattice(args):
             out["rccl_init"] = rk.rccl_note
         print(json.dumps(out), flush=True)
     if rk.rccl_hung:                                     # a thread is still inside ncclCommInitRank: no orderly teardown through it
+        rk.barrier()
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
     rk.close()
