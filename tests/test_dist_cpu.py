@@ -123,3 +123,56 @@ def test_bench_self_launch_fails_loudly_without_gpus():
         assert p.returncode != 0, p.stdout[-2000:]
         assert "f1p_device_count()" in p.stdout or "GPU(s) are visible" in p.stdout, p.stdout[-2000:]
         assert '"n_gpus"' not in p.stdout
+
+
+RCCL_WORKER = r'''
+import os, sys, json, time
+sys.path.insert(0, os.environ["F1P_ROOT"])
+import bench
+rank = int(os.environ["RANK"]); case = os.environ["F1P_CASE"]
+
+class Stub:                                   # the two calls Ranks.init_rccl makes on a context
+    def comm_unique_id(self):
+        return b"u" * 128
+    def comm_init(self, uid, nranks, r):
+        assert bytes(uid) == b"u" * 128 and nranks == 2 and r == rank
+        if case == "raise" and rank == 1: raise RuntimeError("stub: no communicator")
+        if case == "hang" and rank == 1: time.sleep(30)
+
+rk = bench.Ranks()
+rk.init()
+rk.init_rccl(Stub())
+print("RESULT " + json.dumps(dict(rank=rank, ok=rk.rccl_ok, hung=rk.rccl_hung, note=rk.rccl_note)), flush=True)
+rk.barrier()
+os._exit(0)                                   # (a stub thread may still be asleep)
+'''
+
+
+def _run_rccl_case(case, timeout_s):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), F1P_ROOT=ROOT,
+                   F1P_CASE=case, F1P_RCCL_INIT_TIMEOUT_S=str(timeout_s))
+        procs.append(subprocess.Popen([sys.executable, "-c", RCCL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        import json
+        line = [l for l in out.splitlines() if l.startswith("RESULT ")][-1]
+        d = json.loads(line[7:]); res[d["rank"]] = d
+    return res
+
+
+def test_bench_ranks_agree_on_the_communicator():
+    """bench.py brings RCCL up off the critical path: if ANY rank's communicator is missing, EVERY rank must skip the legs that need it
+    (same control flow on all ranks), whether that rank's init raised or never returned.  Stub context, world size 2, gloo."""
+    ok = _run_rccl_case("ok", 60)
+    assert ok[0]["ok"] and ok[1]["ok"] and ok[0]["note"] is None
+    bad = _run_rccl_case("raise", 60)
+    assert not bad[0]["ok"] and not bad[1]["ok"] and not bad[0]["hung"] and not bad[1]["hung"]
+    assert "another rank" in bad[0]["note"] and "stub: no communicator" in bad[1]["note"]
+    hung = _run_rccl_case("hang", 3)
+    assert not hung[0]["ok"] and not hung[1]["ok"] and hung[1]["hung"] and not hung[0]["hung"]
+    assert "did not return" in hung[1]["note"]
