@@ -185,6 +185,8 @@ PROTOTYPES = {
     "f1p_lattice_plan_dev": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 9),
     "f1p_lattice_plan_batch_f32": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 7),
     "f1p_lattice_plan_dev_f32": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 7),
+    "f1p_lattice_set_closed_loop": (C.c_int, [_P, _I]),
+    "f1p_lattice_closed_loop_state": (C.c_int, [_P, _P, _P, _P]),
     "f1p_lattice_set_mode": (C.c_int, [_P, _I, _P, _P]),
     "f1p_lattice_set_split": (C.c_int, [_P, _I]),
     "f1p_lattice_set_clearance": (C.c_int, [_P, _I]),

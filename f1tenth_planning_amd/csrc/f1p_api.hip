@@ -283,7 +283,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -646,16 +646,64 @@ int f1p_lqr_batch(f1p_ctx* ctx, const double* states, double* err, int32_t E, do
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Closed-loop mode (f1p_lattice_set_closed_loop): every plan leaves its winners' heading column on the device, [E][S] fp64 in one of two
+// ctx-owned buffers used alternately, and the next plan of the same shape that passes prev_theta == NULL takes it as its previous path
+// (get_similarity_cost, lattice_planner.py:287-296: the reference compares with the previous plan's best trajectory).  Nothing crosses PCIe.
+struct ClosedLoop {
+    const double* prev = nullptr;      // the plan's prev_theta (the caller's, or the kept headings, or null = first plan)
+    double* out = nullptr;             // where its winners' headings go (null: closed loop off)
+    bool from_ctx = false;
+};
+
+static int cl_begin(f1p_ctx* ctx, const double* d_prev_caller, int E, int S, bool writes, ClosedLoop* cl) {
+    cl->prev = d_prev_caller; cl->out = nullptr; cl->from_ctx = false;
+    if (!ctx->lattice_closed_loop || E <= 0) return F1P_OK;
+    const size_t need = sizeof(double) * (size_t)E * S;
+    if (need > ctx->cl_bytes) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& b : ctx->d_cl_theta) { if (b) (void)hipFree(b); b = nullptr; }
+        ctx->cl_bytes = 0; ctx->cl_valid = false;
+        for (auto& b : ctx->d_cl_theta) F1P_HIP(ctx, hipMalloc((void**)&b, need));
+        ctx->cl_bytes = need;
+    }
+    if (ctx->cl_valid && (ctx->cl_E != E || ctx->cl_S != S)) ctx->cl_valid = false;   // another batch shape: a first plan again
+    if (!d_prev_caller && ctx->cl_valid) { cl->prev = ctx->d_cl_theta[ctx->cl_cur]; cl->from_ctx = true; }
+    if (writes) cl->out = ctx->d_cl_theta[ctx->cl_valid ? ctx->cl_cur ^ 1 : 0];
+    return F1P_OK;
+}
+
+static void cl_commit(f1p_ctx* ctx, const ClosedLoop& cl, int E, int S) {
+    if (!cl.out) return;
+    ctx->cl_cur = cl.out == ctx->d_cl_theta[0] ? 0 : 1;
+    ctx->cl_valid = true; ctx->cl_E = E; ctx->cl_S = S;
+}
+
 static int lattice_plan_dev_impl(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                                  int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                                  int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
-                                 double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32) {
+                                 double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32, double* d_theta_out = nullptr) {
     int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_best_idx && (cfg && cfg->cand_count > 0 ? true : (d_steer && d_speed))));
     if (rc) return rc;
     // a candidate shard evaluates only (cost + index); the emit half runs after the cross-rank argmin
     const int mode = cfg->cand_count > 0 ? LATTICE_EVAL : LATTICE_FULL;
     return launch_lattice(ctx, mode, d_poses, d_goals, d_prev_theta, E, cfg, nullptr, nullptr, d_steer, d_speed, d_best_idx,
-                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj, d_best_traj32);
+                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj, d_best_traj32, d_theta_out);
+}
+
+// the *_dev entry points in closed-loop mode: prev_theta == NULL means "the headings the previous plan left on the device"
+static int lattice_plan_dev_cl(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
+                               int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
+                               int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
+                               double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32) {
+    ClosedLoop cl;
+    if (cfg && E > 0 && cfg->n_stations >= 2) {
+        const int rc0 = cl_begin(ctx, d_prev_theta, E, cfg->n_stations, cfg->cand_count == 0, &cl);
+        if (rc0) return rc0;
+    } else cl.prev = d_prev_theta;
+    const int rc = lattice_plan_dev_impl(ctx, d_poses, d_goals, cl.prev, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
+                                         d_best_traj, d_all_cost, d_all_traj, d_best_traj32, cl.out);
+    if (rc == F1P_OK) cl_commit(ctx, cl, E, cfg->n_stations);
+    return rc;
 }
 
 int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
@@ -663,16 +711,16 @@ int f1p_lattice_plan_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
                          int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
                          double* d_best_traj, double* d_all_cost, double* d_all_traj) {
     F1P_ENTER(ctx);
-    return lattice_plan_dev_impl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
-                                 d_best_traj, d_all_cost, d_all_traj, nullptr);
+    return lattice_plan_dev_cl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
+                               d_best_traj, d_all_cost, d_all_traj, nullptr);
 }
 
 int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                              int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                              int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx, float* d_best_traj32) {
     F1P_ENTER(ctx);
-    return lattice_plan_dev_impl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
-                                 nullptr, nullptr, nullptr, d_best_traj32);
+    return lattice_plan_dev_cl(ctx, d_poses, d_goals, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx,
+                               nullptr, nullptr, nullptr, d_best_traj32);
 }
 
 int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_goals, int32_t E,
@@ -681,8 +729,28 @@ int f1p_lattice_emit_dev(f1p_ctx* ctx, const double* d_poses, const double* d_go
     F1P_ENTER(ctx);
     int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_cand_idx && d_steer && d_speed));
     if (rc) return rc;
-    return launch_lattice(ctx, LATTICE_EMIT, d_poses, d_goals, nullptr, E, cfg, d_cand_idx, d_cand_cost, d_steer, d_speed,
-                          nullptr, nullptr, d_status, d_near_idx, d_best_traj, nullptr, nullptr);
+    ClosedLoop cl;                                                 // the emitted winners are this plan's previous path for the next one
+    if (E > 0 && (rc = cl_begin(ctx, nullptr, E, cfg->n_stations, true, &cl))) return rc;
+    rc = launch_lattice(ctx, LATTICE_EMIT, d_poses, d_goals, nullptr, E, cfg, d_cand_idx, d_cand_cost, d_steer, d_speed,
+                        nullptr, nullptr, d_status, d_near_idx, d_best_traj, nullptr, nullptr, nullptr, cl.out);
+    if (rc == F1P_OK) cl_commit(ctx, cl, E, cfg->n_stations);
+    return rc;
+}
+
+int f1p_lattice_set_closed_loop(f1p_ctx* ctx, int32_t on) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->lattice_closed_loop = on != 0;
+    ctx->cl_valid = false;                                         // (re)armed: the next plan is a first plan
+    return F1P_OK;
+}
+
+int f1p_lattice_closed_loop_state(f1p_ctx* ctx, const double** d_prev_theta, int32_t* E, int32_t* S) {
+    if (!ctx) return F1P_EINVAL;
+    const bool v = ctx->lattice_closed_loop && ctx->cl_valid;
+    if (d_prev_theta) *d_prev_theta = v ? ctx->d_cl_theta[ctx->cl_cur] : nullptr;
+    if (E) *E = v ? ctx->cl_E : 0;
+    if (S) *S = v ? ctx->cl_S : 0;
+    return F1P_OK;
 }
 
 // TRAJ = double (the reference's fp64 rows) or float (f1p_lattice_plan_batch_f32: the same rows rounded once on the device)
@@ -708,6 +776,9 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
     if ((rc = s.in(poses, 4 * e, &d_poses))) return rc;
     if ((rc = s.in(goals, e * C * 3, &d_goals))) return rc;
     if ((rc = s.in(prev_theta, e * S, &d_prev))) return rc;
+    ClosedLoop cl;                                             // closed-loop mode: prev_theta == NULL = the headings the previous plan left on the device
+    if (E > 0 && (rc = cl_begin(ctx, d_prev, E, (int)S, cfg->cand_count == 0, &cl))) return rc;
+    d_prev = cl.prev;
     double* d_steer = s.out(steer, e); double* d_speed = s.out(speed, e); int32_t* d_bi = s.out(best_idx, e);
     double* d_bc = s.out(best_cost, e); int32_t* d_st = s.out(status, e); int32_t* d_ni = s.out(near_idx, e);
     // Trajectories into PAGE-LOCKED host memory (f1p_host_alloc / hipHostRegister), 2048 <= E < 8192: the selection kernel writes
@@ -727,12 +798,13 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
         return lattice_plan_dev_impl(ctx, d_poses + 4 * e0, d_goals ? d_goals + e0 * C * 3 : nullptr, d_prev ? d_prev + e0 * S : nullptr,
                                      (int32_t)n, cfg, d_steer ? d_steer + e0 : nullptr, d_speed ? d_speed + e0 : nullptr, d_bi + e0, d_bc ? d_bc + e0 : nullptr,
                                      d_st ? d_st + e0 : nullptr, d_ni ? d_ni + e0 : nullptr, bt64, e0 == 0 && n == e ? d_ac : nullptr,
-                                     e0 == 0 && n == e ? d_at : nullptr, bt32);
+                                     e0 == 0 && n == e ? d_at : nullptr, bt32, cl.out ? cl.out + e0 * S : nullptr);
     };
     const int K = (pinned && E >= 8192) ? (E / 4096 < F1P_PLAN_CHUNKS_MAX ? E / 4096 : F1P_PLAN_CHUNKS_MAX) : 1;
     if (K > 1 && (rc = ensure_copy_stream(ctx))) return rc;
     if (K == 1) {
         if ((rc = plan(0, e))) return rc;
+        cl_commit(ctx, cl, E, (int)S);
         return s.finish();
     }
     for (int k = 0; k < K; ++k) {
@@ -742,6 +814,7 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
         F1P_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk[k], 0));
         F1P_HIP(ctx, hipMemcpyAsync(best_traj + e0 * S * 4, d_bt + e0 * S * 4, n * S * 4 * sizeof(TRAJ), hipMemcpyDeviceToHost, ctx->copy_stream));
     }
+    cl_commit(ctx, cl, E, (int)S);
     rc = s.gather(best_traj);                                  // the per-ego scalars of every slice: one copy + scatter, on the planning stream
     F1P_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return rc;

@@ -96,6 +96,15 @@ struct f1p_ctx {
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
     int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
 
+    // closed-loop mode (f1p_lattice_set_closed_loop): the heading column of every plan's winners stays on the device and is the next
+    // plan's prev_theta (get_similarity_cost's previous path, lattice_planner.py:287-296) -- two buffers used alternately
+    bool lattice_closed_loop = false;
+    double* d_cl_theta[2] = {nullptr, nullptr};   // [E][S] fp64 each
+    size_t cl_bytes = 0;               // capacity of each
+    int cl_cur = 0;                    // buffer holding the LAST plan's headings (valid when cl_valid)
+    bool cl_valid = false;
+    int cl_E = 0, cl_S = 0;            // shape of the last plan
+
     // candidate slices of one ego over several workgroups (few egos, many candidates): partial winners + tickets
     char* d_split_scratch = nullptr;
     int split_cap_E = 0;               // capacity (egos) the scratch is laid out for
@@ -142,7 +151,8 @@ enum LatticeMode { LATTICE_FULL = 0, LATTICE_EVAL = 1, LATTICE_EMIT = 2 };
 int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                    int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
                    double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
-                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32 = nullptr);
+                   int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32 = nullptr,
+                   double* d_theta_out = nullptr);   // d_theta_out [E][S]: the winners' heading column (closed-loop mode), or null
 int launch_clothoid_sample(f1p_ctx* ctx, const double* d_params, int n, int S, double* d_rows);
 int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok);
 

@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void k_stmpc_filter(const double* __restrict__
     double s0d, c0d;
     sincos_core(syaw, &s0d, &c0d);
     kk.c0 = (float)c0d; kk.s0 = (float)s0d;
-    const bool poly = kf.max_steer <= 0.45f;
+    // the odd polynomial of tan is good for |delta| <= 0.45: every later delta is clamped to max_steer, but step 0 evaluates tan(delta0)
+    // UNCLAMPED (dyn_step does, like the reference) -- an out-of-range initial steering state takes the sin / cos path (workgroup-uniform)
+    const bool poly = kf.max_steer <= 0.45f && fabs(sdelta) <= 0.45;
     float tmin = __builtin_huge_valf();
     constexpr int NR = F1P_ST_FILTER_NR;
     for (int rb = tid; rb < R; rb += NR * blockDim.x) {

@@ -378,6 +378,22 @@ class Context:
                                                   p(d_steer), p(d_speed), p(d_best_idx), p(d_best_cost), p(d_status),
                                                   p(d_near_idx), p(d_best_traj), p(d_all_cost), p(d_all_traj)))
 
+    def lattice_set_closed_loop(self, on=True):
+        """closed-loop mode: every plan's winning headings stay on the device and are the next plan's prev_theta (similarity cost,
+        lattice_planner.py:287-296) whenever prev_theta is None; (re)arming forgets the previous path"""
+        self._check(self.lib.f1p_lattice_set_closed_loop(self.h, 1 if on else 0))
+
+    def lattice_closed_loop_prev(self):
+        """the headings the NEXT closed-loop plan would use as prev_theta: numpy [E, S] (a copy), or None"""
+        ptr = C.c_void_p(); E = C.c_int32(); S = C.c_int32()
+        self._check(self.lib.f1p_lattice_closed_loop_state(self.h, C.byref(ptr), C.byref(E), C.byref(S)))
+        if not ptr.value:
+            return None
+        out = np.empty((E.value, S.value))
+        self._check(self.lib.f1p_d2h(self.h, C.c_void_p(out.ctypes.data), ptr, C.c_size_t(out.nbytes)))
+        self.sync()
+        return out
+
     def lattice_set_mode(self, mixed=1, d_cost32=None, d_state=None):
         """0: all fp64; 1: f32 filter + fp64 decision from 320 egos (default); 2: always.  Optional device buffers [E][C] receive
         the filter's costs (f32) and states (i32)."""

@@ -291,6 +291,17 @@ int f1p_lattice_plan_batch_f32(f1p_ctx* ctx, const double* poses, const double* 
 int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                              int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                              int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx, float* d_best_traj32);
+/* Closed-loop mode.  The reference's fourth cost, get_similarity_cost (lattice_planner.py:287-296), compares a candidate's heading column
+ * with the PREVIOUS plan's best trajectory, so a caller of the reference carries best_traj[:, 2] from one plan() to the next.  on = 1: the
+ * context keeps the heading column of every plan's winners on the device ([E][S] fp64, two ctx-owned buffers used alternately, written by
+ * the kernel that emits best_traj) and every following f1p_lattice_plan_* / f1p_lattice_step_* call of the same (E, S) that passes
+ * prev_theta == NULL uses it as its prev_theta -- nothing crosses PCIe.  The first plan after (re)arming, or after the batch shape changed,
+ * has no previous path (term = 0), like the reference's first call.  An explicit prev_theta still wins; a candidate shard
+ * (cfg.cand_count > 0) reads the kept headings, f1p_lattice_emit_dev writes them.  on = 0: off (and forgotten).
+ * f1p_lattice_closed_loop_state returns the device pointer / shape of the headings the NEXT plan would use (NULL / 0 when none). */
+int f1p_lattice_set_closed_loop(f1p_ctx* ctx, int32_t on);
+int f1p_lattice_closed_loop_state(f1p_ctx* ctx, const double** d_prev_theta, int32_t* E, int32_t* S);
+
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
  *   mixed = 1 (default): batches of >= 320 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the

@@ -157,3 +157,32 @@ def test_nonfinite_reference_in_an_unweighted_row_is_decided_in_fp64(ctx):
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
     assert (nref[[3, 5, 8]] == -1).all() and (np.delete(nref, [3, 5, 8]) >= 1).all()
     assert np.isnan(want["best_cost"][[3, 5, 8]]).all()
+
+
+def test_initial_steering_beyond_the_polynomial_range(ctx):
+    """step 0 evaluates tan(delta0) UNCLAMPED (dyn_step, like the reference); the filter's odd polynomial of tan is good for
+    |delta| <= 0.45 only, so an initial steering state of 1.0-1.3 rad (2.57 against the series' 2.48 at 1.2: every f32 rollout rotated
+    by the same wrong angle) must take the sin / cos path of that ego -- outputs bit-identical to the all-fp64 kernel, and the fp64
+    winner's f32 cost still within the margin of the f32 minimum."""
+    E, T, R = 48, 40, 512
+    x0, ref, ctrl = _stmpc_case(ctx, 61, E, T, R, 2.6, 5.0, 1.5)
+    x0[:, 2] = np.where(np.arange(E) % 3 == 0, 0.02, np.linspace(-1.3, 1.3, E))
+    cfg = _abi.stmpc_cfg(horizon=T, n_rollouts=R)
+    d_c32, d_n = ctx.alloc(4 * E * R), ctx.alloc(4 * E)
+    try:
+        ctx.stmpc_set_mode(True, d_c32, d_n)
+        got = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+        c32 = d_c32.download(np.float32, (E, R)); nref = d_n.download(np.int32, (E,))
+        ctx.stmpc_set_mode(False)
+        want = ctx.stmpc_shoot(x0, ref, ctrl, cfg)
+    finally:
+        ctx.stmpc_set_mode(True)
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    e_ok = np.nonzero(nref >= 1)[0]
+    assert len(e_ok) > E // 2
+    cb = c32[e_ok, want["best_idx"][e_ok]]
+    tmin = np.where(np.isfinite(c32[e_ok]), c32[e_ok], np.inf).min(axis=1)
+    tr = np.isfinite(cb)
+    margin = np.abs(tmin) * min(2.0e-5 * T, 0.5) + 2.0e-2
+    assert ((cb - tmin)[tr] <= 0.1 * margin[tr]).all()

@@ -4,8 +4,11 @@
 
     python tools/kernel_resources.py            # table
     python tools/kernel_resources.py --check    # exit 1 when a kernel carries more scratch than its budget (BUDGET; default 0)
+    python tools/kernel_resources.py --objdir build_x    # another object directory of csrc/ (variant builds)
 
-Compiles to /dev/null-equivalent objects under /tmp; CPU only (hipcc cross-compiles gfx950).
+Reads the compiler's own remarks of the REAL build (csrc/Makefile keeps them next to every object, <obj>.res: same flags as the shipped
+object, per-file flags such as k_stmpc.o's -fno-slp-vectorize included); `make libf1p.so` is run first so they are current.  Nothing is
+compiled here, nothing is written outside the build directory.  CPU only (hipcc cross-compiles gfx950).
 """
 import glob
 import os
@@ -15,8 +18,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
-         "-Rpass-analysis=kernel-resource-usage"]
 # scratch bytes per lane a kernel may carry (mangled-name substring -> budget).  Everything else must have none.
 #   ILb1E...            the materialising variants (all_traj requested): HBM-write-bound, not VALU-bound
 #   k_kmpc_*            spills sit in the once-per-workgroup setup blocks and the rarely taken serial fp64 fallback, not in the
@@ -35,13 +36,9 @@ def demangle(names):
         return names
 
 
-def resources(src):
-    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", src, "-o", "/tmp/_kres.o"], capture_output=True, text=True, cwd=CSRC)
-    if r.returncode:
-        sys.stderr.write(r.stderr)
-        raise SystemExit(r.returncode)
+def resources(res_file):
     rows, cur = [], None
-    for ln in r.stderr.splitlines():
+    for ln in open(res_file, errors="replace").read().splitlines():
         m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]):\s*(\S+)", ln)
         if not m:
             continue
@@ -62,8 +59,18 @@ def main():
     if quiet:
         sys.stdout = open(os.devnull, "w")
     print(f"{'kernel':<58} {'SGPR':>5} {'VGPR':>5} {'AGPR':>5} {'sgpr-spill':>10} {'vgpr-spill':>10} {'scratch':>8} {'occ':>4} {'LDS':>7}")
-    for src in sorted(glob.glob(os.path.join(CSRC, "k_*.hip"))) + [os.path.join(CSRC, "f1p_api.hip")]:
-        rows = resources(src)
+    objdir = sys.argv[sys.argv.index("--objdir") + 1] if "--objdir" in sys.argv else "build"
+    if objdir == "build":                                   # the default build: bring it (and its remarks) up to date first
+        r = subprocess.run(["make", "-C", CSRC, "-j4", "libf1p.so"], capture_output=True, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise SystemExit(r.returncode)
+    res = sorted(glob.glob(os.path.join(CSRC, objdir, "k_*.o.res"))) + [os.path.join(CSRC, objdir, "f1p_api.o.res")]
+    srcs = sorted(glob.glob(os.path.join(CSRC, "k_*.hip")))
+    if len(res) != len(srcs) + 1 or not all(os.path.exists(p) for p in res):
+        raise SystemExit(f"kernel_resources: {objdir}/ holds remarks for {len(res) - 1} of {len(srcs)} kernel files -- rebuild (make clean; make)")
+    for rf in res:
+        rows = resources(rf)
         names = demangle([r["name"] for r in rows])
         for r, nm in zip(rows, names):
             print(f"{nm[:58]:<58} {r.get('TotalSGPRs', '?'):>5} {r.get('VGPRs', '?'):>5} {r.get('AGPRs', '?'):>5} {r.get('SGPRs Spill', '?'):>10} "
