@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the candidate-sharded and kmpc legs of the default run")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="profiling runs (tools/profile_gpu.sh): nothing but the warm-up and the timed steady-state region touches the GPU, so that "
+                         "every dispatch of a kernel in the trace is a steady-state one")
     ap.add_argument("--latency-iters", type=int, default=200, help="host-boundary plan() calls for p50/p95 (0 = skip)")
     ap.add_argument("--workload", choices=["lattice", "lattice-materialised", "kmpc", "stmpc", "pursuit"], default="lattice",
                     help="lattice = the headline (BASELINE configs[2]); the others are secondary lines for DESIGN.md")
@@ -204,7 +207,9 @@ class Ranks:
         d_cost.upload(c); d_idx.upload(i)
 
     def comm_info(self, ctx):
-        return (self.world, self.rank) if self.oversubscribed else ctx.comm_info()
+        """(ranks, rank) of the RCCL communicator itself; (None, rank) under the test hook that shares one GPU between ranks -- no
+        communicator exists there, the exchange is the gloo stand-in"""
+        return (None, self.rank) if self.oversubscribed else ctx.comm_info()
 
     def init_rccl(self, ctx, fatal=False):
         """ncclCommInitRank off the critical path.  The communicator only serves the candidate-sharded / exchange legs -- the headline
@@ -324,11 +329,15 @@ def leg_candidate_sharded(rk, ctx, rl, steps, E=4096, C=512, S=50, timed=True):
     d_steer, d_speed, d_status, d_near, d_traj = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)
     r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E),
                                                                   ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
-    ctx.lattice_plan_dev(d_poses, E, cfg, r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj)     # the unsharded truth
+    # the similarity term is live here too: a first plan's winners are the previous path of the sharded plan AND of its unsharded truth
+    ctx.lattice_set_closed_loop(False)
+    ctx.lattice_plan_dev(d_poses, E, cfg, r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj)
+    d_prev = ctx.to_device(np.ascontiguousarray(r_traj.download(np.float64, (E, S, 4))[:, :, 2]))
+    ctx.lattice_plan_dev(d_poses, E, cfg, r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj, d_prev_theta=d_prev)   # the unsharded truth
     nranks, myrank = rk.comm_info(ctx)
 
     def step():
-        ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost)                                  # this rank's candidate slice
+        ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost, d_prev_theta=d_prev)             # this rank's candidate slice
         rk.exchange(ctx, d_cost, d_idx, E)                                                               # RCCL, same stream
         ctx.lattice_emit_dev(d_poses, E, cfg, d_idx, d_cost, d_steer, d_speed, d_status, d_near, d_traj)
 
@@ -338,8 +347,9 @@ def leg_candidate_sharded(rk, ctx, rl, steps, E=4096, C=512, S=50, timed=True):
                 (d_cost, r_cost, np.float64, (E,)), (d_status, r_status, np.int32, (E,)), (d_near, r_near, np.int32, (E,)),
                 (d_traj, r_traj, np.float64, (E, S, 4))))
     same_everywhere = rk.all_equal_int(1 if same else 0) and same
-    out = {"egos": E, "candidates": C, "stations": S, "candidates_per_rank": int(sh.cand_count), "rccl_ranks": int(nranks),
-           "rccl_rank_of_reporter": int(myrank), "bit_identical_to_unsharded_plan_on_every_rank": bool(same_everywhere)}
+    out = {"egos": E, "candidates": C, "stations": S, "candidates_per_rank": int(sh.cand_count), "rccl_ranks": None if nranks is None else int(nranks),
+           "rccl_rank_of_reporter": int(myrank), "bit_identical_to_unsharded_plan_on_every_rank": bool(same_everywhere),
+           "similarity_term": "live (previous path = a first plan's winners, device-resident)"}
     def exchange_only(n):
         """the exchange alone: evaluate, drain the stream, then time only the two collectives + the two key kernels"""
         ex = []
@@ -408,6 +418,7 @@ def leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, steps
     bufs = []
     for c in ctxs:
         c.set_waypoints(rl); c.set_grid(img, res, origin, 206)
+        c.lattice_set_closed_loop(True)                             # steady state: every plan's previous path is its context's last plan
         d_p = c.to_device(poses)
         bufs.append((d_p, (c.alloc(8 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(8 * E), c.alloc(4 * E), c.alloc(4 * E), c.alloc(8 * E * S * 4))))
     for c, (d_p, b) in zip(ctxs, bufs):
@@ -432,9 +443,27 @@ def leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, steps
             "note": "two contexts on one GPU, plans issued alternately: one plan's fp64 refinement / selection overlaps the next plan's f32 filter"}
 
 
+def kmpc_valu_roofline(pmc, kernel_ms, E, R, T):
+    """roofline.valu of k_kmpc_plan_gen from the newest committed PMC profile of this configuration (instructions per launch are a property
+    of the code, the duration is the one measured in this run)"""
+    if not (pmc and pmc.get("SQ_INSTS_VALU")):
+        return None
+    tl = pmc["SQ_INSTS_VALU"] * 64.0 / (kernel_ms * 1e-3) / 1e12
+    v = {"kernel": pmc["kernel"], "achieved": tl, "peak": VALU_PEAK_F32_GUIDE, "unit": "T lane-instr/s", "frac": tl / VALU_PEAK_F32_GUIDE,
+         "peak_definition": "MI355X_MICROARCH.md: one wave64 f32 VALU instruction per 2 cycles at 2.4 GHz; measured on this chip "
+                            "(profiles/r03_valu_issue_cycles.txt): 2.5 cycles for plain VGPR-operand f32, 4.3 for packed f32 / integer multiplies / "
+                            "conversions (most of this kernel: Philox + v_pk_fma), 8.3 for transcendentals",
+         "frac_of_slow_class_issue_peak": tl / VALU_PEAK_SLOW_CLASS,
+         "valu_instr_per_rollout_step": pmc["SQ_INSTS_VALU"] * 64.0 / (E * R * T), "source": pmc["source"]}
+    if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+        v["busy_frac_profiled"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+    return v
+
+
 def leg_kmpc_c4(rk, args, steps):
-    """BASELINE configs[4]: kinematic-MPC random shooting, 1024 egos x 512 rollouts x 30 steps IN TOTAL, 1024 / N egos per GPU,
-    controls streamed from HBM (8 B per rollout-step)."""
+    """BASELINE configs[4]: kinematic-MPC random shooting, 1024 egos x 512 rollouts x 30 steps IN TOTAL, 1024 / N egos per GPU.  Two
+    variants: controls streamed from HBM (8 B per rollout-step) and -- the planner's own path, KMPCPlanner.plan -- controls generated in the
+    kernel around the device-resident warm start.  Carries its own roofline, cpu_baseline (rank 0, N = 1) and parity gate."""
     import numpy as np
     from f1tenth_planning_amd.dist import shard_range
     T, R, E_total = 30, 512, 1024
@@ -451,10 +480,30 @@ def leg_kmpc_c4(rk, args, steps):
     elapsed, ms_total = timed_region(rk, ctx, step, 5, steps)
     kernel_ms = ms_total / steps
     abytes = E * R * T * 8 + E * (T + 1) * 32 + E * 32 + E * 28
+    gbs = abytes / (kernel_ms * 1e-3) / 1e9
     out = {"workload": f"kmpc shooting: {E_total} egos x {R} rollouts x {T} steps over {rk.world} GPU(s) (BASELINE configs[4]), {E} egos per GPU",
            "rollout_steps_per_s": float(E_total) * R * T * steps / elapsed, "ms_per_plan": elapsed / steps * 1e3, "kernel_ms": kernel_ms,
-           "control_stream_GBps_per_gpu": abytes / (kernel_ms * 1e-3) / 1e9,
-           "note": "controls streamed from HBM as f32 [E][T][2][R]; 126 MB per 1024 egos, i.e. Infinity-Cache resident below ~2048 egos per GPU"}
+           "control_stream_GBps_per_gpu": gbs,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_kmpc_shoot_mixed", "algorithmic_bytes_per_launch": abytes, "bytes_per_rollout_step": abytes / (E * R * T),
+                        "note": "126 MB of controls per 1024 egos are Infinity-Cache resident across launches below ~2048 egos per GPU: a cache-stream "
+                                "rate, NOT an HBM fraction (profiles/r04_kmpc8192_* is the HBM-resident evidence)"},
+           "note": "controls streamed from HBM as f32 [E][T][2][R]"}
+    # parity + CPU baseline of the streamed plan (rank 0; the CPU figure is an N = 1 one)
+    if rk.rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle
+        nthr = oracle.max_threads()
+        n_cpu = min(E, max(nthr, 128))
+        ctrl = d_ctrl.download(np.float32, (E, T, 2, R))[:n_cpu]
+        t1 = time.perf_counter()
+        want = oracle.kmpc_shoot_batch(states[:n_cpu], ref[:n_cpu], ctrl, cfg, nthreads=nthr)
+        cpu_s = time.perf_counter() - t1
+        got = d_bi.download(np.int32, (E,))[:n_cpu]
+        out["parity"] = {"egos_checked": int(n_cpu), "best_idx_mismatches": int((want["best_idx"] != got).sum()),
+                         "max_abs_dsteer": float(np.abs(want["steer"] - d_steer.download(np.float64, (E,))[:n_cpu]).max())}
+        if rk.world == 1:
+            out["cpu_baseline"] = {"value": n_cpu * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
+                                   "sample": f"first {n_cpu} egos x {R} rollouts x {T} steps, oracle/f1p_oracle.c orc_kmpc_shoot_batch, {nthr} threads, {cpu_s:.2f} s"}
     # the same plan with the controls generated in the kernel around the device-resident warm start (no control buffer at all)
     from f1tenth_planning_amd import _abi
     calls = [0]
@@ -467,12 +516,88 @@ def leg_kmpc_c4(rk, args, steps):
     for _ in range(30):                                   # host boundary: x0 up, reference extraction, plan, winners down
         smp = _abi.kmpc_sampler(seed=2 + rk.rank, call=calls[0]); calls[0] += 1
         t1 = time.perf_counter(); ctx.kmpc_plan(states, cfg, smp, want_seq=False, want_cost=False); ts.append((time.perf_counter() - t1) * 1e3)
-    out["generated_in_kernel"] = {"rollout_steps_per_s": float(E_total) * R * T * steps / g_elapsed, "ms_per_plan": g_elapsed / steps * 1e3,
-                                  "kernel_ms": g_ms / steps, "host_boundary_p50_ms": float(np.percentile(ts, 50)),
-                                  "note": "f1p_kmpc_plan_*: Philox4x32-10 controls in registers around the ctx's warm start; VALU-bound, no HBM stream; "
-                                          "one workgroup per ego at every batch size (f1p_kmpc_set_groups can split an ego's rollouts; measured slower)"}
+    gen = {"rollout_steps_per_s": float(E_total) * R * T * steps / g_elapsed, "ms_per_plan": g_elapsed / steps * 1e3,
+           "kernel_ms": g_ms / steps, "host_boundary_p50_ms": float(np.percentile(ts, 50)),
+           "note": "f1p_kmpc_plan_*: Philox4x32-10 controls in registers around the ctx's warm start; VALU-bound, no HBM stream; "
+                   "one workgroup per ego at every batch size (f1p_kmpc_set_groups can split an ego's rollouts; measured slower)"}
+    if rk.rank == 0:
+        g_bytes = E * (T + 1) * 32 + E * 32 + E * 28 + E * T * 16
+        valu = kmpc_valu_roofline(load_pmc({"workload": "kmpc", "egos": E, "rollouts": R, "horizon": T, "controls": "generated"}), g_ms / steps, E, R, T)
+        gen["roofline"] = {"bound": "valu" if valu else "hbm", "achieved": valu["achieved"] if valu else g_bytes / (g_ms / steps * 1e-3) / 1e9,
+                           "peak": valu["peak"] if valu else HBM_PEAK_GBS, "unit": valu["unit"] if valu else "GB/s",
+                           "frac": valu["frac"] if valu else g_bytes / (g_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_kmpc_plan_gen", "valu": valu,
+                           "hbm": {"achieved": g_bytes / (g_ms / steps * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "algorithmic_bytes_per_launch": g_bytes, "bytes_per_rollout_step": g_bytes / (E * R * T)}}
+        if not args.no_cpu_baseline:                      # parity of the generated plan: its controls materialised for the oracle
+            from oracle import oracle
+            nthr = oracle.max_threads()
+            n_cpu = min(E, max(nthr, 128))
+            ctx.kmpc_warm_reset()
+            smp = _abi.kmpc_sampler(seed=2 + rk.rank, call=54321, use_warm=False)
+            ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, smp, d_steer, d_speed, d_bi, None)
+            ctx.kmpc_gen_controls_dev(d_ctrl, E, cfg, smp)
+            ctrl = d_ctrl.download(np.float32, (E, T, 2, R))[:n_cpu]
+            want = oracle.kmpc_shoot_batch(states[:n_cpu], ref[:n_cpu], ctrl, cfg, nthreads=nthr)
+            gen["parity"] = {"egos_checked": int(n_cpu), "best_idx_mismatches": int((want["best_idx"] != d_bi.download(np.int32, (E,))[:n_cpu]).sum())}
+    out["generated_in_kernel"] = gen
     ctx.close()
     return out
+
+
+def filter_shape(S, r):
+    """What k_lattice_filter3 does per candidate in the clearance mode r (station_loop_f2, csrc/k_lattice.hip -- this mirrors its loop
+    structure): G = 2 r + 1; r single intervals up to the first tested station, then ONE integrated piece of G intervals between
+    consecutive tested stations, single intervals through the tail; one look-up per tested station.  r = 0: every interval a piece of
+    its own, every station looked up."""
+    if r <= 0:
+        return {"pieces_integrated_per_candidate": S - 1, "stations_looked_up_per_candidate": S, "clearance_r": 0}
+    G = 2 * r + 1
+    pieces = tests = 0
+    base = pos = 0
+    if base + G < S:
+        pieces += r; pos = r; tests += 1
+        base = G
+        while base + G < S:
+            pieces += 1; pos += G; tests += 1
+            base += G
+    pieces += (S - 1) - pos
+    tests += 1
+    return {"pieces_integrated_per_candidate": pieces, "stations_looked_up_per_candidate": tests, "clearance_r": r,
+            "intervals_per_candidate": S - 1, "stations_per_candidate": S}
+
+
+def algorithmic_ops(poses, rl, cfg, grid, prev_in, n_egos=3, stride=8):
+    """"the builder must replace these estimates by an exact count from its own CPU restatement".  oracle/opcount.py is the
+    oracle's candidate path on a counting float (tests/test_oracle_opcount.py pins it to the C oracle's costs); here it runs over a sample of
+    this run's candidates (every `stride`-th candidate of the first n_egos egos, similarity term and occupancy test included)."""
+    from oracle import opcount, oracle
+    tot = {"incremental": [], "reference": []}
+    n = 0
+    classes = None
+    for e in range(min(n_egos, len(poses))):
+        goals, valid = oracle.lattice_goals(poses[e], rl, cfg)
+        g = goals[valid][::stride]
+        if not len(g):
+            continue
+        for scheme in tot:
+            _, counts = opcount.count_candidates(g, poses[e], cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[e], scheme=scheme)
+            sm = opcount.summarize(counts, len(g), cfg.n_stations)
+            tot[scheme].append(sm["ops_per_candidate"])
+            if scheme == "incremental":
+                classes = sm["by_class_per_candidate"]
+        n += len(g)
+    if not n:
+        return None
+    import numpy as np
+    return {"ops_per_candidate": float(np.mean(tot["incremental"])), "ops_per_candidate_step": float(np.mean(tot["incremental"])) / cfg.n_stations,
+            "ops_per_candidate_reference_order": float(np.mean(tot["reference"])),
+            "by_class_per_candidate": classes, "candidates_counted": n,
+            "definition": "scalar fp64 ops of oracle/opcount.py's restatement of one candidate (G1 fit by Newton on 16-point Gauss-Legendre moments, "
+                          "S stations, occupancy look-up, four cost terms): add/sub, mul, div, sqrt, compare-class and transcendental CALLS count 1 each, "
+                          "a multiply-add pair 2.  ops_per_candidate = one 8-point rule per station interval + running sum (what a batched "
+                          "implementation does: oracle/numpy_lattice.py); ops_per_candidate_reference_order = every station integrated from 0 as the "
+                          "reference's per-station X(s) / Y(s) calls do (utils/utils.py:289-293)"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -507,9 +632,16 @@ def main_lattice(args):
     d_all_cost = ctx.alloc(8 * E * C) if materialised else None
     d_all_traj = ctx.alloc(8 * E * C * S * 4) if materialised else None   # the reference's all_traj data flow (:194-201)
 
+    # Steady state (round 4): the reference's fourth cost, get_similarity_cost (lattice_planner.py:287-296), compares with the PREVIOUS
+    # plan's best trajectory, so every plan of a closed loop but the first carries it.  Closed-loop mode keeps the winners' headings on
+    # the device (f1p_lattice_set_closed_loop): every timed plan k uses plan k-1's winners as its previous path.  `value` is THIS
+    # figure; the first plan of a chain (no previous path: the term is zero, round 3's headline) is timed beside it as `first_plan`.
+    steady = not materialised
+    ctx.lattice_set_closed_loop(steady)
+
     # p50 / p95 latency of one plan() at the ctypes boundary: host poses in, host results out (H2D + kernel + D2H + sync).
     # Runs on every rank BEFORE the timed region (it also brings the chip's clocks up, so a short --steps run is not measuring
-    # the ramp from idle).
+    # the ramp from idle).  Closed loop: the similarity term is live in every one of these calls, nothing extra crosses PCIe.
     lat = None
     if args.latency_iters > 0 and not materialised and not cand_sharded:
         import copy
@@ -527,57 +659,81 @@ def main_lattice(args):
         q50, q95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True))
         r50, r95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=False, reuse_outputs=True))
         h50, h95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True, traj_dtype=np.float32))
+        c50, c95 = percentiles(lambda: ctx.lattice_step(poses, cfg))
         cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
         ctx.lattice_set_mode(0)
         b50, b95 = percentiles(lambda: ctx.lattice_plan(poses, cfg_bb, want_traj=True, reuse_outputs=True))
         f50, f95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
         ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
+        # BASELINE configs[1]: ONE ego x 512 candidates x 50 stations, the single-vehicle call
+        cfg1 = synth.bench_lattice_cfg(n_cand=512, n_stations=S)
+        ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)       # another batch shape: re-armed
+        s50, s95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True))
+        ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)
         lat = {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
-               "includes": "H2D poses + kernel + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays",
+               "includes": "H2D poses + kernels + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays; "
+                           "closed loop: the similarity term is live (previous headings stay on the device)",
+               "closed_loop": {"p50_ms": c50, "p95_ms": c95,
+                               "note": "f1p_lattice_step_batch: poses in, (steer, speed, status) out as ONE packed block the selection kernel writes straight "
+                                       "into page-locked host memory; previous headings and best_traj stay on the device (f1p_lattice_fetch_traj on request)"},
                "pageable_host_arrays": {"p50_ms": q50, "p95_ms": q95},
                "without_best_traj": {"p50_ms": r50, "p95_ms": r95},
                "f32_best_traj": {"p50_ms": h50, "p95_ms": h95,
                                  "note": "f1p_lattice_plan_batch_f32: the same fp64 plan, best_traj rounded once to f32 on the device (3.3 MB instead of 6.6 MB down)"},
                "all_fp64": {"p50_ms": f50, "p95_ms": f95},
-               "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"}}
+               "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"},
+               "config1_single_ego": {"p50_ms": s50, "p95_ms": s95, "workload": f"1 ego x 512 candidates x {S} stations (BASELINE configs[1]), Context.lattice_plan"}}
 
     cs = None
     if cand_sharded:
         cs, step, cs_exchange = leg_candidate_sharded(rk, ctx, rl, args.steps, E=E, C=C, S=S, timed=False)
     else:
-        def step():
+        def step(d_prev=None):
             ctx.lattice_plan_dev(d_poses, E, cfg, d_steer, d_speed, d_bidx, d_bcost, d_status, d_near, d_traj,
-                                 d_all_cost=d_all_cost, d_all_traj=d_all_traj)
+                                 d_prev_theta=d_prev, d_all_cost=d_all_cost, d_all_traj=d_all_traj)
 
     elapsed, kernel_ms_total = timed_region(rk, ctx, step, args.warmup, args.steps)
 
-    # outputs of the timed (exhaustive) plan, downloaded before any other leg reuses the buffers: the parity gate below and
-    # the branch-and-bound comparison both refer to THESE
+    # outputs the parity gate and the other schedules are compared with: ONE more plan of the chain, whose previous path (the headings the
+    # last timed plan left) is copied first so that every comparison below can hand it over explicitly
+    d_prev_in = prev_in = None
     if cand_sharded:
         steer = bidx = status = None
         cs_exchange(min(args.steps, 50))
     else:
+        if steady:
+            prev_in = ctx.lattice_closed_loop_prev()
+            d_prev_in = ctx.to_device(prev_in)
+            step()
+            ctx.sync()
+            ctx.lattice_set_closed_loop(False)                    # from here on the previous path is explicit (d_prev_in)
         steer = d_steer.download(np.float64, (E,)); bidx = d_bidx.download(np.int32, (E,)); status = d_status.download(np.int32, (E,))
         ref_cost = d_bcost.download(np.float64, (E,)); ref_traj = d_traj.download(np.float64, (E, S, 4))
 
-    # The same plan by the other schedules, every one checked bit for bit against the timed plan's outputs:
+    # the first plan of a chain: no previous path, the similarity term is zero (what rounds 1-3 timed)
+    first_plan = None
+    if steady and not cand_sharded and not args.only_timed:
+        e1, k1 = timed_region(rk, ctx, step, min(args.warmup, 5), args.steps)
+        first_plan = {"ms_per_step": e1 / args.steps * 1e3, "kernel_ms": k1 / args.steps, "value": float(E) * C * S * args.steps * world / e1,
+                      "note": "closed loop off, prev_theta = NULL: w_similarity multiplies 0 (rounds 1-3 timed this)"}
+
+    # The same plan by the other schedules, every one checked bit for bit against the chain's plan above (same previous path):
     #   all_fp64          the plain kernel (one fp64 thread per candidate; round 1's headline kernel)
     #   branch_and_bound  all fp64 with cfg.prune = 1 (station loops skipped while a cost lower bound exceeds the best so far)
-    # `value` is the default schedule: f32 filter over EVERY candidate-trajectory-step + fp64 decision (k_lattice_filter / _refine /
-    # _select), or --all-fp64 / --prune.
-    bnb = fp64 = None
-    if rank == 0 and not materialised and args.generator == "clothoid" and not cand_sharded:
+    #   every_station     the default schedule with f1p_lattice_set_clearance(0): every station looked up in the bitmap, single intervals
+    bnb = fp64 = every_station = None
+    if rank == 0 and not materialised and args.generator == "clothoid" and not cand_sharded and not args.only_timed:
         import copy
         alt = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
 
         def other(cfg_x, mode):
             ctx.lattice_set_mode(mode)
             for _ in range(args.warmup):
-                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt)
+                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
             ctx.sync()
             ctx.timer_begin()
             for _ in range(args.steps):
-                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt)
+                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
             ms = ctx.timer_end() / args.steps
             same = bool((alt[2].download(np.int32, (E,)) == bidx).all() and
                         np.array_equal(alt[3].download(np.float64, (E,)), ref_cost, equal_nan=True) and
@@ -590,17 +746,23 @@ def main_lattice(args):
         fp64["note"] = "f1p_lattice_set_mode(0): every candidate-step in fp64, one thread per candidate (k_lattice)"
         bnb = other(cfg_bb, 0)
         bnb["note"] = "all fp64 + cfg.prune = 1: candidates sorted by a lower bound of their cost after the fit; a station loop runs only while the bound does not exceed the best cost found"
+        if not (args.all_fp64 or args.prune):
+            ctx.lattice_set_clearance(0)
+            every_station = other(cfg_ex, 1)
+            every_station["note"] = ("the default schedule with f1p_lattice_set_clearance(0): the f32 filter integrates every station interval as a piece "
+                                     "of its own and looks every station up in the bitmap (49 pieces, 50 look-ups per candidate)")
+            ctx.lattice_set_clearance(2)
         ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
         for b in alt:
             b.free()
 
-    # per-kernel durations of the default schedule (HIP events between its three kernels, outside the timed region)
+    # per-kernel durations of the default schedule (HIP events between its kernels, outside the timed region), same previous path
     mixed_ms = None
-    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 512:
+    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded or args.only_timed) and args.generator == "clothoid" and E >= 512:
         ctx.lattice_profile(True)
         acc = np.zeros(4)
         for _ in range(max(10, min(args.steps, 50))):
-            step()
+            step(d_prev_in)
             acc += np.array(ctx.lattice_profile(True, read=True))
         ctx.lattice_profile(False)
         acc /= max(10, min(args.steps, 50))
@@ -609,16 +771,16 @@ def main_lattice(args):
     # runtime audit of the mixed schedule (f1p_lattice_set_audit): the timed plan again, every plan followed by the all-fp64 exhaustive
     # kernel on a moving window of 256 egos and a bit-for-bit comparison of every output; outside the timed region
     audit = None
-    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded) and args.generator == "clothoid" and E >= 512:
+    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded or args.only_timed) and args.generator == "clothoid" and E >= 512:
         ctx.lattice_audit_read(reset=True)
         ctx.lattice_set_audit(1, min(256, E))
         n_aud = max(20, min(args.steps, 64))
         for _ in range(n_aud):
-            step()
+            step(d_prev_in)
         audit = ctx.lattice_audit_read(reset=True)
         ctx.lattice_set_audit(0)
-        audit["note"] = ("every audited plan: all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs compared bit for bit; "
-                         "mismatching_egos must be 0")
+        audit["note"] = ("every audited plan (similarity term live): all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs "
+                         "compared bit for bit; mismatching_egos must be 0")
 
     env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
@@ -687,28 +849,83 @@ def main_lattice(args):
             traffic = int(tb) if tb > 0 else None
         achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9              # the plan's algorithmic bytes over the plan's kernel time
         pcie_value = (float(E) * C * S / (lat["p50_ms"] * 1e-3)) if lat else None
+        default_sched = not (args.all_fp64 or args.prune or materialised or args.generator != "clothoid")
+        shape = filter_shape(S, 2) if default_sched else None
+        # SURVEY 8d's op count, from the instrumented restatement (rank 0, a few seconds of pure Python)
+        algo = None
+        if default_sched and not cand_sharded and not args.no_cpu_baseline:
+            algo = algorithmic_ops(poses, rl, cfg, (img, res, origin[0], origin[1], 206), prev_in)
+            if algo and mixed_ms:
+                ops_s = algo["ops_per_candidate"] * E * C / (dom_ms * 1e-3)
+                algo["achieved_Tops_per_s_in_the_dominant_kernel"] = ops_s / 1e12
+                algo["peak_Tops_per_s"] = 2.0 * VALU_PEAK_F32_GUIDE
+                algo["achieved_over_peak"] = ops_s / 1e12 / (2.0 * VALU_PEAK_F32_GUIDE)
+                algo["note"] = ("algorithmic ops of the CPU restatement per candidate x candidates / the candidate kernel's duration, against 157.3 T flop/s "
+                                "(guide: f32 FMA = 2 flop per lane-instruction).  NOT an efficiency: k_lattice_filter3 reaches the same decisions with "
+                                "far fewer operations (f32 fit on ONE 16-node pass, closed-form cost terms, one integrated piece per five intervals, one "
+                                "look-up per five stations: see filter_shape and valu.valu_instr_per_candidate), so this ratio measures how much work "
+                                "the algorithm removed as much as how fast the rest runs -- the issue-slot figure is roofline.frac")
+        hbm = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_launch": abytes, "bytes_per_candidate_step": abytes / (E * C * S),
+               "note": "0.14 B per candidate-step: the planning kernels are not memory-bound; the HBM fraction is tiny and reported as such"}
+        kernels_name = ("k_lattice_prologue + k_lattice_filter3 + k_lattice_refine + k_lattice_select (one plan; the dominant kernel is k_lattice_filter3)"
+                        if mixed_ms else (pmc["kernel"] if pmc else "k_lattice"))
+        if valu and not materialised:
+            # SURVEY 8d / DESIGN 5: the fused lattice path is VALU-bound -- the top-level figures are the dominant kernel's issue-slot utilisation
+            roofline = {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"],
+                        "frac_definition": "lane-instructions the dominant kernel ISSUES per second (PMC SQ_INSTS_VALU per candidate x candidates / its live duration) "
+                                           "over the guide's issue peak: an issue-slot utilisation of the kernel's own instruction stream, not a fraction of an "
+                                           "algorithmic bound (see algorithmic_ops_per_candidate for that count)"}
+        else:
+            roofline = dict(hbm)
+        roofline.update({"traffic": traffic, "traffic_source": pmc["source"] if traffic is not None else None, "kernel": kernels_name,
+                         "kernel_ms": kernel_ms, "dominant_kernel_ms": dom_ms, "kernels_ms": mixed_ms,
+                         "kernels_ms_note": ("per-kernel figures come from a separate run with a HIP event between consecutive kernels; an event is a barrier "
+                                             "packet of its own (~1.5-2 us each here), so their sum exceeds kernel_ms -- the unstamped plan of the timed "
+                                             "region -- by the stamps, not because kernels overlap (one in-order stream).  "
+                                             "profiled_kernels_us holds rocprofv3's own per-kernel averages from the committed trace") if mixed_ms else None,
+                         "profiled_kernels_us": ({k["kernel"].split("(")[0].replace("void f1p::", "").replace("f1p::", ""): round(k["avg_us"], 2)
+                                                  for k in pmc.get("all_kernels", []) if k.get("avg_us") and "lattice" in k.get("kernel", "")} if same_cfg else None),
+                         "hbm": hbm, "valu": valu})
+        steady_state = None
+        if steady and not cand_sharded:
+            steady_state = {"ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms, "value": value,
+                            "note": "closed loop: plan k's previous path = plan k-1's winners (device-resident headings); all four cost terms live"}
         out = {
             "metric": "candidate-trajectory-steps/sec per GPU; p50 plan() latency @4096 egos",
             "value": value, "unit": "candidate-trajectory-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if cand_sharded else "weak", "vs_baseline": None,
-            "dtype": "f64" if (args.all_fp64 or args.prune or materialised or args.generator != "clothoid") else "f32 filter + f64 decision", "data": "synthetic",
+            "dtype": "f64" if not default_sched else "f32 filter + f64 decision", "data": "synthetic",
             "config": {"workload": (f"batched lattice, candidate-sharded: {E} egos x {C} candidates x {S} stations, candidates split over {world} GPU(s) + RCCL all-reduce(min)"
                                     if cand_sharded else
                                     f"batched lattice{' (all_traj materialised)' if materialised else ''}: {E} egos x {C} candidates x {S} stations per GPU (BASELINE configs[{3 if world == 8 and E == 4096 else 2}])"),
                        "egos_per_gpu": E, "candidates": C, "stations": S, "raceline_points": int(rl.shape[0]),
                        "grid": [int(img.shape[1]), int(img.shape[0])], "goals": "device-sampled 16 x %d" % (C // 16), "generator": args.generator,
+                       "cost_terms": "1/L, max|kappa|, mean|kappa|, heading similarity to the previous plan's winner (weights 0.25 each) + occupancy => +inf",
+                       "state": "steady state of a closed loop (similarity term live)" if steady else "single plans (no previous path)",
                        "parallelism": (f"one ego batch, candidates sharded over {world} GPU(s), RCCL all-reduce(min)" if cand_sharded
                                        else f"egos sharded over {world} GPU(s), no collective")},
-            "value_definition": "E*C*S*steps*n_gpus / wall time of the K timed launches, inputs resident in HBM (kernel-only figure); "
-                                "the SURVEY 8d host-boundary figure (H2D + kernel + D2H + sync per plan) is pcie_inclusive_value",
+            "value_definition": "E*C*S*steps*n_gpus / wall time of the K timed STEADY-STATE plans, inputs resident in HBM (kernel-only figure).  E*C*S is the "
+                                "workload's NOMINAL size (BASELINE's unit): the default schedule does not evaluate every candidate-step literally (filter_shape); "
+                                "every_station and all_fp64 are the schedules that do, timed beside it with bit-identical outputs.  "
+                                "The SURVEY 8d host-boundary figure (H2D + kernels + D2H + sync per plan) is pcie_inclusive_value / plan_latency_host_boundary",
             "per_gpu_value": value / (1 if cand_sharded else world),
+            "steady_state": steady_state,
+            "first_plan": first_plan,
             "pcie_inclusive_value": pcie_value,
             "plan_latency_host_boundary": lat,
-            "schedule": ("all fp64" + (" + branch and bound" if args.prune else "")) if (args.all_fp64 or args.prune) else
-                        "f32 filter over every candidate-step + fp64 decision (outputs bit-identical to the all-fp64 kernel)",
+            "schedule": ("all fp64" + (" + branch and bound" if args.prune else "")) if not default_sched else
+                        ("k_lattice_prologue (fp64, wave per ego: nearest segment, look-ahead centres, goal frames, moments of the previous path) -> "
+                         "k_lattice_filter3 (f32, thread per candidate: G1 fit on one 16-node pass, integrated pieces + clearance look-ups per filter_shape, "
+                         "closed-form curvature and similarity terms, cost bracket + collision state) -> k_lattice_refine (fp64, the reference's arithmetic "
+                         "on the ~2 candidates per ego the brackets cannot rank) -> k_lattice_select (fp64 argmin, winner's rows, tracker); "
+                         "outputs bit-identical to the all-fp64 kernel"),
+            "filter_shape": shape,
+            "algorithmic_ops_per_candidate": algo,
             "all_fp64": fp64,
             "branch_and_bound": bnb,
+            "every_station": every_station,
             "candidate_sharded": cs,
             # top level for multi-GPU runs: the communicator's own rank count and the exchange alone (HIP events around the two
             # collectives + the two key kernels).  At one rank the "exchange" is a local self-reduce: no xGMI figure.
@@ -719,22 +936,7 @@ def main_lattice(args):
             "kmpc_c4": kmpc_c4,
             "two_plans_in_flight": two_in_flight,
             "audit": audit,
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": pmc["source"] if traffic is not None else None,
-                         "kernel": ("k_lattice_prologue + k_lattice_filter3 + k_lattice_refine + k_lattice_select (one plan; the dominant kernel is k_lattice_filter3, see valu)"
-                                    if mixed_ms else (pmc["kernel"] if pmc else "k_lattice")),
-                         "kernel_ms": kernel_ms, "dominant_kernel_ms": dom_ms, "kernels_ms": mixed_ms,
-                         "kernels_ms_note": ("per-kernel figures come from a separate run with a HIP event between consecutive kernels; an event is a barrier "
-                                             "packet of its own (~1.5-2 us each here), so their sum exceeds kernel_ms -- the unstamped plan of the timed "
-                                             "region -- by the stamps, not because kernels overlap (one in-order stream).  "
-                                             "profiled_kernels_us holds rocprofv3's own per-kernel averages from the committed trace") if mixed_ms else None,
-                         "profiled_kernels_us": ({k["kernel"].split("(")[0].replace("void f1p::", "").replace("f1p::", ""): round(k["avg_us"], 2)
-                                                  for k in pmc.get("all_kernels", []) if k.get("avg_us") and "lattice" in k.get("kernel", "")} if same_cfg else None),
-                         "algorithmic_bytes_per_launch": abytes,
-                         "bytes_per_candidate_step": abytes / (E * C * S),
-                         "note": "the planning kernels are VALU / transcendental bound by construction (0.14 B per candidate-step); the HBM fraction is tiny and reported as such",
-                         "valu": valu},
+            "roofline": roofline,
             "blocked_egos": None if status is None else int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
         if not args.no_cpu_baseline and not cand_sharded:
@@ -746,11 +948,11 @@ def main_lattice(args):
                 n_cpu = min(E, 256)                       # N > 1: parity gate only; the CPU baseline is an N = 1 figure
             if n_cpu <= 0:
                 t1 = time.perf_counter()
-                oracle.lattice_plan_batch(poses[:nthr], rl, cfg, grid=grid, nthreads=nthr)
+                oracle.lattice_plan_batch(poses[:nthr], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:nthr], nthreads=nthr)
                 per_ego = (time.perf_counter() - t1) / nthr
                 n_cpu = int(min(E, max(nthr, (12.0 / max(per_ego, 1e-6)) // nthr * nthr)))
             t1 = time.perf_counter()
-            want = oracle.lattice_plan_batch(poses[:n_cpu], rl, cfg, grid=grid, nthreads=nthr)
+            want = oracle.lattice_plan_batch(poses[:n_cpu], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:n_cpu], nthreads=nthr)
             cpu_s = time.perf_counter() - t1
             mism = int((want["best_idx"] != bidx[:n_cpu]).sum())
             dsteer = float(np.abs(want["steer"] - steer[:n_cpu]).max())
@@ -761,9 +963,10 @@ def main_lattice(args):
                 "note": "the oracle follows the reference's per-station X(s)/Y(s) evaluation (utils.py:289-293): every station is integrated "
                         "from 0, O(S^2) per candidate -- a faithful restatement, not a tuned CPU implementation; the GPU/CPU ratio is no credit"}
             out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": mism, "max_abs_dsteer": dsteer,
-                             "checked_outputs": "the timed exhaustive plan's (downloaded right after the timed region)"}
+                             "checked_outputs": "the plan of the closed-loop chain right after the timed region (its previous path handed to the oracle)",
+                             "similarity_term_live": prev_in is not None}
             if world == 1 and args.generator == "clothoid" and not materialised and os.path.exists(os.path.join(ROOT, "oracle", "numpy_lattice.py")):
-                out["cpu_baseline_numpy"] = numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer)
+                out["cpu_baseline_numpy"] = numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, prev_in=prev_in)
         if rk.rccl_note:
             out["rccl_init"] = rk.rccl_note
         print(json.dumps(out), flush=True)
@@ -775,7 +978,7 @@ def main_lattice(args):
     ctx.close()
 
 
-def numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, budget_s=15.0):
+def numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, budget_s=15.0, prev_in=None):
     """north_star's "same-box CPU numpy baseline": oracle/numpy_lattice.py, the path vectorised over E x C arrays in fp64 numpy.
     numpy's elementwise kernels are single-threaded -> 1 core (BLAS is not on the path; OMP/MKL threads are pinned to 1 anyway).
     Runs on a reduced ego count sized to the time budget; the per-step rate is size-independent above a few egos."""
@@ -789,7 +992,7 @@ def numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, budget_s=15.0):
 
     def run(n):
         t1 = time.perf_counter()
-        r = numpy_lattice.lattice_plan_batch(poses[:n], rl, cfg, grid=grid)
+        r = numpy_lattice.lattice_plan_batch(poses[:n], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:n])
         return r, time.perf_counter() - t1
     if threadpool_limits:
         with threadpool_limits(limits=1):

@@ -187,6 +187,8 @@ PROTOTYPES = {
     "f1p_lattice_plan_dev_f32": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 7),
     "f1p_lattice_set_closed_loop": (C.c_int, [_P, _I]),
     "f1p_lattice_closed_loop_state": (C.c_int, [_P, _P, _P, _P]),
+    "f1p_lattice_step_batch": (C.c_int, [_P, _P, _I, C.POINTER(LatticeCfg), _P, _P, _P, _I]),
+    "f1p_lattice_fetch_traj": (C.c_int, [_P, _P, _I, _I]),
     "f1p_lattice_set_mode": (C.c_int, [_P, _I, _P, _P]),
     "f1p_lattice_set_split": (C.c_int, [_P, _I]),
     "f1p_lattice_set_clearance": (C.c_int, [_P, _I]),

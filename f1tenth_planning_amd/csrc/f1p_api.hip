@@ -145,10 +145,25 @@ struct Stage {
 #define F1P_PLAN_CHUNK_MIN_EGOS 2048
 #define F1P_PLAN_CHUNKS_MAX 8          // = number of slice events in f1p_ctx
 
-static bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable: not known to HIP
-    return a.type == hipMemoryTypeHost;
+// The device-side address of [p, p + bytes) when the WHOLE range lies in page-locked host memory this device can address (hipHostMalloc /
+// hipHostRegister), else null.  A kernel that stores through it writes straight into the caller's array; a range that is only partly
+// registered would fault, so both ends must be known to HIP as host memory with ONE linear device mapping between them (the
+// first byte alone had been checked, and the host address used instead of attr.devicePointer).
+static void* pinned_device_ptr(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return nullptr;
+    hipPointerAttribute_t a, b;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // pageable: not known to HIP
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    if (bytes > 1) {
+        if (hipPointerGetAttributes(&b, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (b.type != hipMemoryTypeHost || !b.devicePointer) return nullptr;
+        if ((const char*)b.devicePointer - (const char*)a.devicePointer != (ptrdiff_t)(bytes - 1)) return nullptr;
+        void* base = nullptr; size_t size = 0;                       // one allocation (where the runtime can tell)
+        if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)a.devicePointer) == hipSuccess) {
+            if ((const char*)a.devicePointer + bytes > (const char*)base + size) return nullptr;
+        } else (void)hipGetLastError();
+    }
+    return a.devicePointer;
 }
 
 static int ensure_copy_stream(f1p_ctx* ctx) {
@@ -283,11 +298,12 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1]};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1], ctx->d_step};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    if (ctx->h_step) (void)hipHostFree(ctx->h_step);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto& ev : ctx->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->ev_prof) if (ev) (void)hipEventDestroy(ev);
@@ -767,10 +783,15 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
         return set_error(ctx, F1P_EINVAL, "a candidate shard (cfg.cand_count > 0) only evaluates: it produces best_idx, best_cost and near_idx; "
                                           "pass NULL for steer / speed / status / best_traj and emit the global winner with f1p_lattice_emit_dev");
     const size_t C = (size_t)cfg->n_lookahead * cfg->n_width, S = cfg->n_stations, e = E;
+    // (page-locked best_traj: see below -- decided here so that the arena does not reserve bytes nobody uses)
+    TRAJ* bt_dev = (best_traj && !all_cost && !all_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS)
+                       ? (TRAJ*)pinned_device_ptr(best_traj, sizeof(TRAJ) * e * S * 4) : nullptr;
+    const bool pinned = bt_dev != nullptr;
+    const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
     Stage s(ctx);
     s.need(8 * 4 * e); s.need(8 * e * C * 3, goals); s.need(8 * e * S, prev_theta);
     s.need(8 * e, steer); s.need(8 * e, speed); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
-    s.need(sizeof(TRAJ) * e * S * 4, best_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
+    s.need(sizeof(TRAJ) * e * S * 4, best_traj && !zero_copy_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);
     if ((rc = s.begin())) return rc;
     const double *d_poses, *d_goals, *d_prev;
     if ((rc = s.in(poses, 4 * e, &d_poses))) return rc;
@@ -788,9 +809,7 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
     // 0.233); slicing only the selection kernel was worse still (0.30 / 0.24: every cross-stream edge costs ~10 us).
     // From 8192 egos the batch is planned in slices of >= 4096 egos whose results travel on a second stream while the next slice
     // is planned (only into page-locked memory: copies into pageable memory block the calling thread and would serialise the slices).
-    const bool pinned = best_traj && !all_cost && !all_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS && is_pinned_host(best_traj);
-    const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
-    TRAJ* d_bt = zero_copy_traj ? best_traj : s.out(best_traj, e * S * 4);
+    TRAJ* d_bt = zero_copy_traj ? bt_dev : s.out(best_traj, e * S * 4);
     double* d_ac = s.out(all_cost, e * C); double* d_at = s.out(all_traj, e * C * S * 4);
     auto plan = [&](size_t e0, size_t n) {
         double* bt64 = nullptr; float* bt32 = nullptr;
@@ -834,6 +853,86 @@ int f1p_lattice_plan_batch_f32(f1p_ctx* ctx, const double* poses, const double* 
                                double* best_cost, int32_t* status, int32_t* near_idx, float* best_traj32) {
     F1P_ENTER(ctx);
     return lattice_plan_batch_impl<float>(ctx, poses, goals, prev_theta, E, cfg, steer, speed, best_idx, best_cost, status, near_idx, best_traj32, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One closed-loop control step: poses in, (steer, speed, status) out, nothing else across PCIe.  No copy is submitted in either
+// direction: k_lattice_prologue reads the poses straight out of page-locked host memory (one 32-byte read per ego-wave, hidden by
+// the other waves) and leaves a device copy for the kernels behind it; the selection kernel stores the three result columns straight
+// into page-locked host memory.  The caller's own arrays are used when they are page-locked (f1p_host_alloc / hipHostRegister), the
+// context's block otherwise (one memcpy each way on the host).  Previous headings (similarity term) and -- on request -- the winners'
+// rows stay in HBM.
+static int ensure_step(f1p_ctx* ctx, int E, int S, bool keep_traj) {
+    const size_t hb = al256(32 * (size_t)E) + 2 * al256(8 * (size_t)E) + al256(4 * (size_t)E);
+    if (hb > ctx->step_host_bytes) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_step) (void)hipHostFree(ctx->h_step);
+        ctx->h_step = nullptr; ctx->step_host_bytes = 0;
+        F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_step, hb, hipHostMallocDefault));
+        ctx->step_host_bytes = hb;
+    }
+    const size_t db = al256(32 * (size_t)E) + 2 * al256(4 * (size_t)E) + (keep_traj ? al256(32 * (size_t)E * S) : 0);
+    if (db > ctx->step_dev_bytes) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_step) (void)hipFree(ctx->d_step);
+        ctx->d_step = nullptr; ctx->step_dev_bytes = 0; ctx->step_traj_E = 0;
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_step, db));
+        ctx->step_dev_bytes = db;
+    }
+    return F1P_OK;
+}
+
+int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                           int32_t* status, int32_t keep_traj) {
+    F1P_ENTER(ctx);
+    int rc = validate_lattice(ctx, cfg, E, true, E == 0 || (poses && steer && speed));
+    if (rc) return rc;
+    if (cfg->cand_count > 0) return set_error(ctx, F1P_EINVAL, "f1p_lattice_step_batch plans whole egos: cfg.cand_count must be 0");
+    if (E == 0) return F1P_OK;
+    const int S = cfg->n_stations;
+    const size_t e = (size_t)E;
+    if ((rc = ensure_step(ctx, E, S, keep_traj != 0))) return rc;
+    char* hb = ctx->h_step;
+    double* h_poses = (double*)hb; double* h_steer = (double*)(hb + al256(32 * e)); double* h_speed = (double*)((char*)h_steer + al256(8 * e));
+    int32_t* h_status = (int32_t*)((char*)h_speed + al256(8 * e));
+    char* db = ctx->d_step;
+    double* d_pose_copy = (double*)db; int32_t* d_idx = (int32_t*)(db + al256(32 * e)); int32_t* d_near = (int32_t*)((char*)d_idx + al256(4 * e));
+    double* d_traj = keep_traj ? (double*)((char*)d_near + al256(4 * e)) : nullptr;
+    // the caller's arrays when page-locked, the context's block otherwise
+    const double* k_poses = (const double*)pinned_device_ptr(poses, 32 * e);
+    if (!k_poses) { memcpy(h_poses, poses, 32 * e); k_poses = (const double*)pinned_device_ptr(h_poses, 32 * e); }
+    double* k_steer = (double*)pinned_device_ptr(steer, 8 * e); double* k_speed = (double*)pinned_device_ptr(speed, 8 * e);
+    int32_t* k_status = status ? (int32_t*)pinned_device_ptr(status, 4 * e) : nullptr;
+    const bool own_steer = !k_steer, own_speed = !k_speed, own_status = status && !k_status;
+    if (own_steer) k_steer = (double*)pinned_device_ptr(h_steer, 8 * e);
+    if (own_speed) k_speed = (double*)pinned_device_ptr(h_speed, 8 * e);
+    if (own_status) k_status = (int32_t*)pinned_device_ptr(h_status, 4 * e);
+    if (!k_poses || !k_steer || !k_speed || (status && !k_status)) return set_error(ctx, F1P_ESTATE, "page-locked step block is not device-visible");
+    if (!ctx->lattice_closed_loop) { ctx->lattice_closed_loop = true; ctx->cl_valid = false; }   // a step IS a link of a closed loop
+    ClosedLoop cl;
+    if ((rc = cl_begin(ctx, nullptr, E, S, true, &cl))) return rc;
+    rc = launch_lattice(ctx, LATTICE_FULL, k_poses, nullptr, cl.prev, E, cfg, nullptr, nullptr, k_steer, k_speed, d_idx, nullptr, k_status, d_near,
+                        d_traj, nullptr, nullptr, nullptr, cl.out, d_pose_copy);
+    if (rc) return rc;
+    cl_commit(ctx, cl, E, S);
+    ctx->step_traj_E = keep_traj ? E : 0; ctx->step_traj_S = S;
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (own_steer) memcpy(steer, h_steer, 8 * e);
+    if (own_speed) memcpy(speed, h_speed, 8 * e);
+    if (own_status) memcpy(status, h_status, 4 * e);
+    return F1P_OK;
+}
+
+int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S) {
+    F1P_ENTER(ctx);
+    if (!best_traj) return set_error(ctx, F1P_EINVAL, "best_traj is NULL");
+    if (ctx->step_traj_E <= 0 || !ctx->d_step) return set_error(ctx, F1P_ESTATE, "no trajectories kept: call f1p_lattice_step_batch with keep_traj = 1 first");
+    if (E != ctx->step_traj_E || S != ctx->step_traj_S) return set_error(ctx, F1P_EINVAL, "E / S differ from the last f1p_lattice_step_batch");
+    const size_t e = (size_t)E;
+    const char* d_traj = ctx->d_step + al256(32 * e) + 2 * al256(4 * e);
+    F1P_HIP(ctx, hipMemcpyAsync(best_traj, d_traj, 32 * e * S, hipMemcpyDeviceToHost, ctx->stream));
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F1P_OK;
 }
 
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state) {

@@ -105,6 +105,12 @@ struct f1p_ctx {
     bool cl_valid = false;
     int cl_E = 0, cl_S = 0;            // shape of the last plan
 
+    // f1p_lattice_step_batch: page-locked block (poses | steer | speed | status) the kernels read / write directly, and the device side
+    // (pose copy | best_idx | near_idx | kept trajectories)
+    char* h_step = nullptr; size_t step_host_bytes = 0;
+    char* d_step = nullptr; size_t step_dev_bytes = 0;
+    int step_traj_E = 0, step_traj_S = 0;   // shape of the trajectories kept by the last step (0 = none)
+
     // candidate slices of one ego over several workgroups (few egos, many candidates): partial winners + tickets
     char* d_split_scratch = nullptr;
     int split_cap_E = 0;               // capacity (egos) the scratch is laid out for
@@ -152,7 +158,8 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
                    int E, const f1p_lattice_cfg* cfg, const int32_t* d_emit_idx, const double* d_emit_cost,
                    double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
                    int32_t* d_near_idx, double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32 = nullptr,
-                   double* d_theta_out = nullptr);   // d_theta_out [E][S]: the winners' heading column (closed-loop mode), or null
+                   double* d_theta_out = nullptr,    // d_theta_out [E][S]: the winners' heading column (closed-loop mode), or null
+                   double* d_pose_copy = nullptr);   // d_poses is page-locked HOST memory: the first kernel leaves a device copy here for the others
 int launch_clothoid_sample(f1p_ctx* ctx, const double* d_params, int n, int S, double* d_rows);
 int launch_clothoid_g1(f1p_ctx* ctx, const double* d_goals, int n, double* d_k0, double* d_dk, double* d_len, int32_t* d_ok);
 

@@ -378,6 +378,25 @@ class Context:
                                                   p(d_steer), p(d_speed), p(d_best_idx), p(d_best_cost), p(d_status),
                                                   p(d_near_idx), p(d_best_traj), p(d_all_cost), p(d_all_traj)))
 
+    def lattice_step(self, poses, cfg: LatticeCfg, keep_traj=False):
+        """One closed-loop control step (f1p_lattice_step_batch): poses [E, 4] -> dict(steer, speed, status), page-locked arrays owned by
+        the context (overwritten by the next step of the same batch size).  The previous plan's headings (similarity term) stay on the
+        device; keep_traj=True keeps the winners' rows there too (lattice_fetch_traj)."""
+        E = int(np.shape(poses)[0])
+        hp = self.pinned("step_poses", (E, 4), np.float64)
+        hp[...] = poses
+        out = dict(steer=self.pinned("step_steer", E, np.float64), speed=self.pinned("step_speed", E, np.float64),
+                   status=self.pinned("step_status", E, np.int32))
+        self._check(self.lib.f1p_lattice_step_batch(self.h, _ptr(hp), E, C.byref(cfg), _ptr(out["steer"]), _ptr(out["speed"]),
+                                                    _ptr(out["status"]), 1 if keep_traj else 0))
+        return out
+
+    def lattice_fetch_traj(self, E, S):
+        """the winners' rows [E, S, 4] of the last lattice_step(keep_traj=True)"""
+        out = np.empty((int(E), int(S), 4))
+        self._check(self.lib.f1p_lattice_fetch_traj(self.h, _ptr(out), int(E), int(S)))
+        return out
+
     def lattice_set_closed_loop(self, on=True):
         """closed-loop mode: every plan's winning headings stay on the device and are the next plan's prev_theta (similarity cost,
         lattice_planner.py:287-296) whenever prev_theta is None; (re)arming forgets the previous path"""

@@ -302,6 +302,18 @@ int f1p_lattice_plan_dev_f32(f1p_ctx* ctx, const double* d_poses, const double* 
 int f1p_lattice_set_closed_loop(f1p_ctx* ctx, int32_t on);
 int f1p_lattice_closed_loop_state(f1p_ctx* ctx, const double** d_prev_theta, int32_t* E, int32_t* S);
 
+/* One closed-loop control step for E egos -- what a simulator / vehicle fleet calls once per tick (the loop of
+ * examples/control/pure_pursuit.py:35-58 with LatticePlanner.plan, lattice_planner.py:174-214, for E vehicles): poses [E][4] in,
+ * steer [E], speed [E] and (nullable) status [E] out.  It always runs in closed-loop mode (turns it on): the previous plan's headings
+ * are the similarity term's previous path and never leave the device; best_traj is NOT returned (keep_traj = 1 keeps the winners'
+ * rows in HBM, f1p_lattice_fetch_traj copies them out on request: [E][S][4] fp64).  No copy is submitted in either direction: the
+ * kernels read the poses from, and store the results into, page-locked host memory -- the caller's own arrays when they are
+ * page-locked (f1p_host_alloc / hipHostRegister), a block of the context otherwise.  Device-sampled goals, whole egos
+ * (cfg.cand_count == 0).  Outputs are those of f1p_lattice_plan_batch on the same chain, bit for bit. */
+int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f1p_lattice_cfg* cfg, double* steer, double* speed,
+                           int32_t* status, int32_t keep_traj);
+int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S);
+
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
  *   mixed = 1 (default): batches of >= 320 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the

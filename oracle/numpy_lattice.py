@@ -227,9 +227,10 @@ def _track_batch(traj, lookahead, wheelbase, max_reacquire, speed_cmd):
     return steer, speed, status
 
 
-def lattice_plan_batch(poses, waypoints, cfg, grid=None, chunk=4):
+def lattice_plan_batch(poses, waypoints, cfg, grid=None, chunk=4, prev_theta=None):
     """LatticePlanner.plan (lattice_planner.py:174-214, glue of DESIGN.md section 3) for poses [E, 4]; device-style goal sampling,
-    clothoid generator, no previous trajectory.  grid = (img, res, ox, oy, occupied_below) or None.  Egos are processed in
+    clothoid generator.  prev_theta [E, S] = heading column of the previous plan's winners (get_similarity_cost :287-296) or None.
+    grid = (img, res, ox, oy, occupied_below) or None.  Egos are processed in
     chunks of a few egos: the E x C x S x 8 quadrature arrays of a chunk then stay cache-resident (measured: chunk 4 is 3-4x faster
     than chunk 64)."""
     poses = np.ascontiguousarray(poses, np.float64)
@@ -263,7 +264,15 @@ def lattice_plan_batch(poses, waypoints, cfg, grid=None, chunk=4):
             cost = 0.0 + cfg.w_length * (1.0 / L)
         cost = cost + cfg.w_max_kappa * ak.max(-1)
         cost = cost + cfg.w_mean_kappa * (ak.sum(-1) / S)
-        cost = cost + cfg.w_similarity * 0.0
+        if prev_theta is None:
+            cost = cost + cfg.w_similarity * 0.0
+        else:                                                                                         # get_similarity_cost :287-296 with N = S
+            m = S - cfg.n_shift - cfg.n_cull
+            dth = tr[:, :, :m, 2] - np.asarray(prev_theta, np.float64)[e0:e0 + chunk, None, cfg.n_shift:cfg.n_shift + m]
+            sim = np.zeros(dth.shape[:2])
+            for j in range(m):                                                                        # the reference's running sum, station by station
+                sim = sim + dth[:, :, j] * dth[:, :, j]
+            cost = cost + cfg.w_similarity * sim
         if cfg.check_collision and grid is not None:
             img, res, ox, oy, occ_below = grid
             h, w = img.shape

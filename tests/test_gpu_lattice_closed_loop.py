@@ -148,3 +148,45 @@ def test_closed_form_similarity_against_fp64(scene):
                         np.testing.assert_array_equal(got[n], want[n], err_msg=f"S {S} shift {n_shift} cull {n_cull} w {w_sim} prev {i} {n}")
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("E", [7, 400, 2100])
+def test_step_batch_is_the_chain_without_copies(scene, E):
+    """f1p_lattice_step_batch: poses in, (steer, speed, status) out through page-locked memory the kernels read / write directly; the
+    previous headings and the winners' rows stay in HBM.  Same outputs as the explicit chain, for page-locked AND pageable caller arrays."""
+    import ctypes as C
+    rl, img, origin = scene
+    cfg = synth.bench_lattice_cfg(n_cand=128, n_stations=40)
+    S = cfg.n_stations
+    poses0 = synth.make_egos(rl, E, seed=3 * E, pos_sigma=0.35)
+    poses0[E // 2, :2] += 400.0
+    a, b = _ctx(scene), _ctx(scene)
+    try:
+        b.lattice_set_mode(0)
+        prev = None
+        for k in range(4):
+            poses = _drive(poses0, rl, k)
+            want = b.lattice_plan(poses, cfg, prev_theta=prev)
+            if k % 2 == 0:
+                got = a.lattice_step(poses, cfg, keep_traj=(k == 2))                      # page-locked arrays of the context
+            else:                                                                           # pageable numpy arrays straight through the C-ABI
+                got = dict(steer=np.full(E, np.nan), speed=np.full(E, np.nan), status=np.full(E, -7, np.int32))
+                pp = np.ascontiguousarray(poses)
+                a._check(a.lib.f1p_lattice_step_batch(a.h, pp.ctypes.data_as(C.c_void_p), E, C.byref(cfg), got["steer"].ctypes.data_as(C.c_void_p),
+                                                      got["speed"].ctypes.data_as(C.c_void_p), got["status"].ctypes.data_as(C.c_void_p) if k == 1 else None, 0))
+                if k == 3:
+                    got["status"] = want["status"]
+            for n in ("steer", "speed", "status"):
+                np.testing.assert_array_equal(got[n], want[n], err_msg=f"step {k} {n}")
+            if k == 2:
+                np.testing.assert_array_equal(a.lattice_fetch_traj(E, S), want["best_traj"])
+            prev = want["best_traj"][:, :, 2].copy()
+            np.testing.assert_array_equal(a.lattice_closed_loop_prev(), prev)
+        from f1tenth_planning_amd.runtime import F1PError
+        with pytest.raises(F1PError):
+            a.lattice_fetch_traj(E, S)                                                      # the last step kept none
+        sh = copy.copy(cfg); sh.cand_begin, sh.cand_count = 0, 64
+        with pytest.raises(ValueError):
+            a.lattice_step(poses, sh)
+    finally:
+        a.close(); b.close()

@@ -56,6 +56,13 @@ def test_numpy_plan_equals_the_c_oracle(orc):
         assert np.abs(a["steer"] - b["steer"]).max() < 1e-9 and np.abs(a["speed"] - b["speed"]).max() < 1e-12
         assert np.abs(a["best_traj"][fin] - b["best_traj"][fin]).max() < 1e-9
         assert (b["status"] == 3).any()
+        # the similarity term (a closed loop's steady state: the previous plan's winners, perturbed)
+        prev = b["best_traj"][:, :, 2] + np.random.default_rng(seed).normal(0, 0.05, (40, S))
+        a2 = nl.lattice_plan_batch(poses, rl, cfg, grid=grid, prev_theta=prev)
+        b2 = orc.lattice_plan_batch(poses, rl, cfg, grid=grid, prev_theta=prev, nthreads=4)
+        np.testing.assert_array_equal(a2["best_idx"], b2["best_idx"])
+        fin2 = np.isfinite(b2["best_cost"])
+        assert np.abs(a2["best_cost"][fin2] - b2["best_cost"][fin2]).max() < 1e-12 and (b2["best_cost"][fin2] != b["best_cost"][fin2]).any()
 
 
 def test_numpy_clothoid_fit_matches_the_independent_solver(golden):

@@ -7,7 +7,7 @@ TAG=${1:-r03}; HEAD=${2:-k_lattice_filter3}; SCHED=${3:-mixed}
 shift $(( $# < 3 ? $# : 3 ))      # (a bare `shift 3` with fewer arguments shifts nothing and the tag would reach bench.py)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --latency-iters 0 $*"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --latency-iters 0 --only-timed $*"
 export TMPDIR=/tmp
 cd $ROOT
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o run -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
