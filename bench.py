@@ -554,15 +554,18 @@ def filter_shape(S, r):
         return {"pieces_integrated_per_candidate": S - 1, "stations_looked_up_per_candidate": S, "clearance_r": 0}
     G = 2 * r + 1
     pieces = tests = 0
-    base = pos = 0
-    if base + G < S:
+    pos = 0
+    if G < S:                                   # r single intervals to the first tested station, then one piece per tested station
         pieces += r; pos = r; tests += 1
         base = G
-        while base + G < S:
+        while base + r <= S - 1:
             pieces += 1; pos += G; tests += 1
             base += G
-    pieces += (S - 1) - pos
-    tests += 1
+        tail_test = S - 1 > pos + r             # what lies beyond pos + r is proved by the last station
+    else:
+        tail_test = True
+    pieces += (S - 1) - pos                     # single intervals through the tail
+    tests += 1 if tail_test else 0
     return {"pieces_integrated_per_candidate": pieces, "stations_looked_up_per_candidate": tests, "clearance_r": r,
             "intervals_per_candidate": S - 1, "stations_per_candidate": S}
 

@@ -1,0 +1,30 @@
+"""Steady-state vs first-plan timing of the default lattice schedule at 4096 x 256 x 50 (GPU box), per kernel; A/B over libraries:
+    F1P_LIBRARY=.../libf1p_x.so python tools/time_steady.py        (one library per process: run once per library in ONE gpurun call)"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from f1tenth_planning_amd import synth
+from f1tenth_planning_amd.runtime import Context
+E, C, S = int(os.environ.get("EGOS", 4096)), 256, 50
+N = int(os.environ.get("STEPS", 200))
+rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S); poses = synth.make_egos(rl, E, seed=1)
+with Context(0) as ctx:
+    ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+    d_poses = ctx.to_device(poses)
+    b = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
+    for _ in range(300): ctx.lattice_plan_dev(d_poses, E, cfg, *b)          # clocks up
+    line = [os.path.basename(os.environ.get("F1P_LIBRARY", "default"))]
+    for state in ("first", "steady"):
+        ctx.lattice_set_closed_loop(state == "steady")
+        for _ in range(20): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+        ctx.sync(); ctx.timer_begin()
+        for _ in range(N): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+        ms = ctx.timer_end() / N
+        ctx.lattice_profile(True)
+        acc = np.zeros(4)
+        for _ in range(50):
+            ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
+        ctx.lattice_profile(False)
+        line.append("%s %.4f ms [pro %.1f flt %.1f ref %.1f sel %.1f us]" % ((state, ms) + tuple(1e3 * acc / 50)))
+    print("  ".join(line))
