@@ -46,9 +46,13 @@ def test_random_lattice_configurations(ctx, orc, seed):
     if seed % 2:
         ctx.inflate_grid(float(rng.uniform(0.05, 0.3)))
     prev = None
+    ctx.lattice_set_mode(0)                                    # all fp64: exhaustive and branch and bound
     if seed % 3 == 1 and S - n_shift - n_cull > 0:
         prev = rng.normal(0, 0.3, (E, S))
-    ctx.lattice_set_mode(0)                                    # all fp64: exhaustive and branch and bound
+    elif seed % 3 == 2:
+        # the steady state of a closed loop: the previous plan's own winners (exactly, or nudged) -- where the f32 filter's closed-form
+        # similarity term (per-ego moments, round 4) cancels most
+        prev = ctx.lattice_plan(poses, full)["best_traj"][:, :, 2] + (0.0 if seed % 2 else rng.normal(0, 1e-3, (E, S)))
     a = ctx.lattice_plan(poses, full, prev_theta=prev)
     b = ctx.lattice_plan(poses, bb, prev_theta=prev)
     ctx.lattice_set_mode(2)                                    # f32 filter + fp64 decision, whatever the batch size
