@@ -347,19 +347,28 @@ def leg_candidate_sharded(rk, ctx, rl, steps, E=4096, C=512, S=50, timed=True):
                 (d_cost, r_cost, np.float64, (E,)), (d_status, r_status, np.int32, (E,)), (d_near, r_near, np.int32, (E,)),
                 (d_traj, r_traj, np.float64, (E, S, 4))))
     same_everywhere = rk.all_equal_int(1 if same else 0) and same
-    out = {"egos": E, "candidates": C, "stations": S, "candidates_per_rank": int(sh.cand_count), "rccl_ranks": None if nranks is None else int(nranks),
+    out = {"egos": E, "candidates": C, "stations": S, "candidates_per_rank": int(sh.cand_count), "ranks": rk.world, "rccl_ranks": None if nranks is None else int(nranks),
            "rccl_rank_of_reporter": int(myrank), "bit_identical_to_unsharded_plan_on_every_rank": bool(same_everywhere),
            "similarity_term": "live (previous path = a first plan's winners, device-resident)"}
     def exchange_only(n):
         """the exchange alone: evaluate, drain the stream, then time only the two collectives + the two key kernels"""
-        ex = []
-        for _ in range(n):
-            ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost)
-            ctx.sync(); rk.barrier()
-            ctx.timer_begin(); rk.exchange(ctx, d_cost, d_idx, E); ex.append(ctx.timer_end() * 1e3)
+        def timed_exchange():
+            ex = []
+            for _ in range(n):
+                ctx.lattice_plan_dev(d_poses, E, sh, None, None, d_idx, d_cost, d_prev_theta=d_prev)
+                ctx.sync(); rk.barrier()
+                ctx.timer_begin(); rk.exchange(ctx, d_cost, d_idx, E); ex.append(ctx.timer_end() * 1e3)
+            return ex
+        ex = timed_exchange()
         out.update({"exchange_us_p50": float(np.percentile(ex, 50)), "exchange_us_min": float(np.min(ex)), "exchange_bytes_per_rank": E * 12,
                     "exchange": ("host stand-in through gloo (ranks share one GPU: test hook)" if rk.oversubscribed else
                                  "all-reduce(min, u64 cost key) + all-reduce(min, i32 index among the holders), RCCL on the ctx stream")})
+        if not rk.oversubscribed:                                  # the single-collective form, same results (checked by the self-test)
+            ctx.comm_set_exchange(1)
+            ex1 = timed_exchange()
+            ctx.comm_set_exchange(0)
+            out["exchange_allgather"] = {"us_p50": float(np.percentile(ex1, 50)), "us_min": float(np.min(ex1)), "bytes_gathered_per_rank": E * 16 * rk.world,
+                                         "form": "f1p_comm_set_exchange(1): ONE all-gather of (key, index) records + a local minimum on every rank"}
     if timed:
         elapsed, ms_total = timed_region(rk, ctx, step, 3, steps)
         out.update({"ms_per_plan": elapsed / steps * 1e3, "candidate_steps_per_s": float(E) * C * S * steps / elapsed})
@@ -381,6 +390,11 @@ def leg_exchange_selftest(rk, ctx, E=1024):
     d_c, d_i = ctx.to_device(cost[rk.rank]), ctx.to_device(idx[rk.rank])
     rk.exchange(ctx, d_c, d_i, E)
     got_c, got_i = d_c.download(np.float64, (E,)), d_i.download(np.int32, (E,))
+    same_ag = None
+    if not rk.oversubscribed:                                      # the all-gather form must return the same bits
+        d_c2, d_i2 = ctx.to_device(cost[rk.rank]), ctx.to_device(idx[rk.rank])
+        ctx.comm_set_exchange(1); rk.exchange(ctx, d_c2, d_i2, E); ctx.comm_set_exchange(0)
+        same_ag = bool(np.array_equal(d_i2.download(np.int32, (E,)), got_i) and np.array_equal(d_c2.download(np.float64, (E,)), got_c, equal_nan=True))
     # np.argmin over all ranks' candidates ordered by global index: first NaN, else first minimum
     want_i = np.empty(E, np.int32); want_c = np.empty(E)
     for e in range(E):
@@ -388,7 +402,8 @@ def leg_exchange_selftest(rk, ctx, E=1024):
         j = order[int(np.argmin(cost[order, e]))]
         want_i[e] = idx[j, e]; want_c[e] = cost[j, e]
     ok = bool(np.array_equal(got_i, want_i) and np.array_equal(got_c, want_c, equal_nan=True))
-    return {"pairs": E, "nan_costs": int(np.isnan(cost).sum()), "matches_np_argmin_on_every_rank": rk.all_equal_int(1 if ok else 0) and ok}
+    return {"pairs": E, "nan_costs": int(np.isnan(cost).sum()), "matches_np_argmin_on_every_rank": rk.all_equal_int(1 if ok else 0) and ok,
+            "allgather_form_identical_on_every_rank": None if same_ag is None else (rk.all_equal_int(1 if same_ag else 0) and same_ag)}
 
 
 def kmpc_setup(rk, args, E, T, R, ctx=None):

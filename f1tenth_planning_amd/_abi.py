@@ -226,6 +226,8 @@ PROTOTYPES = {
     "f1p_comm_destroy": (C.c_int, [_P]),
     "f1p_comm_info": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "f1p_comm_argmin_dev": (C.c_int, [_P, _P, _P, _I]),
+    "f1p_comm_set_exchange": (C.c_int, [_P, _I]),
+    "f1p_argmin_gather_reduce_batch": (C.c_int, [_P, _P, _P, _I, _I, _P, _P]),
     "f1p_argmin_key_batch": (C.c_int, [_P, _P, _I, _P]),
     "f1p_argmin_mask_batch": (C.c_int, [_P, _P, _P, _P, _I, _P, _P]),
 }

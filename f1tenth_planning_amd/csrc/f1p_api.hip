@@ -213,6 +213,7 @@ typedef ncclResult_t (*pfn_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId, int
 typedef ncclResult_t (*pfn_ncclCommDestroy)(ncclComm_t);
 typedef ncclResult_t (*pfn_ncclCommCount)(const ncclComm_t, int*);
 typedef ncclResult_t (*pfn_ncclCommUserRank)(const ncclComm_t, int*);
+typedef ncclResult_t (*pfn_ncclAllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*pfn_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
 typedef const char* (*pfn_ncclGetErrorString)(ncclResult_t);
 
@@ -298,7 +299,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1], ctx->d_step};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1], ctx->d_step, ctx->d_comm_rec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1307,6 +1308,26 @@ int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E)
         F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_idx, sizeof(int32_t) * (size_t)E));
         ctx->comm_cap = E;
     }
+    if (ctx->comm_exchange == 1) {
+        // ONE collective: all-gather of the (key, index) records (16 B per ego and rank), then every rank takes the minimum itself.  Half
+        // the xGMI latency of the two dependent all-reduces below at the price of N x 16 B instead of 12 B per ego on the wire.
+        const int N = ctx->comm_nranks;
+        if (E > ctx->comm_rec_cap || N != ctx->comm_rec_ranks) {
+            F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_comm_rec) (void)hipFree(ctx->d_comm_rec);
+            ctx->d_comm_rec = nullptr; ctx->comm_rec_cap = 0;
+            F1P_HIP(ctx, hipMalloc((void**)&ctx->d_comm_rec, sizeof(uint64_t) * 2 * (size_t)E * (size_t)(N + 1)));
+            ctx->comm_rec_cap = E; ctx->comm_rec_ranks = N;
+        }
+        auto ag = rccl_sym<pfn_ncclAllGather>(ctx, "ncclAllGather");
+        if (!ag) return set_error(ctx, F1P_ECOMM, "ncclAllGather not found");
+        uint64_t* mine = ctx->d_comm_rec;
+        uint64_t* all = ctx->d_comm_rec + 2 * (size_t)ctx->comm_rec_cap;
+        int rc1 = launch_argmin_pack(ctx, d_cost, d_idx, mine, E); if (rc1) return rc1;
+        ncclResult_t r1 = ag(mine, all, 2 * (size_t)E, ncclUint64, (ncclComm_t)ctx->comm, ctx->stream);
+        if (r1 != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclAllGather(u64)", r1));
+        return launch_argmin_reduce(ctx, all, N, E, d_idx, d_cost);
+    }
     auto ar = rccl_sym<pfn_ncclAllReduce>(ctx, "ncclAllReduce");
     if (!ar) return set_error(ctx, F1P_ECOMM, "ncclAllReduce not found");
     uint64_t* own = ctx->d_comm_key;
@@ -1321,6 +1342,33 @@ int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E)
     r = ar(ctx->d_comm_idx, d_idx, (size_t)E, ncclInt32, ncclMin, (ncclComm_t)ctx->comm, ctx->stream);
     if (r != ncclSuccess) return set_error(ctx, F1P_ECOMM, rccl_err(ctx, "ncclAllReduce(min, i32)", r));
     return F1P_OK;
+}
+
+int f1p_comm_set_exchange(f1p_ctx* ctx, int32_t mode) {
+    if (!ctx) return F1P_EINVAL;
+    if (mode != 0 && mode != 1) return set_error(ctx, F1P_EINVAL, "mode must be 0 (two all-reduces) or 1 (one all-gather + local minimum)");
+    ctx->comm_exchange = mode;
+    return F1P_OK;
+}
+
+// the local kernels of the single-collective exchange on host arrays (the all-gather replaced by the caller): cost / idx [N][E] of N
+// emulated ranks -> idx_out [E], cost_out [E]
+int f1p_argmin_gather_reduce_batch(f1p_ctx* ctx, const double* cost, const int32_t* idx, int32_t N, int32_t E, int32_t* idx_out, double* cost_out) {
+    F1P_ENTER(ctx);
+    if (N < 1 || E < 0 || (E > 0 && (!cost || !idx || !idx_out || !cost_out))) return set_error(ctx, F1P_EINVAL, "bad argument");
+    const size_t n = (size_t)N * E;
+    Stage s(ctx);
+    s.need(8 * n); s.need(4 * n); s.need(16 * n); s.need(4 * (size_t)E); s.need(8 * (size_t)E);
+    int rc = s.begin(); if (rc) return rc;
+    const double* d_c; const int32_t* d_i;
+    if ((rc = s.in(cost, n, &d_c))) return rc;
+    if ((rc = s.in(idx, n, &d_i))) return rc;
+    uint64_t* d_rec = (uint64_t*)arena_take(ctx, 16 * n);
+    int32_t* d_io = s.out(idx_out, (size_t)E); double* d_co = s.out(cost_out, (size_t)E);
+    for (int r = 0; r < N; ++r)
+        if ((rc = launch_argmin_pack(ctx, d_c + (size_t)r * E, d_i + (size_t)r * E, d_rec + 2 * (size_t)r * E, E))) return rc;
+    if ((rc = launch_argmin_reduce(ctx, d_rec, N, E, d_io, d_co))) return rc;
+    return s.finish();
 }
 
 // the two local kernels of the exchange on host arrays (the collective replaced by the caller): lets a single-GPU box check

@@ -123,6 +123,9 @@ struct f1p_ctx {
     uint64_t* d_comm_key = nullptr;    // [2][comm_cap]: own keys | reduced keys of the argmin exchange
     int32_t* d_comm_idx = nullptr;
     int comm_cap = 0;
+    int comm_exchange = 0;             // 0: two all-reduces (min key, then min index among the holders); 1: one all-gather of (key, index) + a local reduction
+    uint64_t* d_comm_rec = nullptr;    // [1 + nranks][comm_rec_cap][2]: own records | every rank's records
+    int comm_rec_cap = 0, comm_rec_ranks = 0;
 };
 
 namespace f1p {
@@ -187,5 +190,7 @@ int launch_stmpc_ref(f1p_ctx* ctx, const double* d_states, int E, int horizon, d
 int launch_argmin_key(f1p_ctx* ctx, const double* d_cost, uint64_t* d_key, int E);
 int launch_argmin_mask(f1p_ctx* ctx, const uint64_t* d_own, const uint64_t* d_min, const int32_t* d_idx, int32_t* d_masked,
                        double* d_cost_out, int E);
+int launch_argmin_pack(f1p_ctx* ctx, const double* d_cost, const int32_t* d_idx, uint64_t* d_rec, int E);
+int launch_argmin_reduce(f1p_ctx* ctx, const uint64_t* d_recs, int N, int E, int32_t* d_idx_out, double* d_cost_out);
 
 }  // namespace f1p

@@ -684,9 +684,6 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
         __syncthreads();
     }
 
-#if defined(F1P_K4_ABLATE) && F1P_K4_ABLATE == 1
-    return;                                                           // timing experiment: the filter alone
-#endif
     // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
     if (!in_range) {
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
@@ -717,10 +714,6 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     }
     __syncthreads();
     const int n = cnt[0];
-#if defined(F1P_K4_ABLATE) && F1P_K4_ABLATE == 2
-    if (tid == 0) best_idx[e] = list[0];                              // timing experiment: no refinement, no re-emission
-    return;
-#endif
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
     } else if (n == 1 && !best_cost) {
@@ -875,6 +868,36 @@ __global__ void k_argmin_mask(const uint64_t* __restrict__ own, const uint64_t* 
     cost_out[e] = k == 0ull ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double((long long)b);
 }
 
+// The single-collective form of the exchange (f1p_comm_set_exchange 1): every rank contributes ONE record per ego, (key, index) as two
+// u64 words; after an all-gather every rank reduces the N records of an ego locally with the same (key, index) order -- np.argmin's
+// first minimum over the concatenation of the ranks' candidates, a NaN (key 0) first.
+__global__ void k_argmin_pack(const double* __restrict__ cost, const int32_t* __restrict__ idx, uint64_t* __restrict__ rec, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double c = cost[e];
+    uint64_t key;
+    if (c != c) key = 0ull;
+    else {
+        if (c == 0.0) c = 0.0;
+        const uint64_t b = (uint64_t)__double_as_longlong(c);
+        key = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    }
+    rec[2 * (size_t)e] = key;
+    rec[2 * (size_t)e + 1] = (uint64_t)(uint32_t)idx[e];
+}
+__global__ void k_argmin_reduce(const uint64_t* __restrict__ recs, int N, int E, int32_t* __restrict__ idx_out, double* __restrict__ cost_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint64_t bk = ~0ull, bi = ~0ull;
+    for (int r = 0; r < N; ++r) {
+        const uint64_t k = recs[((size_t)r * E + e) * 2], i = recs[((size_t)r * E + e) * 2 + 1];
+        if (k < bk || (k == bk && i < bi)) { bk = k; bi = i; }
+    }
+    idx_out[e] = (int32_t)(uint32_t)bi;
+    const uint64_t b = (bk >> 63) ? (bk & 0x7fffffffffffffffull) : ~bk;
+    cost_out[e] = bk == 0ull ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double((long long)b);
+}
+
 static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg);
 
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
@@ -1006,6 +1029,18 @@ int launch_argmin_key(f1p_ctx* ctx, const double* d_cost, uint64_t* d_key, int E
     if (E <= 0) return F1P_OK;
     hipLaunchKernelGGL(k_argmin_key, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_cost, d_key, E);
     return check_hip(ctx, hipGetLastError(), "k_argmin_key launch");
+}
+
+int launch_argmin_pack(f1p_ctx* ctx, const double* d_cost, const int32_t* d_idx, uint64_t* d_rec, int E) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_argmin_pack, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_cost, d_idx, d_rec, E);
+    return check_hip(ctx, hipGetLastError(), "k_argmin_pack launch");
+}
+
+int launch_argmin_reduce(f1p_ctx* ctx, const uint64_t* d_recs, int N, int E, int32_t* d_idx_out, double* d_cost_out) {
+    if (E <= 0) return F1P_OK;
+    hipLaunchKernelGGL(k_argmin_reduce, dim3((E + 255) / 256), dim3(256), 0, ctx->stream, d_recs, N, E, d_idx_out, d_cost_out);
+    return check_hip(ctx, hipGetLastError(), "k_argmin_reduce launch");
 }
 
 int launch_argmin_mask(f1p_ctx* ctx, const uint64_t* d_own, const uint64_t* d_min, const int32_t* d_idx, int32_t* d_masked,

@@ -1,0 +1,2233 @@
+// k_lattice_mixed.hip -- the mixed-precision schedule of the lattice planner (default from 320 egos): an f32 filter that knows its own
+// error decides what CANNOT win, the unchanged fp64 arithmetic decides among the rest; every output is bit-identical to k_lattice
+// (k_lattice.hip).  Kernels: k_lattice_prologue (fp64, wave per ego) -> k_lattice_filter3 (f32, thread per candidate) -> k_lattice_refine
+// (fp64, 16 lanes per queue entry) -> k_lattice_select (fp64, wave per ego); k_lattice_filter is the one-kernel fallback filter for host
+// goals, the every-station occupancy rule without a clearance map and the oriented footprint.  Replaces LatticePlanner.plan
+// (planning/lattice_planner/lattice_planner.py:174-214) together with k_lattice.hip; shared device code in lattice_device.h.
+#include "lattice_device.h"
+
+namespace f1p {
+
+// ===================================================================================================================
+// Mixed-precision schedule (f1p_lattice_set_mode(ctx, 1), the default from F1P_MIX_MIN_EGOS egos): an f32 FILTER over every
+// candidate-trajectory-step, the DECISION in fp64 -- the pattern of k_kmpc_shoot_mixed applied to the lattice planner.
+//
+//   k_lattice_filter  (workgroup per ego)   nearest segment, look-ahead centres, occupancy tile and goals exactly as k_lattice
+//       (fp64: they decide indices).  Then per candidate IN F32: G1 fit (16-node Gauss-Legendre with hardware sin / cos, degree-5
+//       Taylor model of the residual), all S stations (midpoint-frame series, hardware sin / cos of the midpoint heading), the
+//       occupancy test against the LDS tile, the cost.  Alongside the cost every candidate gets a STATE:
+//         FREE    no station within `edge` cells of a cell boundary, none occupied          -> certainly collision-free in fp64
+//         HIT     a station well inside an occupied cell                                     -> certainly +inf in fp64
+//         UNSURE  a station near a cell boundary / off the tile, or an f32 result that cannot be trusted (goal direction near
+//                 the +-pi seam of the fit's normalisation, phase excursion beyond the 16-node rule, model root outside its
+//                 trust radius, |kappa| ds beyond the one-piece series)                      -> only fp64 can tell
+//         BAD     no goal / degenerate goal (the fp64 tests themselves)                      -> certainly infeasible
+//       and the interval [lo, hi] = cost32 -+ margin that contains its fp64 cost.  With T = min hi over the FREE candidates (an
+//       upper bound of the ego's final minimum), a candidate needs fp64 only if it is FREE or UNSURE and lo <= T: typically the
+//       f32 winner plus the UNSURE candidates ranked above it.  Those (ego, candidate, goal) triples are appended to a global
+//       queue (one atomicAdd per ego).
+//   k_lattice_refine  (thread per queue entry, all lanes busy)   the UNCHANGED fp64 arithmetic of k_lattice for that candidate:
+//       g1_fit + station_loop + cost -- so every refined cost is bit-identical to the exhaustive kernel's.
+//   k_lattice_select  (wave per ego)   argmin over the ego's refined candidates (np.argmin rules), winner re-emission, tracking.
+//
+// Exactness: the final minimum is attained by a candidate whose fp64 cost is <= T, hence whose lo <= T (margin >= the f32 error,
+// measured by tests/test_gpu_lattice_mixed.py through the debug hook and sized ~20x above it), hence refined; every candidate
+// NOT refined has fp64 cost > the final minimum (or is +inf), so it loses to the refined winner under the (cost, index) order
+// as well.  When no candidate is FREE, T = +inf and every FREE / UNSURE candidate is refined; the shard's first candidate is
+// added so that "everything blocked" returns the exhaustive loop's answer (first candidate, +inf).  Outputs are bit-identical to
+// k_lattice (tests: all fuzz seeds, the 4096-ego bench batch, collisions, similarity term, NaN inputs, host goals, shards).
+// ===================================================================================================================
+#ifndef F1P_MIX_MIN_EGOS
+#define F1P_MIX_MIN_EGOS 320   // measured crossover (tools/time_modes_vs_egos.py, round 3): 1 ego 0.0397 (all fp64) / 0.0398 (mixed), 64: 0.048 / 0.054, 256: 0.0502 / 0.0507, 512: 0.064 / 0.053, 1024: 0.077 / 0.060, 2048: 0.132 / 0.073 ms (round 2: 512)
+#endif
+// filter tolerances (calibrated by tests/test_gpu_lattice_mixed.py through the debug hook):
+#ifndef F1P_MIX_MARGIN_REL
+#define F1P_MIX_MARGIN_REL 3.0e-5f   // relative to the sum of the absolute cost terms (measured f32 error: <= 1.0e-6 over 4e6 candidates)
+#endif
+#ifndef F1P_MIX_MARGIN_ABS
+#define F1P_MIX_MARGIN_ABS 1.0e-6f
+#endif
+#ifndef F1P_MIX_MACRO
+#define F1P_MIX_MACRO 1            // station_loop_f2: one integrated piece between two tested stations (see there); 0 = one piece per interval
+#endif
+#ifndef F1P_MIX_INC_PER_EGO
+#define F1P_MIX_INC_PER_EGO 4       // increment blocks (k_lattice_refine -> k_lattice_select) per ego and shard; 0 = the selection re-evaluates its winner
+#endif
+#ifndef F1P_MIX_EXC_MAX
+#define F1P_MIX_EXC_MAX 20.0f        // phase excursion |A| + |delta - A| [rad] up to which the 16-node rule is f32-exact (measured)
+#endif
+#ifndef F1P_MIX_LOOKAHEAD_PAIRS
+#define F1P_MIX_LOOKAHEAD_PAIRS 1    // look-ahead centres by wave_lookahead_centres (one pass of exact hit tests per wave) instead of one scan per radius
+#endif
+#ifndef F1P_MIX_FILTER_BLOCK
+#define F1P_MIX_FILTER_BLOCK 256     // threads per ego in the filter kernel (a multiple of 64)
+#endif
+#ifndef F1P_MIX_FILTER_WAVES
+#define F1P_MIX_FILTER_WAVES 8       // waves per SIMD the filter kernel's register allocation is held to (64 VGPRs: 8 workgroups per CU = two full rounds at 4096 egos; measured 125 -> 120 us against 4)
+#endif
+#ifndef F1P_MIX_FIT_UNROLL
+#define F1P_MIX_FIT_UNROLL 2
+#endif
+#ifndef F1P_MIX_FILTER_V3
+#define F1P_MIX_FILTER_V3 1          // prologue + candidate kernel (k_lattice_prologue, k_lattice_filter3) where it applies; 0: the one-kernel k_lattice_filter everywhere (A/B builds)
+#endif
+#ifndef F1P_MIX_F3_EGOS_PER_WG
+#define F1P_MIX_F3_EGOS_PER_WG 1     // egos a k_lattice_filter3 workgroup evaluates one after the other (grid = egos / this)
+#endif
+#ifndef F1P_PIPE_CHUNKS
+#define F1P_PIPE_CHUNKS 1            // chunks of egos a pipelined plan is cut into by default (f1p_lattice_set_pipeline overrides).  Measured at 4096
+                                     // egos (tools/time_pipeline.py): 1 chunk 0.108 ms, 2 chunks 0.130, 4 chunks 0.170 -- the candidate kernel fills every
+                                     // wave slot of the chip, so the other chunk's kernels cannot co-reside, and each cross-stream edge costs ~10 us
+#endif
+#ifndef F1P_PIPE_MIN_EGOS
+#define F1P_PIPE_MIN_EGOS 2048       // batches from this size are pipelined
+#endif
+#ifndef F1P_MIX_EDGE0
+#define F1P_MIX_EDGE0 2.0e-4f        // cells: rounding of the f32 cell transform (tile-relative coordinates up to ~300)
+#endif
+#ifndef F1P_MIX_EDGE1
+#define F1P_MIX_EDGE1 8.0e-6f        // metres of f32 position error per metre of arc length (measured: <= 0.8e-6, tools/mixed_endpoint_error.py)
+#endif
+#ifndef F1P_MIX_QSHARDS
+#define F1P_MIX_QSHARDS 8    // measured (4096 egos): 1 shard filter 87 us / refine 25 us; 8: 73 / 25; 16: 73 / 26; 32: 73 / 30; 64: 73 / 39 (refinement groups spread over too many half-empty workgroups)
+#endif
+#define F1P_ST_FREE 0
+#define F1P_ST_HIT 1
+#define F1P_ST_UNSURE 2
+#define F1P_ST_BAD 3
+#define F1P_INV_2PI_F 0.15915494309189535f
+
+__constant__ float c_gl16_xf[16] = {5.299532504e-03f, 2.771248846e-02f, 6.718439881e-02f, 1.222977958e-01f, 1.910618778e-01f, 2.709916112e-01f, 3.591982246e-01f, 4.524937451e-01f, 5.475062549e-01f, 6.408017754e-01f, 7.290083888e-01f, 8.089381222e-01f, 8.777022042e-01f, 9.328156012e-01f, 9.722875115e-01f, 9.947004675e-01f};
+__constant__ float c_gl16_wuf[16][6] = {
+    {1.357622971e-02f, -7.156638159e-05f, 3.772584204e-07f, -1.988697942e-09f, 1.048331671e-11f, -5.526225325e-14f},
+    {3.112676197e-02f, -8.386952385e-04f, 2.259822926e-05f, -6.088981340e-07f, 1.640645970e-08f, -4.420639591e-10f},
+    {4.757925584e-02f, -2.981823145e-03f, 1.868728107e-04f, -1.171144152e-05f, 7.339637150e-07f, -4.599798703e-08f},
+    {6.231448563e-02f, -6.688902003e-03f, 7.179937307e-04f, -7.707019733e-05f, 8.272795516e-06f, -8.880105154e-07f},
+    {7.479799441e-02f, -1.156057132e-02f, 1.786769958e-03f, -2.761582272e-04f, 4.268225247e-05f, -6.596850996e-06f},
+    {8.457825970e-02f, -1.670887144e-02f, 3.300923736e-03f, -6.521145096e-04f, 1.288285849e-04f, -2.545075142e-05f},
+    {9.130170752e-02f, -2.101535775e-02f, 4.837207029e-03f, -1.113403451e-03f, 2.562774835e-04f, -5.898863390e-05f},
+    {9.472530523e-02f, -2.346754605e-02f, 5.813923915e-03f, -1.440359858e-03f, 3.568392966e-04f, -8.840449344e-05f},
+    {9.472530523e-02f, -2.346754605e-02f, 5.813923915e-03f, -1.440359858e-03f, 3.568392966e-04f, -8.840449344e-05f},
+    {9.130170752e-02f, -2.101535775e-02f, 4.837207029e-03f, -1.113403451e-03f, 2.562774835e-04f, -5.898863390e-05f},
+    {8.457825970e-02f, -1.670887144e-02f, 3.300923736e-03f, -6.521145096e-04f, 1.288285849e-04f, -2.545075142e-05f},
+    {7.479799441e-02f, -1.156057132e-02f, 1.786769958e-03f, -2.761582272e-04f, 4.268225247e-05f, -6.596850996e-06f},
+    {6.231448563e-02f, -6.688902003e-03f, 7.179937307e-04f, -7.707019733e-05f, 8.272795516e-06f, -8.880105154e-07f},
+    {4.757925584e-02f, -2.981823145e-03f, 1.868728107e-04f, -1.171144152e-05f, 7.339637150e-07f, -4.599798703e-08f},
+    {3.112676197e-02f, -8.386952385e-04f, 2.259822926e-05f, -6.088981340e-07f, 1.640645970e-08f, -4.420639591e-10f},
+    {1.357622971e-02f, -7.156638159e-05f, 3.772584204e-07f, -1.988697942e-09f, 1.048331671e-11f, -5.526225325e-14f}};
+
+struct RefEntry {                 // one fp64 re-evaluation: written by k_lattice_filter, completed by k_lattice_refine
+    int32_t e, c;
+    double gx, gy, gth;           // the candidate's goal in the ego frame (fp64, from candidate_goal)
+    double cost, k0, dk, L;       // results
+    int32_t ok, pad;
+};
+
+struct EgoXform { double txx, txy, tx0, tyx, tyy, ty0; int tile_gx0, tile_gy0; };
+
+struct MixArgs {
+    // The refinement queue is SHARDED: ego e appends to shard e % F1P_MIX_QSHARDS, whose counter is qcount[shard * 32] (128 B
+    // apart) and whose entries are q[shard * q_shard_cap ...).  One counter for the whole batch had every workgroup's returning
+    // atomicAdd on ONE word: a word takes ~88 atomics / us (MI355X_MICROARCH.md "dequeue"), i.e. 46 us of serialised atomics for
+    // 4096 egos -- measured 37 us of a 63 us prologue-only filter (tools/pmc_ablate.sh, ablation 15 against 31).
+    unsigned int* qcount;         // [F1P_MIX_QSHARDS * 32] entries appended so far per shard (zero before the filter kernel)
+    unsigned int q_shard_cap;     // entries a shard can hold: ceil(E / shards) * candidates per ego
+    double* inc;                  // [shards][inc_cap][2][S] station positions (x | y) of the refined entries (k_lattice_refine -> k_lattice_select), or null
+    unsigned int inc_cap;         // entries per shard that have an increment block (the first inc_cap of each shard; later ones are re-evaluated by the selection)
+    RefEntry* q;
+    int32_t* ego_base;            // [E] first entry of the ego
+    int32_t* ego_n;               // [E] number of entries
+    int32_t* ego_ni;              // [E] nearest raceline segment
+    struct EgoXform* xf;          // [E] ego -> tile-relative cell transform (fp64; written by the filter's setup thread, read by k_lattice_refine)
+    const uint32_t* clear_bits;   // clearance map of the collision bitmap (k_grid.hip ensure_clear_map) when clear_r > 0
+    int clear_r;                  // a tested station in a clear cell proves clear_r stations on each side free (0: every station against the bitmap)
+    float clear_ds_cap;           // ... for candidates whose station spacing is <= this [m]
+    int n_disc;                   // oriented footprint under the mixed schedule (clearance mode only): discs along the heading, 0 = station point
+    double disc_off[4];           // their longitudinal offsets [m] (f1p_set_footprint)
+    double sim_s2, sim_s3, sim_s4; // sum_{j < sim_m} j^2, j^3, j^4 (exact integers; host): the candidate side of the closed-form similarity term
+    float margin_rel, margin_abs; // |cost64 - cost32| <= margin_rel * (sum of |terms|) + margin_abs
+    float edge0, edge1;           // a station is "near a cell boundary" within edge0 + edge1 * L cells
+    float* dbg_bound;             // [E][C] test hook (nullable): the candidate's a-priori cost error bound (filter3)
+    float* dbg_cost32;            // [E][C] test hook (nullable)
+    int32_t* dbg_state;           // [E][C] test hook (nullable)
+};
+
+// ek0 / edk / eLrel: a-priori bounds of |k0 - k0_64|, |dk - dk_64| and |L - L_64| / L for THIS candidate
+struct Fit32 { float k0, dk, L; bool ok; int why; float ek0, edk, eLrel; };
+
+// Clothoid.G1Hermite(0,0,0,x,y,theta) in f32: the structure of g1_fit (published guess, one quadrature pass, degree-5 Taylor
+// model) with 16 nodes and the hardware sin / cos (v_sin_f32 / v_cos_f32 take revolutions).  ok = false: do not trust it.
+__device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
+    Fit32 f;
+    f.k0 = 0.f; f.dk = 0.f; f.L = 0.f; f.ok = false; f.why = 40; f.ek0 = 0.f; f.edk = 0.f; f.eLrel = 0.f;
+    const float r = __builtin_sqrtf(x1 * x1 + y1 * y1);
+    if (!(r > 1e-6f) || !(r < 1e6f)) return f;
+    const float phi = atan2f(y1, x1);
+    const float PI_F = 3.14159265358979f;
+    const float phi0 = -phi;                                                  // |phi| <= pi already
+    float phi1 = th1 - phi;
+    phi1 = phi1 - 2.0f * PI_F * __builtin_rintf(phi1 * F1P_INV_2PI_F);
+    // near the +-pi seam of either angle the fp64 normalisation may land on the other side: a different curve altogether
+    f.why = 41;
+    if (!(fabsf(phi0) < PI_F - 2e-3f) || !(fabsf(phi1) < PI_F - 2e-3f)) return f;
+    const float delta = phi1 - phi0;
+    const float X = phi0 * (1.0f / PI_F), Y = phi1 * (1.0f / PI_F);
+    const float xy = X * Y, X2 = X * X, Y2 = Y * Y;
+    const float A0 = (phi0 + phi1) * (2.989696028701907f + xy * (0.716228953608281f + xy * -0.458969738821509f) +
+                                      (-0.502821153340377f + xy * 0.261062141752652f) * (X2 + Y2) + -0.045854475238709f * (X2 * X2 + Y2 * Y2));
+    f.why = 42;
+    if (!(fabsf(A0) + fabsf(delta - A0) <= F1P_MIX_EXC_MAX)) return f;       // beyond what 16 nodes integrate to f32 accuracy (also NaN)
+    const float ar = A0 * F1P_INV_2PI_F, br = (delta - A0) * F1P_INV_2PI_F, cr = phi0 * F1P_INV_2PI_F;   // phase in revolutions
+    float mc[6], ms[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
+#pragma unroll F1P_MIX_FIT_UNROLL
+    for (int j = 0; j < 16; ++j) {
+        const float tau = c_gl16_xf[j];
+        const float ph = __builtin_fmaf(__builtin_fmaf(ar, tau, br), tau, cr);
+        const float sn = __builtin_amdgcn_sinf(ph), cs = __builtin_amdgcn_cosf(ph);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            mc[k] = __builtin_fmaf(c_gl16_wuf[j][k], cs, mc[k]);
+            ms[k] = __builtin_fmaf(c_gl16_wuf[j][k], sn, ms[k]);
+        }
+    }
+    const float g0 = ms[0], g1 = mc[1], g2 = -0.5f * ms[2], g3 = mc[3] * (-1.0f / 6.0f), g4 = ms[4] * (1.0f / 24.0f), g5 = mc[5] * (1.0f / 120.0f);
+    f.why = 43;
+    if (!(fabsf(g1) > 1e-4f)) return f;
+    float d = -g0 * __builtin_amdgcn_rcpf(g1);                                  // 1-ulp reciprocals: the filter's error budget is the margin
+    float dv_last = g1;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const float pv = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, g5, g4), g3), g2), g1), g0);
+        const float dv = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, 5.0f * g5, 4.0f * g4), 3.0f * g3), 2.0f * g2), g1);
+        d -= pv * __builtin_amdgcn_rcpf(dv);
+        dv_last = dv;
+    }
+    f.why = 44;
+    if (!(fabsf(d) <= 0.3f)) return f;                                         // the degree-5 model's remainder is < 1e-10 there: |g^(6)| / 6! <= 1.2e-7
+    const float A = A0 + d;
+    const float q5 = ms[5] * (-1.0f / 120.0f), q4 = mc[4] * (1.0f / 24.0f), q3 = ms[3] * (1.0f / 6.0f), q2 = -0.5f * mc[2], q1 = -ms[1];
+    const float c0 = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, q5, q4), q3), q2), q1), mc[0]);
+    f.why = 45;
+    if (!(c0 > 0.05f)) return f;                                               // L = r / c0 ill-conditioned or negative: fp64 decides
+    const float L = r * __builtin_amdgcn_rcpf(c0), iL = c0 * __builtin_amdgcn_rcpf(r);
+    f.L = L; f.k0 = (delta - A) * iL; f.dk = 2.0f * A * (iL * iL); f.ok = true;
+    // ---- a-priori error of THIS fit against the fp64 fit of the same goal (u = 2^-24 = 6e-8) ----------------------------
+    //   node phase [rev]: coefficient and fma roundings <= 4 u P / 2 pi with P = |A0| + |delta - A0| + |phi0| [rad]; v_sin / v_cos: 2.1 u
+    //   absolute (EXHAUSTIVE over |x| <= 8 rev, profiles/r03_hw_f32_primitive_errors.txt)  =>  each node value within (2.1 + 4 P) u;
+    //   a moment = sum_j (w u^k)_j {cos, sin}_j with sum_j |w u^k| <= 1, 16 fma roundings        =>  e_m <= (18.1 + 4 P) u  (24 + 4 P used)
+    //   residual model at d: Horner + remainder (< 1e-10 for |d| <= 0.3), sum_k |d|^k <= 1.43       =>  e_g <= 1.6 e_m
+    //   root: |dA| <= e_g / |g'(d)| + input rounding;  c0: |d c0 / dA| <= int |tau^2 - tau| = 1/6       =>  e_c0 <= e_g + e_A / 6
+    //   L = r / c0, k0 = (delta - A) / L, dk = 2 A / L^2: first-order propagation, reciprocal 1.53 u
+    const float U = 6.0e-8f;
+    const float Pm = fabsf(A0) + fabsf(delta - A0) + fabsf(phi0);
+    const float e_m = (24.0f + 4.0f * Pm) * U, e_g = 1.6f * e_m;
+    const float e_A = e_g * __builtin_amdgcn_rcpf(fabsf(dv_last)) + 4.0f * U * (fabsf(A) + fabsf(delta) + Pm);   // + the rounding of phi0, phi1, delta themselves
+    const float e_c0 = e_g + e_A * (1.0f / 6.0f);
+    f.eLrel = e_c0 * __builtin_amdgcn_rcpf(c0) + 4.0f * U;
+    f.ek0 = iL * (e_A + 4.0f * U * (fabsf(delta) + fabsf(A))) + fabsf(f.k0) * f.eLrel;
+    f.edk = 2.0f * (iL * iL) * e_A + fabsf(f.dk) * (2.0f * f.eLrel + 4.0f * U);
+    return f;
+}
+
+// workgroup-uniform f32 parameters of the filter's station loop (LDS)
+struct EgoParams32 {
+    float txx, txy, tx0, tyx, tyy, ty0;
+    float w_len, w_maxk, w_meank, w_sim;
+    float margin_rel, margin_abs, edge0, edge1;
+    const double* prev;
+    int tile_w, tile_h, tile_words, S, den, sim_m, n_shift, collide;
+    int clear_r;                  // > 0: the LDS tile holds the CLEARANCE map (MixArgs::clear_bits)
+    float clear_ds_cap;
+    int n_disc;                   // oriented footprint: disc centres (x, y) + o_d (cos theta, sin theta) are tested instead of the station point
+    float disc_off[4], disc_omax;
+};
+
+struct Filt32 { float cost, lo, hi; int state; float xe, ye; float ebound; };
+
+__device__ __forceinline__ int cvt_i32_sat_f32(float v) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// all S stations of one clothoid in f32: rows of sample_traj, occupancy against the LDS tile, cost terms
+__device__ __forceinline__ Filt32 station_loop_f32(const Fit32& f, const F1P_LDS(EgoParams32)* ep, const F1P_LDS(uint32_t)* tile) {
+    Filt32 o;
+    // workgroup-uniform integers through readfirstlane: an LDS read lands in a VGPR, and a loop counter compared against a VGPR
+    // bound becomes vector code (v_add / v_cmp per station) under the 64-VGPR budget of this kernel
+    const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m), n_shift = __builtin_amdgcn_readfirstlane(ep->n_shift);
+    const int tile_w = __builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = __builtin_amdgcn_readfirstlane(ep->tile_h), tile_words = __builtin_amdgcn_readfirstlane(ep->tile_words);
+    const bool collide = __builtin_amdgcn_readfirstlane(ep->collide) != 0;
+    const double* prev = ep->prev;
+    const float k0 = f.k0, dk = f.dk, L = f.L;
+    const float ds = L * __builtin_amdgcn_rcpf((float)ep->den), h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;                                       // quadratic phase coefficient of a piece on [-1, 1]
+    const float kend = __builtin_fmaf(dk, L, k0);
+    const float kmax = fmaxf(fabsf(k0), fabsf(kend));
+    const bool untrusted = !(kmax * h <= 0.4f) || !(fabsf(b) <= 0.05f);      // the one-piece series needs a small phase excursion: outside it the positions decide NOTHING
+    bool unsure = untrusted;
+    const float k0r = k0 * F1P_INV_2PI_F, hdkr = 0.5f * dk * F1P_INV_2PI_F;
+    const float edge = __builtin_fmaf(ep->edge1, L, ep->edge0), edge_hi = 1.0f - edge;
+    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
+    const float b2 = b * b, q0 = 2.0f * b;
+    float x = 0.f, y = 0.f, sim = 0.f;
+    uint32_t hit = 0u;                                                       // occupied-cell bits of the stations away from every cell edge
+    for (int i = 0; i < S; ++i) {
+        const float s = (float)i * ds;
+        if (prev && i < sim_m) {
+            const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
+            const float dd = th - (float)prev[i + n_shift];
+            sim = __builtin_fmaf(dd, dd, sim);
+        }
+        if (collide) {
+            const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0));
+            const float lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
+            const float fx = __builtin_floorf(lxf), fy = __builtin_floorf(lyf);
+            const float rx = lxf - fx, ry = lyf - fy;
+            const bool near = (rx < edge) | (rx > edge_hi) | (ry < edge) | (ry > edge_hi);
+            const int lx = cvt_i32_sat_f32(fx), ly = cvt_i32_sat_f32(fy);     // saturating: huge values land outside the tile (NaN: after the loop)
+            const bool inside = ((unsigned)lx < (unsigned)tile_w) & ((unsigned)ly < (unsigned)tile_h);
+            uint32_t occ = 0u;
+            if (inside) {                                                      // byte address in three instructions; v_bfe_u32 masks its offset to 5 bits itself
+                const unsigned addr = __umul24((unsigned)ly, (unsigned)tile_words * 4u) + (((unsigned)lx >> 3) & ~3u);
+                occ = __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(reinterpret_cast<const F1P_LDS(unsigned char)*>(tile) + addr), (unsigned)lx, 1u);
+            }
+            unsure |= near | !inside;                                          // off the tile: the fp64 path reads the global bitmap
+            hit |= near ? 0u : occ;
+        }
+        if (i + 1 < S) {
+            const float sm = s + h;
+            const float a = __builtin_fmaf(dk, sm, k0) * h;
+            const float thr = sm * __builtin_fmaf(hdkr, sm, k0r);              // midpoint heading in revolutions
+            const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
+            const float z = a * a;
+            // int_{-1}^{1} cos / sin (a t + b t^2) dt = P, Q:  P = 2 (1 - z/6 + z^2/120 - b^2/10),  Q = 2 b (1/3 - z/10)
+            const float P = __builtin_fmaf(z, __builtin_fmaf(z, (1.0f / 60.0f), (-1.0f / 3.0f)), __builtin_fmaf(b2, -0.2f, 2.0f));
+            const float Q = q0 * __builtin_fmaf(z, -0.1f, (1.0f / 3.0f));
+            x = __builtin_fmaf(h, __builtin_fmaf(cs, P, -(sn * Q)), x);
+            y = __builtin_fmaf(h, __builtin_fmaf(sn, P, cs * Q), y);
+        }
+    }
+    bool hit_sure = hit != 0u && !untrusted;                                   // (a HIT claimed from untrusted positions pruned free candidates: fuzz seed 378, 2 stations)
+    if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }            // a NaN anywhere in the rows is sticky in x / y: nothing was decided
+    // sum_i |k0 + g i|, g = dk ds, in closed form: kappa is linear in the station index, so the sum splits into at most two
+    // arithmetic series at the sign change (a station within rounding of kappa = 0 on the wrong side changes the sum by < 2 |kappa_i|)
+    float sumk;
+    {
+        const float g = dk * ds, fS = (float)S, kl = __builtin_fmaf(g, fS - 1.0f, k0);
+        if (!(k0 * kl < 0.0f)) {
+            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
+        } else {
+            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));      // last station on kappa_0's side of zero
+            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
+            const float n1 = is + 1.0f, n2 = fS - n1;
+            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
+        }
+    }
+    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (float)(S - 1) * ds, k0)));
+    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * __builtin_amdgcn_rcpf((float)S)), t4 = ep->w_sim * sim;
+    o.cost = ((t1 + t2) + t3) + t4;
+    const float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
+    o.lo = o.cost - m; o.hi = o.cost + m;
+    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+    o.xe = x; o.ye = y;
+    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
+    return o;
+}
+
+// The same with the CLEARANCE map: `tile` (LDS offset 0) holds, per cell, "the centre of an occupied or off-map cell
+// lies within R ds_cap + (sqrt 2 + 1) cells of this cell's centre"; the real bitmap's tile follows at byte offset `occ_off`.
+// Only stations R, 3R + 1, 5R + 2, ... (and one in the tail) are looked up.  A clear cell proves the R stations before and
+// after it free in fp64: they are within R ds <= R ds_cap of the tested one along the curve, and the + 1 cell absorbs the f32
+// position error of the tested station (<< 1 cell), so no boundary band is needed.  A tested station in a cell that is not clear
+// is looked up in the real bitmap: occupied and away from every cell edge -> HIT (a station of the candidate itself), anything
+// else -> UNSURE, and fp64 decides on the real bitmap.  The loop is unrolled by the group of 2R + 1 stations: one branch per
+// group, no per-station bookkeeping.
+template <int R, bool FOOT>
+__device__ __forceinline__ Filt32 station_loop_f32_clear(const Fit32& f, const F1P_LDS(EgoParams32)* ep, const F1P_LDS(uint32_t)* tile, unsigned occ_off) {
+    Filt32 o;
+    const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m), n_shift = __builtin_amdgcn_readfirstlane(ep->n_shift);
+    const int tile_w = __builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = __builtin_amdgcn_readfirstlane(ep->tile_h), tile_words = __builtin_amdgcn_readfirstlane(ep->tile_words);
+    const double* prev = ep->prev;
+    const float k0 = f.k0, dk = f.dk, L = f.L;
+    const float ds = L * __builtin_amdgcn_rcpf((float)ep->den), h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;
+    const float kend = __builtin_fmaf(dk, L, k0);
+    const float kmax = fmaxf(fabsf(k0), fabsf(kend));
+    const bool untrusted = !(kmax * h <= 0.4f) || !(fabsf(b) <= 0.05f);      // outside the one-piece series' range the positions decide nothing
+    // oriented footprint: the tested points are the disc centres (x, y) + o_d (cos theta, sin theta).  Between stations a centre
+    // moves by at most ds (1 + |o_d| kappa_max) -- the station's own step plus the rotation of the offset -- so that is the spacing
+    // the clearance map has to cover
+    const int nd = FOOT ? __builtin_amdgcn_readfirstlane(ep->n_disc) : 0;
+    const float ds_eff = nd > 0 ? ds * __builtin_fmaf(ep->disc_omax, kmax, 1.0f) : ds;
+    bool unsure = untrusted || !(ds_eff <= ep->clear_ds_cap);                // ... and the spacing the map was built for (NaN: unsure)
+    const float k0r = k0 * F1P_INV_2PI_F, hdkr = 0.5f * dk * F1P_INV_2PI_F;
+    const float edge = __builtin_fmaf(ep->edge1, L, ep->edge0), edge_hi = 1.0f - edge;
+    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
+    const float b2 = b * b, q0 = 2.0f * b;
+    float x = 0.f, y = 0.f, sim = 0.f;
+    uint32_t flags = 0u;                                                     // bit 0: a tested station decided nothing; bit 1: a tested station is inside an occupied cell
+    auto step = [&](int i, float sm) {                                       // station i -> i + 1 through the midpoint arc length sm (and station i's similarity term)
+        if (prev && i < sim_m) {
+            const float s = (float)i * ds;
+            const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
+            const float dd = th - (float)prev[i + n_shift];
+            sim = __builtin_fmaf(dd, dd, sim);
+        }
+        const float a = __builtin_fmaf(dk, sm, k0) * h;
+        const float thr = sm * __builtin_fmaf(hdkr, sm, k0r);
+        const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
+        const float z = a * a;
+        const float P = __builtin_fmaf(z, __builtin_fmaf(z, (1.0f / 60.0f), (-1.0f / 3.0f)), __builtin_fmaf(b2, -0.2f, 2.0f));
+        const float Q = q0 * __builtin_fmaf(z, -0.1f, (1.0f / 3.0f));
+        x = __builtin_fmaf(h, __builtin_fmaf(cs, P, -(sn * Q)), x);
+        y = __builtin_fmaf(h, __builtin_fmaf(sn, P, cs * Q), y);
+    };
+    // An ego that itself stands in a cell that is not clear (next to a wall, or inside one) would leave every candidate undecided:
+    // its workgroup tests every station against the real bitmap instead (workgroup-uniform, so no divergence) -- the plain loop's rule.
+    bool exact_all;
+    {
+        uint32_t c = 0u;
+        for (int d = 0; d < (nd > 0 ? nd : 1); ++d) {                        // station 0: heading 0, the centres sit at (o_d, 0) in the ego frame
+            const float o = nd > 0 ? ep->disc_off[d] : 0.0f;
+            const int lx0 = cvt_i32_sat_f32(__builtin_floorf(__builtin_fmaf(txx, o, tx0))), ly0 = cvt_i32_sat_f32(__builtin_floorf(__builtin_fmaf(tyx, o, ty0)));
+            uint32_t cd = 1u;
+            if (((unsigned)lx0 < (unsigned)tile_w) & ((unsigned)ly0 < (unsigned)tile_h)) cd = (tile[ly0 * tile_words + (lx0 >> 5)] >> (lx0 & 31)) & 1u;
+            c |= cd;
+        }
+        exact_all = __builtin_amdgcn_readfirstlane((int)c) != 0;
+    }
+    auto test_point = [&](float qx, float qy) {                              // one point of the station
+        const float lxf = __builtin_fmaf(txx, qx, __builtin_fmaf(txy, qy, tx0));
+        const float lyf = __builtin_fmaf(tyx, qx, __builtin_fmaf(tyy, qy, ty0));
+        const float fx = __builtin_floorf(lxf), fy = __builtin_floorf(lyf);
+        const int lx = cvt_i32_sat_f32(fx), ly = cvt_i32_sat_f32(fy);
+        const bool inside = ((unsigned)lx < (unsigned)tile_w) & ((unsigned)ly < (unsigned)tile_h);
+        uint32_t fl = 1u;                                                     // off the tile: undecided
+        if (inside) {
+            const unsigned addr = __umul24((unsigned)ly, (unsigned)tile_words * 4u) + (((unsigned)lx >> 3) & ~3u);
+            const F1P_LDS(unsigned char)* base = reinterpret_cast<const F1P_LDS(unsigned char)*>(tile);
+            fl = exact_all ? 1u : __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(base + addr), (unsigned)lx, 1u);
+            if (fl) {                                                         // not clear (rare), or every station is tested: the real bitmap, with the boundary band
+                const uint32_t occ = __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(base + addr + occ_off), (unsigned)lx, 1u);
+                const float rx = lxf - fx, ry = lyf - fy;
+                const bool near = (rx < edge) | (rx > edge_hi) | (ry < edge) | (ry > edge_hi);
+                // the station itself is decided unless it is near a cell edge; its neighbours only when every station is tested
+                fl = ((!exact_all | near) ? 1u : 0u) | ((occ && !near) ? 2u : 0u);
+            }
+        }
+        flags |= fl;
+    };
+    auto test = [&](int i) {                                                 // station i at (x, y)
+        if (nd == 0) { test_point(x, y); return; }
+        const float s = (float)i * ds;
+        const float thr = s * __builtin_fmaf(hdkr, s, k0r);                  // heading in revolutions
+        const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
+        for (int d = 0; d < nd; ++d) {
+            const float o = ep->disc_off[d];
+            test_point(__builtin_fmaf(o, cs, x), __builtin_fmaf(o, sn, y));
+        }
+    };
+    constexpr int G = 2 * R + 1;
+    int base = 0;
+    float fb = 0.0f;                                                         // (float)base, kept as a float counter
+    for (; base + G < S; base += G, fb += (float)G) {                        // whole groups with a station after them: unconditional steps
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (exact_all || j == R) test(base + j);
+            step(base + j, __builtin_fmaf(fb, ds, ((float)j + 0.5f) * ds));  // midpoint of interval base + j: one fma (the offsets are loop constants)
+        }
+    }
+    {                                                                        // tail of <= G stations: one test covers it
+        const int t = base + R < S - 1 ? base + R : S - 1;
+        for (int i = base; i < S; ++i) {
+            if (exact_all || i == t) test(i);
+            if (i + 1 < S) step(i, __builtin_fmaf((float)i, ds, h));
+            else if (prev && i < sim_m) {                                     // the last station's similarity term
+                const float s = (float)i * ds;
+                const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
+                const float dd = th - (float)prev[i + n_shift];
+                sim = __builtin_fmaf(dd, dd, sim);
+            }
+        }
+    }
+    bool hit_sure = (flags & 2u) != 0u && !untrusted;
+    unsure |= (flags & 1u) != 0u;
+    if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }
+    float sumk;
+    {
+        const float g = dk * ds, fS = (float)S, kl = __builtin_fmaf(g, fS - 1.0f, k0);
+        if (!(k0 * kl < 0.0f)) {
+            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
+        } else {
+            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));
+            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
+            const float n1 = is + 1.0f, n2 = fS - n1;
+            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
+        }
+    }
+    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (float)(S - 1) * ds, k0)));
+    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * __builtin_amdgcn_rcpf((float)S)), t4 = ep->w_sim * sim;
+    o.cost = ((t1 + t2) + t3) + t4;
+    const float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
+    o.lo = o.cost - m; o.hi = o.cost + m;
+    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+    o.xe = x; o.ye = y;
+    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
+    return o;
+}
+
+// intersect_point's scan (utils/utils.py:84-149, wave_intersect) with whole 64-segment chunks skipped when the circle cannot reach them:
+// `box` is nearest_scan_boxed's table (bounding box of the waypoints of rows 64c .. 64c + 64).  A segment can only be hit if the
+// point is within `radius` of it; a chunk whose box is farther than radius + 1e-4 m (orders above the rounding of the reference's
+// quadratic and its 1e-6 end-point shift; chunks with non-finite boxes are never skipped) holds no hit.  The surviving chunks are
+// tested in the reference's order with its own arithmetic (seg_hit), so the result is wave_intersect's, bit for bit.
+__device__ __forceinline__ Intersect wave_intersect_boxed(double px, double py, double radius, const double* __restrict__ wx, const double* __restrict__ wy,
+                                                          const double* __restrict__ box, int n, double tstart) {
+    const int lane = threadIdx.x & 63;
+    const int start_i = (int)tstart;
+    const double start_t = tstart - __builtin_trunc(tstart);
+    Intersect r;
+    r.found = false; r.i = 0; r.t = 0.0; r.x = 0.0; r.y = 0.0;
+    const int nseg = n - 1, nchunk = (nseg + 63) >> 6;
+    if (!box || nchunk > 64 || start_i < 0 || start_i > nseg) return wave_intersect(px, py, radius, wx, wy, n, tstart, true);
+    bool keep = false;
+    if (lane < nchunk) {
+        const double xmin = box[4 * lane], xmax = box[4 * lane + 1], ymin = box[4 * lane + 2], ymax = box[4 * lane + 3];
+        const double dx = __builtin_fmax(__builtin_fmax(xmin - px, px - xmax), 0.0);
+        const double dy = __builtin_fmax(__builtin_fmax(ymin - py, py - ymax), 0.0);
+        const double reach = radius + 1e-4 + 4e-6 * radius;
+        keep = !(dx * dx + dy * dy > reach * reach);       // NaN anywhere keeps the chunk
+    }
+    const unsigned long long kept = __ballot(keep);
+    const int c_start = start_i >> 6;
+    // pass 1: segments start_i .. n-2 (:84)
+    for (unsigned long long m = c_start < 64 ? (kept >> c_start) << c_start : 0ull; m; m &= m - 1) {
+        const int c = __ffsll((long long)m) - 1;
+        const int i = (c << 6) + lane;
+        SegHit h;
+        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
+        if (i >= start_i && i < nseg) h = seg_hit(px, py, radius, wx[i], wy[i], wx[i + 1], wy[i + 1], i == start_i, start_t);
+        const unsigned long long hm = __ballot(h.hit);
+        if (hm) {
+            const int first = __ffsll((long long)hm) - 1;
+            r.found = true; r.i = (c << 6) + first;
+            r.t = shfl_d(h.t, first); r.x = shfl_d(h.x, first); r.y = shfl_d(h.y, first);
+            return r;
+        }
+    }
+    // pass 2, the wrap loop (:124-149): i = -1 (rows n-1 -> 0; its end points belong to the last and the first chunk), then 0 .. start_i - 1
+    {
+        SegHit h;
+        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
+        if (lane == 0 && start_i > -1) h = seg_hit(px, py, radius, wx[n - 1], wy[n - 1], wx[0], wy[0], false, 0.0);
+        if (__ballot(h.hit)) {
+            r.found = true; r.i = -1;
+            r.t = shfl_d(h.t, 0); r.x = shfl_d(h.x, 0); r.y = shfl_d(h.y, 0);
+            return r;
+        }
+    }
+    for (unsigned long long m = kept; m; m &= m - 1) {
+        const int c = __ffsll((long long)m) - 1;
+        if ((c << 6) >= start_i) break;
+        const int i = (c << 6) + lane;
+        SegHit h;
+        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
+        if (i < start_i && i < nseg) h = seg_hit(px, py, radius, wx[i], wy[i], wx[i + 1], wy[i + 1], false, 0.0);
+        const unsigned long long hm = __ballot(h.hit);
+        if (hm) {
+            const int first = __ffsll((long long)hm) - 1;
+            r.found = true; r.i = (c << 6) + first;
+            r.t = shfl_d(h.t, first); r.x = shfl_d(h.x, first); r.y = shfl_d(h.y, first);
+            return r;
+        }
+    }
+    return r;
+}
+
+// Look-ahead centres of this wave's radii (l = wave, wave + nwaves, ...) with ONE pass of exact hit tests instead of one per radius.
+// The reference's scan (utils/utils.py:69-151, wave_intersect) tests every segment from the start index against a radius: 64
+// segments x (sqrt + 2 divisions) per radius.  Here each lane first brackets the distance from the point to ITS segment, [lo, hi]
+// (one division, three square roots): a radius outside [lo - 1e-4, hi + 1e-4] cannot intersect it (the margin is orders above the
+// rounding of the reference's formula and its 1e-6 end-point shift).  The surviving (segment, radius) pairs -- about one per radius
+// -- are compacted and the EXACT test (seg_hit, the reference's arithmetic) runs once for all of them, one pair per lane; the first
+// hit of a radius is the lowest segment with a hit, as in the sequential scan.  Anything unusual (start within 64 segments of the
+// end of the polyline, no hit in the first 64 segments, more than 64 pairs, NaN) takes wave_intersect for that radius, so the
+// centres are identical by construction.  lds_first [16] / lds_pairs [64] are this wave's scratch.
+__device__ __forceinline__ void wave_lookahead_centres(double px, double py, const f1p_lattice_cfg& cfg, const double* __restrict__ wx,
+                                                       const double* __restrict__ wy, const double* __restrict__ wpsi, int n, double tstart,
+                                                       int wave, int nwaves, double* cen_x, double* cen_y, double* cen_psi, int* cen_ok,
+                                                       int* lds_first, int* lds_pairs, double near_d = 0.0, int* stat = nullptr,
+                                                       const double* __restrict__ wbox = nullptr, int first_cap = 16) {
+    const int lane = threadIdx.x & 63;
+    const int nl = cfg.n_lookahead;
+    const int start_i = (int)tstart;
+    const double start_t = tstart - __builtin_trunc(tstart);
+    // Round 3: the 64 segments are the first 64 of the reference's SCAN ORDER -- start_i .. n-2, then the wrap loop's -1, 0, 1, ...
+    // (utils/utils.py:84, :125) -- so an ego within 64 segments of the end of the polyline (the seam of a closed raceline) stays on
+    // this path instead of running sixteen general scans.  Lane j holds virtual segment j: index vi (may be -1), end points
+    // w[vi mod n], w[(vi + 1) mod n], the start-segment rule on lane 0 only (the wrap loop has none, :138-149).
+    bool fast = start_i >= 0 && start_i <= n - 2 && n > 130 && nl <= first_cap * nwaves;   // first_cap = this wave's lds_first entries
+    const int nreg = n - 1 - start_i;                           // regular segments start_i .. n-2 before the wrap loop begins
+    // lane s holds this wave's s-th radius (l = wave + s nwaves); the closing segment's end points are requested up front
+    const int nslots = nl > wave ? (nl - wave + nwaves - 1) / nwaves : 0;
+    const double my_r = lane < nslots ? cfg.lookahead[wave + lane * nwaves] : 0.0;
+    const float my_r32 = (float)my_r;
+    const double wrap_ax = wx[n - 1], wrap_ay = wy[n - 1], wrap_bx = wx[0], wrap_by = wy[0];
+    const int vi = lane < nreg ? start_i + lane : lane - nreg - 1;
+    int total = 0;
+    double seg_sx = 0.0, seg_sy = 0.0, seg_psi = 0.0;           // row vi of this lane's segment: the centre when the segment is a radius' first hit
+    double seg_ex = 0.0, seg_ey = 0.0;                          // ... and its end row: the exact test takes both from here (a shuffle, not another round trip)
+    if (fast) {
+        const int i0 = vi < 0 ? vi + n : vi, i1 = vi + 1;       // (vi + 1 <= n - 1 on the regular part, <= 63 on the wrap part)
+        seg_psi = wpsi[i0];
+        // the bracket is only a filter for the exact test below, so it is formed in f32 from the fp64 differences (relative
+        // coordinates of a few metres: the f32 rounding is ~1e-6 m against the 1e-4 m margin; one v_sqrt_f32 / v_rcp_f32 each
+        // instead of three fp64 square roots and a division)
+        const double sx = wx[i0], sy = wy[i0], ex = wx[i1], ey = wy[i1];
+        seg_sx = sx; seg_sy = sy; seg_ex = ex; seg_ey = ey;
+        const float ax = (float)(sx - px), ay = (float)(sy - py), bx = (float)(ex - px), by = (float)(ey - py);
+        const float vx = (float)(ex - sx), vy = (float)(ey - sy);
+        const float dS = __builtin_sqrtf(ax * ax + ay * ay), dE = __builtin_sqrtf(bx * bx + by * by);
+        const float len2 = vx * vx + vy * vy;
+        const float u = -(ax * vx + ay * vy);                       // projection parameter times len2
+        float lo = fminf(dS, dE);
+        if (u > 0.0f && u < len2) lo = fminf(lo, fabsf(ax * vy - ay * vx) * __builtin_amdgcn_rsqf(len2));
+        const float hi = fmaxf(dS, dE);
+        const float slack = 1e-4f + 4e-6f * hi;                     // + the f32 rounding of the bracket itself
+        if (lane < first_cap) lds_first[lane] = 0x7fffffff;
+        int slot = 0;
+        for (int l = wave; l < nl; l += nwaves, ++slot) {
+            const float r = __shfl(my_r32, slot, 64);
+            const bool flag = (!(r < lo - slack) & !(r > hi + slack)) | !(dS == dS) | !(dE == dE);   // NaN anywhere: flagged (fminf / fmaxf drop a NaN operand)
+            const unsigned long long m = __ballot(flag);
+            if (flag) {
+                const int idx = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (idx < 64) lds_pairs[idx] = (lane << 8) | slot;
+            }
+            total += __builtin_popcountll(m);
+        }
+        if (total > 64) fast = false;
+    }
+    if (fast) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int code = lane < total ? lds_pairs[lane] : 0;
+        const int off = code >> 8, slot = code & 0xff;
+        // the pair's segment is virtual segment `off`, whose rows lane `off` loaded for the bracket: the same fp64 values by shuffle
+        const double hx0 = shfl_d(seg_sx, off), hy0 = shfl_d(seg_sy, off), hx1 = shfl_d(seg_ex, off), hy1 = shfl_d(seg_ey, off);
+        if (lane < total) {
+            const SegHit h = seg_hit(px, py, cfg.lookahead[wave + slot * nwaves], hx0, hy0, hx1, hy1, off == 0, start_t);
+            if (h.hit) atomicMin(&lds_first[slot], off);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // lane s finishes this wave's s-th radius: one round trip for all the centres instead of one per radius
+    const int my_first = (fast && lane < nslots) ? lds_first[lane] : 0x7fffffff;
+    bool my_found = my_first != 0x7fffffff;
+    int my_idx = my_first < nreg ? start_i + my_first : my_first - nreg - 1;
+    // A circle smaller than the distance to the polyline meets no segment at all: the reference scans everything and returns None
+    // (:84-149).  near_d is nearest_point's distance (the minimum over segments 0 .. n-2, exact); the wrap loop adds the closing
+    // segment w[n-1] -> w[0].  Below that minimum by the bracket's own margin (1e-4 m: orders above the rounding of the
+    // reference's quadratic and its 1e-6 end-point shift) no discriminant can be >= 0 with a root in [0, 1]: None without a scan.
+    double dmin = near_d;
+    {   // distance to the closing segment in f32 from the fp64 differences (a filter with a 1e-4 m margin, like the bracket above)
+        const float ax = (float)(px - wrap_ax), ay = (float)(py - wrap_ay);
+        const float vx = (float)(wrap_bx - wrap_ax), vy = (float)(wrap_by - wrap_ay), l2 = vx * vx + vy * vy;
+        float t = l2 > 0.0f ? (ax * vx + ay * vy) * __builtin_amdgcn_rcpf(l2) : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const float qx = ax - t * vx, qy = ay - t * vy;
+        const double dw = (double)__builtin_sqrtf(qx * qx + qy * qy) * (1.0 - 1e-5);
+        if (!(dw >= dmin)) dmin = dw;                              // (NaN: dmin becomes NaN and nothing is skipped)
+    }
+    const bool surely_none = my_r < dmin - (1e-4 + 4e-6 * dmin);
+    unsigned long long rest = __ballot(lane < nslots && !my_found && !surely_none);   // no hit in the first 64 segments: the general scan (later segments, wrap loop), one radius at a time
+    if (stat) { stat[0] = __builtin_popcountll(rest); stat[1] = fast ? 1 : 0; stat[2] = total; stat[3] = __builtin_popcountll(__ballot(lane < nslots && surely_none)); }
+    while (rest) {
+        const int s = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        const Intersect it = wave_intersect_boxed(px, py, cfg.lookahead[wave + s * nwaves], wx, wy, wbox, n, tstart);
+        if (lane == s) { my_found = it.found; my_idx = it.i; }
+    }
+    // waypoints[i2, [0,1,3]] (:250-251): row i2 is the start row of the hit segment, which the lane holding that segment already has
+    // in registers -- a shuffle instead of a third dependent round trip to memory; general-scan results (rare) are loaded
+    const bool from_scan = my_found && my_first == 0x7fffffff;
+    const int src = my_found && !from_scan ? my_first : 0;
+    double c_x = shfl_d(seg_sx, src), c_y = shfl_d(seg_sy, src), c_psi = shfl_d(seg_psi, src);
+    if (lane < nslots) {
+        const int l = wave + lane * nwaves;
+        cen_ok[l] = my_found ? 1 : 0;
+        if (from_scan) {
+            const int r = my_idx < 0 ? my_idx + n : my_idx;
+            c_x = wx[r]; c_y = wy[r]; c_psi = wpsi[r];
+        }
+        if (my_found) { cen_x[l] = c_x; cen_y[l] = c_y; cen_psi[l] = c_psi; }
+    }
+}
+
+// CR = MixArgs::clear_r (0: every station against the bitmap; 1, 2: clearance mode): one instantiation per station loop, so each keeps the 64-VGPR budget
+// FOOT: oriented footprint (clearance mode only) -- its own instantiations, so the point-test kernels keep their register budget
+// (round 3: 6 waves per SIMD -- 80 registers, no spills.  Since the headline configuration moved to k_lattice_prologue +
+// k_lattice_filter3 this kernel serves host goals, the r = 0 occupancy rule and the oriented footprint)
+template <int CR, bool FOOT = false>
+__global__ __launch_bounds__(256, 6) void k_lattice_filter(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // the occupancy tile sits at LDS offset 0: its address arithmetic in the station loop then needs no base register
+    // clearance mode (MixArgs::clear_r > 0): the clearance map's tile first, the real bitmap's tile after it
+    uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);       // [tile_rows][tile_words]
+    const unsigned tile_bytes = (unsigned)a.tile_rows * (unsigned)a.tile_words * 4u;
+    uint32_t* tile_occ = reinterpret_cast<uint32_t*>(lds_raw + tile_bytes);   // [tile_rows][tile_words], clearance mode only
+    double* red_d = reinterpret_cast<double*>(lds_raw + (((size_t)tile_bytes * 2 + 15) & ~(size_t)15));   // [4]
+    double* cen_x = red_d + 4;                                   // [64]
+    double* cen_y = cen_x + F1P_MAX_LOOKAHEADS;
+    double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
+    EgoParams* egp = reinterpret_cast<EgoParams*>(cen_psi + F1P_MAX_LOOKAHEADS);   // candidate_goal reads the pose from here
+    EgoParams32* ep32 = reinterpret_cast<EgoParams32*>(egp + 1);
+    int* red_i = reinterpret_cast<int*>(ep32 + 1);               // [4]
+    int* cen_ok = red_i + 4;                                     // [64]
+    float* red_f = reinterpret_cast<float*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [4]
+    int* cnt = reinterpret_cast<int*>(red_f + 4);                // [2]: refine count, queue base
+    int* lk_first = cnt + 2;                                     // [4][16] wave_lookahead_centres scratch per wave
+    int* lk_pairs = lk_first + 64;                               // [4][64]
+    const int e = blockIdx.x;
+    if (e >= a.E) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int C = cfg.n_lookahead * cfg.n_width, S = cfg.n_stations;
+    const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
+    const int nc = c1 - c0;
+    float* c_lo = reinterpret_cast<float*>(lk_pairs + 256);      // [nc] per-candidate lower bound of the fp64 cost
+    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_lo + nc);          // [nc] state
+    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
+    // -DF1P_MIX_PHASES: shader-clock stamps at the phase boundaries, written to the debug cost buffer (tools/mixed_phases.py)
+#ifdef F1P_MIX_PHASES
+    long long tph[8]; int nph = 0;
+#define F1P_PH() do { __syncthreads(); tph[nph++] = clock64(); } while (0)
+#else
+#define F1P_PH() do {} while (0)
+#endif
+    F1P_PH();
+
+    // ---- 3 first: the occupancy tile and the per-ego constants depend on the pose only -- their global loads and the sincos of
+    // the heading are in flight while the nearest-segment and look-ahead chains run
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    int tile_gx0 = 0, tile_gy0 = 0;
+    if (collide_on) {
+        const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
+        const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
+        const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+        const int half = a.tile_rows / 2;
+        tile_gx0 = ((egx - half) >> 5) << 5;
+        tile_gy0 = egy - half;
+        const int nwords = a.tile_rows * a.tile_words;
+        const uint32_t* __restrict__ tile_src = CR > 0 ? mx.clear_bits : a.grid.bits;
+        for (int q = tid; q < nwords; q += blockDim.x) {
+            const int r = q / a.tile_words, j = q - r * a.tile_words;
+            const int gy = tile_gy0 + r, gw = (tile_gx0 >> 5) + j;
+            uint32_t v = 0xffffffffu;
+            uint32_t vo = 0xffffffffu;
+            if (gy >= 0 && gy < a.grid.h && gw >= 0 && gw < a.grid.wwords) {
+                v = tile_src[(size_t)gy * a.grid.wwords + gw];
+                if (CR > 0) vo = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
+            }
+            tile[q] = v;
+            if (CR > 0) tile_occ[q] = vo;
+        }
+    }
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    if (tid == (blockDim.x > 64 ? 64 : 0)) {
+        double sn_t, cs_t;
+        sincos(theta, &sn_t, &cs_t);
+        EgoParams q;
+        q.txx = cs_t * a.grid.inv_res; q.txy = -sn_t * a.grid.inv_res; q.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
+        q.tyx = sn_t * a.grid.inv_res; q.tyy = cs_t * a.grid.inv_res; q.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+        q.tile_w = 0; q.tile_h = 0; q.tile_gx0 = 0; q.tile_gy0 = 0; q.grid_w = 0; q.grid_h = 0;
+        q.px = px; q.py = py; q.theta = theta; q.ct = cs_t; q.st = sn_t;
+        q.prev = nullptr; q.bits = nullptr;
+        q.tile_words = 0; q.wwords = 0; q.S = S; q.den = den; q.sim_m = 0; q.n_shift = 0; q.collide = 0; q.tile_rows_i = 0;
+        *egp = q;
+        EgoParams32 p;
+        p.txx = (float)q.txx; p.txy = (float)q.txy; p.tx0 = (float)q.tx0; p.tyx = (float)q.tyx; p.tyy = (float)q.tyy; p.ty0 = (float)q.ty0;
+        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
+        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
+        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;       // metres of position error per metre of arc -> cells
+        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_words = a.tile_words;
+        p.S = S; p.den = den; p.sim_m = S - cfg.n_shift - cfg.n_cull; p.n_shift = cfg.n_shift; p.collide = collide_on ? 1 : 0;
+        p.clear_r = mx.clear_r; p.clear_ds_cap = mx.clear_ds_cap;
+        p.n_disc = 0; p.disc_omax = 0.f;
+        for (int d = 0; d < 4; ++d) p.disc_off[d] = 0.f;
+        if constexpr (FOOT) {
+            p.n_disc = mx.n_disc;
+            for (int d = 0; d < 4; ++d) { p.disc_off[d] = (float)mx.disc_off[d]; if (d < p.n_disc) p.disc_omax = fmaxf(p.disc_omax, fabsf(p.disc_off[d])); }
+        }
+        *ep32 = p;
+        cnt[0] = 0;
+    }
+    // ---- 1-3: identical to k_lattice (fp64: these decide indices) ----------------------------------------------------------
+    double nd; int ni;
+    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, tid, blockDim.x, nd, ni);
+    block_argmin(nd, ni, red_d, red_i);
+    const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
+    F1P_PH();
+    if (!a.goals) {
+#if F1P_MIX_LOOKAHEAD_PAIRS
+        wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, wave, nwaves, cen_x, cen_y, cen_psi, cen_ok,
+                               lk_first + 16 * wave, lk_pairs + 64 * wave, nd, nullptr, a.wbox);
+#else
+        for (int l = wave; l < cfg.n_lookahead; l += nwaves) {
+            const Intersect it = wave_intersect(px, py, cfg.lookahead[l], a.wx, a.wy, a.n, (double)ni + ns.t, true);
+            if (lane == 0) {
+                cen_ok[l] = it.found ? 1 : 0;
+                if (it.found) {
+                    const int r = it.i < 0 ? it.i + a.n : it.i;
+                    cen_x[l] = a.wx[r]; cen_y[l] = a.wy[r]; cen_psi[l] = a.wpsi[r];
+                }
+            }
+        }
+#endif
+    }
+    __syncthreads();
+    F1P_PH();
+    // the refinement kernel's cell arithmetic uses the same fp64 transform: handed over through global memory (one lane per field,
+    // from the LDS copy -- a struct built in the setup thread's registers costs this 64-VGPR kernel a scratch spill)
+    if (collide_on && tid >= 32 && tid < 40) {
+        const int k = tid - 32;
+        const EgoParams* q = egp;
+        if (k < 6) {
+            const double v = k == 0 ? q->txx : (k == 1 ? q->txy : (k == 2 ? q->tx0 : (k == 3 ? q->tyx : (k == 4 ? q->tyy : q->ty0))));
+            reinterpret_cast<double*>(&mx.xf[e])[k] = v;
+        } else if (k == 6) {
+            mx.xf[e].tile_gx0 = tile_gx0; mx.xf[e].tile_gy0 = tile_gy0;
+        }
+    }
+
+    // ---- 4. every candidate in f32: state + [lo, hi] ---------------------------------------------------------------------------
+    float t_min = __builtin_huge_valf();                          // min hi over this thread's FREE candidates
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        double gx = 0.0, gy = 0.0, gth = 0.0;
+        const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+        Filt32 o;
+        int dbg_code = -1;
+        o.cost = __builtin_huge_valf(); o.lo = __builtin_huge_valf(); o.hi = __builtin_huge_valf(); o.state = F1P_ST_BAD;
+        if (gok) {
+            const double r2 = gx * gx + gy * gy;
+            if (r2 > 1e-20 && r2 < 1e20) {
+                const Fit32 f = g1_fit_f32((float)gx, (float)gy, (float)gth);
+                if (f.ok) {
+                    if constexpr (CR > 0) {
+                        if (collide_on) o = station_loop_f32_clear<CR, FOOT>(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile, tile_bytes);
+                        else o = station_loop_f32(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile);
+                    } else {
+                        o = station_loop_f32(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile);
+                    }
+                }
+                else { o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); dbg_code = f.why; }
+            } else if (r2 >= 1e-26) {                                   // tiny or huge but not the fp64 fit's "degenerate" (r <= 1e-12): fp64 decides
+                o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf();
+            }                                                           // r < 1e-13 (or NaN): g1_fit rejects it -> BAD
+        }
+        c_lo[c - c0] = o.lo;
+        c_st[c - c0] = (unsigned char)o.state;
+        if (o.state == F1P_ST_FREE) t_min = fminf(t_min, o.hi);
+#ifdef F1P_MIX_DEBUG_END
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = (o.state != F1P_ST_BAD && dbg_code < 0) ? __builtin_sqrtf(((float)gx - o.xe) * ((float)gx - o.xe) + ((float)gy - o.ye) * ((float)gy - o.ye)) : 0.0f;
+#else
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
+#endif
+        if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : (o.state == F1P_ST_UNSURE && o.lo == -__builtin_huge_valf() ? 5 : o.state);
+    }
+    F1P_PH();
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t_min = fminf(t_min, __shfl_xor(t_min, m, 64));
+    if (lane == 0) red_f[wave] = t_min;
+    __syncthreads();
+    t_min = red_f[0];
+    for (int w = 1; w < nwaves; ++w) t_min = fminf(t_min, red_f[w]);
+
+    // ---- 5. the candidates only fp64 can rank: count, reserve queue space, write the entries --------------------------------------
+    const bool none_free = !(t_min < __builtin_huge_valf());
+    int mine = 0;
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        const int st = c_st[c - c0];
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        mine += (need | (none_free & (c == c0))) ? 1 : 0;
+    }
+    int pos = 0;
+    if (mine) pos = atomicAdd(&cnt[0], mine);
+    __syncthreads();
+    if (tid == 0) {
+        const int n = cnt[0];
+        const unsigned int sh = (unsigned int)e % F1P_MIX_QSHARDS;
+        const unsigned int base = sh * mx.q_shard_cap + atomicAdd(&mx.qcount[sh * 32u], (unsigned int)n);
+        cnt[1] = (int)base;
+        mx.ego_base[e] = (int)base; mx.ego_n[e] = n; mx.ego_ni[e] = ni;
+    }
+    __syncthreads();
+    const int base = cnt[1];
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        const int st = c_st[c - c0];
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        if (need | (none_free & (c == c0))) {
+            double gx = 0.0, gy = 0.0, gth = 0.0;
+            const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
+            RefEntry r;
+            r.e = e; r.c = c; r.gx = gx; r.gy = gy; r.gth = gth;
+            // ok: 0 = no goal (infeasible), -1 = evaluate, -2 = evaluate, certainly collision-free (the occupancy test is skipped)
+            r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0; r.pad = 0;
+            mx.q[base + pos] = r;
+            ++pos;
+        }
+    }
+    F1P_PH();
+#ifdef F1P_MIX_PHASES
+    if (tid == 0 && mx.dbg_cost32) for (int k = 0; k + 1 < nph; ++k) mx.dbg_cost32[(size_t)e * C + k] = (float)(tph[k + 1] - tph[k]);
+#endif
+}
+
+// ===================================================================================================================
+// Round 3: k_lattice_filter2 -- the f32 filter rebuilt around the MEASURED issue costs of gfx950
+// (tools/microbench/issue_cycles.hip, profiles/r03_valu_issue_cycles.txt; cycles per wave64 instruction per SIMD):
+//     2.5   v_add / v_sub / v_mul / v_fmac / v_fma (VGPR or literal operands) / v_and / v_or / v_xor / v_lshrrev / v_add_u32 / v_mov
+//     4.3   everything else that is one pass: v_max / v_min / v_floor / v_cvt / v_bfe / v_med3 / v_cmp / v_cndmask / DPP / readlane,
+//           integer multiplies, v_lshlrev, all fp64, packed f32 (v_pk_*: two results), ANY instruction with an SGPR operand
+//     8.3   v_sin / v_cos / v_rcp / v_sqrt / v_exp
+// (a 4.3-cycle instruction issued between 2.5-cycle ones hides: alternating the two classes averages 2.5).  The round-2 kernel ran
+// 2 983 instructions per candidate at 4.4 cycles each: its stream was fp64 and 4.3-class through and through.  What changed:
+//   * goals: the fp64 candidate_goal (a 30-instruction fp64 sincos of the centre's heading + the rotation, per candidate) becomes ONE
+//     fp64 frame per look-ahead row (centre and path normal in the ego frame, goal heading), stored as f32; a candidate's goal is two
+//     f32 fma.  The queue entries -- the only goals fp64 ever sees -- still come from candidate_goal, so nothing downstream changes.
+//   * station step: every quantity that is a polynomial of the station index is evaluated as one (midpoint phase 2 instructions,
+//     a = kappa h 1), the interval half-length is folded into the series coefficients (h P, h Q: per-candidate constants), and the
+//     rotation is four plain fma -- 12 single-pass VGPR instructions + the hardware sin / cos per station, no packed math, no SGPR
+//     operands, no per-station integer -> float conversion.
+//   * occupancy look-up: unconditional.  The clearance tile carries a guard column and a guard row of "not clear" words, the cell
+//     indices are clamped onto them with v_min_u32 (negative and huge values included: v_cvt_flr_i32_f32 saturates), so the common
+//     case is 13 instructions and one LDS read without a branch; "not clear" -- rare -- enters the exact test on the real bitmap.
+//   * similarity term in its own loop (no pointer test per station).
+// Exactness is argued exactly as for k_lattice_filter: the kernel only decides what CANNOT win or is certainly blocked; its error
+// bounds are the same constants, re-measured for this arithmetic (tests/test_gpu_lattice_mixed.py, tools/mixed_calibrate.py).
+// Scope: device-sampled goals, clearance mode (R = 1, 2), point footprint -- the configuration of the headline; everything else
+// (host goals, R = 0, oriented footprint) keeps k_lattice_filter.
+// ===================================================================================================================
+// one per look-ahead row, ego frame.  Centre and normal stay fp64: a goal next to the ego is the DIFFERENCE of the two (centre +
+// w normal ~ 0), and in f32 the cancellation costs the fit up to 1e-5 of relative cost error (measured); two fp64 fma and two
+// conversions per candidate keep the goal's own 6e-8 relative rounding, like the round-2 kernel's (float)candidate_goal
+struct GoalFrame32 { double cx, cy, nx, ny; float gth; int ok; };
+
+__device__ __forceinline__ int cvt_flr_i32_f32(float v) {      // floor + saturating conversion in one instruction (NaN -> 0)
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// workgroup-uniform parameters of the station loop (LDS): floats land in VGPRs (the cheap operand class), integers go through
+// readfirstlane
+struct EgoParamsF2 {
+    float txx, txy, tx0, tyx, tyy, ty0;
+    float w_len, w_maxk, w_meank, w_sim;
+    float margin_rel, margin_abs, edge0, edge1;
+    float clear_ds_cap, inv_den, inv_S, fS;
+    float cells_per_m, pad0;      // |(txx, txy)|: cells per metre of the ego -> tile transform (the position bound in cells)
+    const double* prev;
+    // moments of the previous path's heading column p_j = prev[j + n_shift], j < sim_m (k_lattice_prologue, fp64): with them the similarity
+    // term sum_j (theta_j - p_j)^2 of a candidate whose theta_j = A j + B j^2 is a closed form -- no per-station loop in the filter
+    double M0, M1, M2;             // sum p^2, sum j p, sum j^2 p
+    int tile_w, tile_h, pitch_bytes, occ_off, S, sim_m, n_shift, exact_all;
+};
+
+template <int R>
+__device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(unsigned char)* tile,
+                                                  double sim_s2, double sim_s3, double sim_s4) {
+    Filt32 o;
+    const int S = __builtin_amdgcn_readfirstlane(ep->S);
+    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
+    const unsigned pitch_bytes = (unsigned)__builtin_amdgcn_readfirstlane(ep->pitch_bytes);   // bytes per tile row: (tile_words + 1) word PAIRS
+    const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
+    const float k0 = f.k0, dk = f.dk, L = f.L;
+    const float ds = L * ep->inv_den, h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;                                       // quadratic phase coefficient of a piece on [-1, 1]
+    const float kend = __builtin_fmaf(dk, L, k0);
+    const float kmax = fmaxf(fabsf(k0), fabsf(kend));
+    // Round 3, second pass: between two TESTED stations (every G = 2 R + 1 stations in the clearance mode) nothing looks at the
+    // positions, so the G intervals between them are integrated as ONE piece of half-length G h with the same one-piece series --
+    // a third (fifth) of the sin / cos and fma of the loop.  The series' range is then a condition on G h (kmax G h <= 0.4, |b| G^2 <=
+    // 0.05): a candidate outside it decides nothing by its positions, exactly like one outside the single-interval range did; the
+    // remainder terms of the a-priori position bound below are evaluated for the piece actually used.  exact_all (every station tested)
+    // keeps single intervals.
+    constexpr int G = 2 * R + 1;
+    const bool macro = F1P_MIX_MACRO && !exact_all && G > 1;
+    const float gm = macro ? (float)G : 1.0f;                                // intervals per integrated piece
+    const float hp = gm * h, bp = (gm * gm) * b;                             // the piece's half-length and quadratic phase coefficient
+    const bool untrusted = !(kmax * hp <= 0.4f) || !(fabsf(bp) <= 0.05f);    // outside the one-piece series' range the positions decide nothing
+    bool unsure = untrusted || !(ds <= ep->clear_ds_cap);                    // ... nor beyond the spacing the clearance map was built for (NaN: unsure)
+    // per-candidate polynomial coefficients in u = (interval index + 1/2):
+    //   midpoint heading [rev]  thr(u) = u (alpha + beta u),  alpha = ds k0 / 2 pi,  beta = ds^2 dk / 4 pi
+    //   a(u) = kappa(s_mid) h   = A0 + A1 u
+    //   h P = c0 + z (c1 + z c2),  h Q = d0 + d1 z,  z = a^2      (P = 2 - z/3 + z^2/60 - b^2/5,  Q = 2 b (1/3 - z/10))
+    const float alpha = ds * (k0 * F1P_INV_2PI_F), beta = (ds * ds) * (0.5f * dk * F1P_INV_2PI_F);
+    float A0, A1, c0, c1, c2, d0, d1;                                        // of the piece in use (one set live at a time: the 64-register budget)
+    auto set_piece = [&](float m) {                                          // m intervals per piece: half-length m h, quadratic coefficient m^2 b
+        const float hm = m * h, bm = (m * m) * b;
+        A0 = k0 * hm; A1 = (dk * ds) * hm;
+        c0 = hm * __builtin_fmaf(bm * bm, -0.2f, 2.0f); c1 = hm * (-1.0f / 3.0f); c2 = hm * (1.0f / 60.0f);
+        d0 = (2.0f * bm) * (hm * (1.0f / 3.0f)); d1 = (2.0f * bm) * (hm * -0.1f);
+    };
+    set_piece(1.0f);
+    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
+    float x = 0.f, y = 0.f;
+    uint32_t flags = 0u;                                                     // bit 0: a tested station decided nothing; bit 1: a tested station is inside an occupied cell
+    auto step = [&](float u) {                                               // one interval: 12 plain VGPR instructions + sin + cos
+        const float thr = u * __builtin_fmaf(beta, u, alpha);
+        const float a = __builtin_fmaf(A1, u, A0);
+        const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
+        const float z = a * a;
+        const float Ph = __builtin_fmaf(z, __builtin_fmaf(z, c2, c1), c0);
+        const float Qh = __builtin_fmaf(z, d1, d0);
+        // (inline asm keeps the SLP vectoriser from packing these into v_pk_fma_f32: 4.3 cycles per pair plus the moves that build its operands)
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(cs), "v"(Ph));
+        asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(x) : "v"(sn), "v"(Qh));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(y) : "v"(sn), "v"(Ph));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(y) : "v"(cs), "v"(Qh));
+    };
+    // One look-up, no branch: the tile interleaves the clearance word and the bitmap word of every 32 cells (one ds_read_b64), the
+    // guard column / row read (not clear, not occupied) = "undecided".  In this scene a wave nearly always holds a candidate that
+    // runs along a wall, so the round-2 split into a cheap "clear" test and a branch to the exact test executed BOTH at almost every
+    // look-up (~40 instructions); evaluated together they are 23.
+    //   normal mode:  bit 0 (undecided) = not clear;  bit 1 (certain hit) = not clear & occupied & away from every cell edge
+    //   exact_all:    every station is tested against the bitmap: bit 0 = near a cell edge or off the tile, bit 1 = occupied & not near
+    // "away from every cell edge" = farther than the f32 POSITION error: the calibrated band (edge0 + edge1 L: 5-10x the measured
+    // end-point error, tools/mixed_endpoint_error.py) or, when larger, this candidate's a-priori bound:
+    //   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
+    //   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
+    //   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
+#ifdef F1P_MIX_DEBUG_END
+    float epos_dbg = 0.f;
+#endif
+    float edge;
+    {
+        const float U = 6.0e-8f;
+        const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+        const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel;
+        const float zm = (kmax * hp) * (kmax * hp);                           // of the piece actually integrated (hp = G h in the macro mode)
+        // the one-piece series keeps P = 2 - z/3 + z^2/60 - b^2/5 and Q = 2 b (1/3 - z/10) of int_{-1}^{1} exp(j (a t + b t^2)) dt; the first
+        // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
+        const float abp = fabsf(bp);
+        const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
+        const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
+#ifdef F1P_MIX_DEBUG_END
+        epos_dbg = e_pos;
+#endif
+        edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
+        if (!(edge == edge)) edge = 2.0f;                                  // NaN: nothing is "away from an edge"
+    }
+    const float edge_hi = 1.0f - edge;
+    auto test = [&]() {                                                      // the station at (x, y)
+        const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0));
+        const float lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
+        const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
+        // clamped onto the guard column (index tile_w) / guard row (index tile_h)
+        const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
+        const unsigned addr = __umul24(lyc, pitch_bytes) + ((lxc >> 2) & ~7u);
+        const unsigned long long w = *reinterpret_cast<const F1P_LDS(unsigned long long)*>(tile + addr);   // low: clearance word, high: bitmap word
+        const uint32_t nc = __builtin_amdgcn_ubfe((uint32_t)w, lxc, 1u), oc = __builtin_amdgcn_ubfe((uint32_t)(w >> 32), lxc, 1u);
+        const float rx = __builtin_amdgcn_fractf(lxf), ry = __builtin_amdgcn_fractf(lyf);
+        const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
+        uint32_t fl;
+        if (!exact_all) {
+            const uint32_t hitbit = near ? 0u : (nc & oc);
+            fl = (hitbit << 1) | nc;
+        } else {
+            const bool off = (lx != (int)lxc) | (ly != (int)lyc);          // on the guard: the fp64 path reads the global bitmap
+            fl = (near | off) ? 1u : (oc << 1);
+        }
+        flags |= fl;
+    };
+    int base = 0;
+    float ub = 0.5f;                                                         // u of interval `base`
+    if (!macro) {
+        for (; base + G < S; base += G, ub += (float)G) {                    // whole groups with a station after them
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (exact_all || j == R) test();
+                step(ub + (float)j);
+            }
+        }
+        {                                                                    // tail of <= G stations: one test covers it
+            const int t = base + R < S - 1 ? base + R : S - 1;
+            for (int i = base; i < S; ++i, ub += 1.0f) {
+                if (exact_all || i == t) test();
+                if (i + 1 < S) step(ub);
+            }
+        }
+    } else {
+        // the SAME stations are tested (R, R + G, R + 2 G, ... of the whole groups, then the tail's); between two of them one piece
+        int pos = 0;                                                         // station (x, y) stands at; ub = pos + 0.5
+        if (base + G < S) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) { step(ub); ub += 1.0f; }            // single intervals up to the first tested station
+            pos = R;
+            test();
+            set_piece((float)G);
+            float um = (float)R + 0.5f * (float)G;                           // midpoint of the piece [pos, pos + G]
+            // (round 4: pieces run while the NEXT tested station pos + G exists -- the last of them used to be five single intervals of
+            // the tail: 13 pieces and 10 look-ups instead of 17 and 10 at 50 stations)
+            for (base = G; base + R <= S - 1; base += G, um += (float)G) {
+                step(um);
+                pos += G;
+                test();
+            }
+            set_piece(1.0f);
+            ub = (float)pos + 0.5f;
+        }
+        // tail: single intervals from the last tested station to the end.  The tested stations R, R + G, ..., pos prove [0, pos + R] (each
+        // covers R stations on both sides); what lies beyond is within R of the LAST station (pos + G > S - 1), which is tested then.
+        const int t = pos > 0 ? (S - 1 > pos + R ? S - 1 : -1) : (R < S - 1 ? R : S - 1);
+        for (int i = pos; i < S; ++i, ub += 1.0f) {
+            if (i == t) test();
+            if (i + 1 < S) step(ub);
+        }
+    }
+    float sim = 0.f;
+    const double* prev = ep->prev;
+    if (prev) {
+        // Similarity to the previous winner's headings (get_similarity_cost, lattice_planner.py:287-296) in CLOSED FORM (round 4).  The
+        // station headings of a clothoid are a polynomial in the station index, theta_j = A j + B j^2 with A = k0 ds, B = dk ds^2 / 2, so
+        //   sum_j (theta_j - p_j)^2 = A^2 S2 + 2 A B S3 + B^2 S4 - 2 A M1 - 2 B M2 + M0
+        // with S_k = sum j^k (constants of the configuration) and the per-EGO moments M0 = sum p^2, M1 = sum j p, M2 = sum j^2 p that
+        // k_lattice_prologue forms once per ego: ~12 fp64 instructions per candidate instead of a 48-iteration loop with a global load
+        // each (round 3: ~300 VALU + 48 VMEM per candidate).  Evaluated in fp64 -- the expansion cancels (similar paths: the sum is small
+        // against its terms), which f32 could not afford; in fp64 the cancellation error is <= 6e-16 (S TH^2 + M0), far inside the bound e4
+        // below, whose terms fS e_th^2 >= 5.8e-14 fS TH^2 and 2 fS U sim dominate it in every regime (M0 <= 2 (S TH^2 + sim)).  The fp64
+        // refinement keeps the reference's sequential order.
+        const double dA = (double)k0 * (double)ds, dB = (0.5 * (double)dk) * ((double)ds * (double)ds);
+        double sv = __builtin_fma(dA, __builtin_fma(dA, sim_s2, __builtin_fma(2.0 * dB, sim_s3, -2.0 * ep->M1)),
+                                  __builtin_fma(dB, __builtin_fma(dB, sim_s4, -2.0 * ep->M2), ep->M0));
+        sv = sv < 0.0 ? 0.0 : sv;                                            // (NaN stays NaN: a NaN / inf previous path sends the candidate to fp64)
+        sim = (float)sv;
+    }
+    bool hit_sure = (flags & 2u) != 0u && !untrusted;
+    unsure |= (flags & 1u) != 0u;
+    if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }          // a NaN anywhere in the rows is sticky in x / y: nothing was decided
+    // sum_i |k0 + g i|, g = dk ds, in closed form (two arithmetic series around the sign change of the linear curvature)
+    const float fS = ep->fS;
+    float sumk;
+    {
+        const float g = dk * ds, kl = __builtin_fmaf(g, fS - 1.0f, k0);
+        if (!(k0 * kl < 0.0f)) {
+            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
+        } else {
+            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));      // last station on kappa_0's side of zero
+            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
+            const float n1 = is + 1.0f, n2 = fS - n1;
+            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
+        }
+    }
+    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (fS - 1.0f) * ds, k0)));
+    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * ep->inv_S), t4 = ep->w_sim * sim;
+    o.cost = ((t1 + t2) + t3) + t4;
+    // the bracket: the calibrated margin (rel * sum|terms| + abs, 30x the measured error) or, when larger, this candidate's own
+    // a-priori bound: first-order propagation of the fit's error bounds through the four cost terms
+    //   1/L: relative eLrel;  any kappa(s) = k0 + dk s, s <= L (s itself scales with L): e_kap = ek0 + L edk + |dk| L eLrel;
+    //   max|kappa| and mean|kappa| (closed form: a station within e_kap of kappa = 0 on the other side of the sign change moves the
+    //   sum by < 2 e_kap) both within e_kap;  theta(s) within e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, TH = |k0| L + |dk| L^2 / 2,
+    //   and sum (theta_i - prev_i)^2 moves by <= 2 e_th sqrt(S sum) + S e_th^2 (Cauchy-Schwarz), the f32 copy of prev by u (TH + sqrt(sum))
+    float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
+    {
+        const float U = 6.0e-8f;
+        const float e_kap = f.ek0 + L * f.edk + fabsf(dk) * L * f.eLrel;
+        const float e1 = fabsf(t1) * (f.eLrel + 3.0f * U);
+        const float e2 = fabsf(ep->w_maxk) * e_kap, e3 = fabsf(ep->w_meank) * (e_kap * (1.0f + 2.0f * ep->inv_S));
+        float e4 = 0.0f;
+        if (prev) {
+            const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+            const float rs = __builtin_sqrtf(sim);
+            const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel + U * (4.0f * TH + rs);
+            e4 = fabsf(ep->w_sim) * (2.0f * e_th * __builtin_sqrtf(fS) * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
+        }
+        const float bound = 1.25f * ((e1 + e2) + (e3 + e4)) + 8.0f * U * ((fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)));
+        o.ebound = bound;
+#ifdef F1P_MIX_DEBUG_END
+        o.ebound = epos_dbg;                                              // the end-point tool compares the measured miss with the a-priori POSITION bound [m]
+#endif
+        if (!(ep->margin_rel < 0.0f)) {                                   // (a negative margin only comes from the test hook that BREAKS the filter on purpose)
+            m = fmaxf(m, bound);
+            if (!(bound == bound)) m = __builtin_huge_valf();             // (the cost itself is then NaN as well and handled below)
+        }
+    }
+    o.lo = o.cost - m; o.hi = o.cost + m;
+    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+    o.xe = x; o.ye = y;
+    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
+    return o;
+}
+
+// ===================================================================================================================
+// Round 3, second step: the filter as TWO kernels.
+//   k_lattice_prologue   one WAVE per ego: nearest segment, look-ahead centres, goal frames, the ego's cell transform -> one
+//                        record per ego in HBM (~1.2 KB at 16 look-aheads)
+//   k_lattice_filter3    one workgroup per ego: record + tiles into LDS, then nothing but the f32 candidate evaluation and the queue
+// Why: inside one kernel every one of the 256 threads of an ego's workgroup ran the per-ego fp64 chains (nearest scan, look-ahead
+// scan, setup): ~1 050 of 2 640 VALU instructions per thread were per-EGO work replicated four times (four waves), and all 2 048
+// resident workgroups moved through the latency-bound prologue and the VALU-bound candidate phase in lockstep, so the phases of
+// different workgroups never overlapped (tools/pmc_ablate.sh: the prologue alone 26 us, the candidate phase alone ~20 us per
+// round, the kernel 87 us).  As two kernels the prologue is executed by one wave per ego at four waves per SIMD (latency hidden
+// by occupancy), and the candidate kernel is uniform VALU work.
+// ===================================================================================================================
+struct EgoRecHdr {                 // 184 bytes; followed by cen_x[nl], cen_y[nl], sin psi[nl], cos psi[nl], goal heading[nl] (fp64: what candidate_goal
+                                   // computes per look-ahead ROW, so a queue entry's goal is ten fp64 operations) and GoalFrame32[nl]
+    double px, py, theta, ct, st;  // candidate_goal's inputs
+    EgoParamsF2 p;                 // the station loop's parameters (exact_all is decided by the filter kernel: it needs the tile)
+};
+static_assert(sizeof(EgoRecHdr) % 8 == 0, "record header must keep the fp64 arrays aligned");
+
+__host__ __device__ inline size_t ego_rec_stride(int nl) { return (sizeof(EgoRecHdr) + (size_t)nl * (40 + sizeof(GoalFrame32)) + 15) & ~(size_t)15; }
+
+__global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, unsigned char* __restrict__ recs) {
+    __shared__ double s_cen[4][3 * F1P_MAX_LOOKAHEADS];
+    __shared__ int s_ok[4][F1P_MAX_LOOKAHEADS];
+    __shared__ int s_first[4][F1P_MAX_LOOKAHEADS];               // one wave holds every look-ahead row of its ego
+    __shared__ int s_pairs[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = a.e0 + blockIdx.x * 4 + wave;
+    if (e >= a.E) return;                                        // wave-uniform
+    const int nl = cfg.n_lookahead, S = cfg.n_stations;
+    double* cen_x = s_cen[wave]; double* cen_y = cen_x + F1P_MAX_LOOKAHEADS; double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
+    int* cen_ok = s_ok[wave];
+#ifdef F1P_PRO_PHASES
+    long long pph[10]; int npp = 0;
+#define F1P_PPH() do { __builtin_amdgcn_s_waitcnt(0); pph[npp++] = clock64(); } while (0)
+#else
+#define F1P_PPH() do {} while (0)
+#endif
+    F1P_PPH();
+    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
+    if (a.pose_copy && lane < 4) a.pose_copy[4 * e + lane] = a.poses[4 * e + lane];   // the poses came from host memory: HBM copy for the kernels behind this one
+    // moments of the previous path's headings for the filter's closed-form similarity term (EgoParamsF2::M0..M2): the loads are
+    // requested first and consumed after the look-ahead pass
+    const int sim_m = S - cfg.n_shift - cfg.n_cull;
+    double pm0 = 0.0, pm1 = 0.0, pm2 = 0.0;
+    if (a.prev_theta) {
+        const double* pv = a.prev_theta + (size_t)e * S + cfg.n_shift;
+        for (int j = lane; j < sim_m; j += 64) {
+            const double p = pv[j], fj = (double)j;
+            pm0 = __builtin_fma(p, p, pm0); pm1 = __builtin_fma(fj, p, pm1); pm2 = __builtin_fma(fj * fj, p, pm2);
+        }
+    }
+    double sn_t = 0.0, cs_t = 1.0;
+    if (lane == 0) sincos(theta, &sn_t, &cs_t);                  // one lane: the library call is long, the other lanes skip it
+    F1P_PPH();
+    // ---- nearest segment and look-ahead centres: the arithmetic of k_lattice (fp64: these decide indices), one wave ---------------
+    double nd; int ni;
+    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, lane, 64, nd, ni);
+    F1P_PPH();
+    wave_argmin(nd, ni);
+    const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
+    F1P_PPH();
+#ifdef F1P_PRO_PHASES
+    int lstat[4] = {0, 0, 0, 0};
+    wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, lstat, a.wbox, F1P_MAX_LOOKAHEADS);
+    if (lane == 0 && mx.dbg_cost32) for (int k = 0; k < 4; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 40 + k] = (float)lstat[k];
+#else
+    wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, nullptr, a.wbox, F1P_MAX_LOOKAHEADS);
+#endif
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    F1P_PPH();
+    sn_t = shfl_d(sn_t, 0); cs_t = shfl_d(cs_t, 0);
+    if (a.prev_theta) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { pm0 += shfl_xor_d(pm0, m); pm1 += shfl_xor_d(pm1, m); pm2 += shfl_xor_d(pm2, m); }
+    }
+    unsigned char* rec = recs + (size_t)e * ego_rec_stride(nl);
+    double* r_cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
+    GoalFrame32* r_gf = reinterpret_cast<GoalFrame32*>(r_cen + 5 * (size_t)nl);
+    // ---- goal frames: lane l = look-ahead row l (two passes beyond 64 rows never happen: F1P_MAX_LOOKAHEADS = 64) -------------------
+    if (lane < nl) {
+        const int l = lane;
+        GoalFrame32 g;
+        g.cx = 0.0; g.cy = 0.0; g.nx = 0.0; g.ny = 0.0; g.gth = 0.f; g.ok = cen_ok[l];
+        double cxv = 0.0, cyv = 0.0, sp = 0.0, cp = 1.0, gth64 = 0.0;
+        if (g.ok) {
+            cxv = cen_x[l]; cyv = cen_y[l];
+            const double cpv = cen_psi[l];
+            sincos_core(cpv, &sp, &cp);                                       // candidate_goal's own call
+            const double dx = cxv - px, dy = cyv - py;
+            g.cx = cs_t * dx + sn_t * dy; g.cy = -sn_t * dx + cs_t * dy;
+            g.nx = cs_t * (-sp) + sn_t * cp; g.ny = sn_t * sp + cs_t * cp;
+            gth64 = remainder_2pi(cpv - theta);                               // ... and its goal heading
+            g.gth = (float)gth64;
+        }
+        r_cen[l] = cxv; r_cen[nl + l] = cyv; r_cen[2 * nl + l] = sp; r_cen[3 * nl + l] = cp; r_cen[4 * nl + l] = gth64;
+        r_gf[l] = g;
+    }
+    F1P_PPH();
+    if (lane == 0) {
+        const bool collide_on = cfg.check_collision && a.has_grid;
+        int tile_gx0 = 0, tile_gy0 = 0;
+        if (collide_on) {
+            const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
+            const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
+            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+            const int half = a.tile_rows / 2;
+            tile_gx0 = ((egx - half) >> 5) << 5;
+            tile_gy0 = egy - half;
+        }
+        EgoXform xf;
+        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
+        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+        xf.tile_gx0 = tile_gx0; xf.tile_gy0 = tile_gy0;
+        mx.xf[e] = xf;                                                        // the refinement kernel's fp64 cell arithmetic
+        mx.ego_ni[e] = ni;
+        EgoRecHdr h;
+        h.px = px; h.py = py; h.theta = theta; h.ct = cs_t; h.st = sn_t;
+        const int den = S - 1 > 1 ? S - 1 : 1;
+        const int pitch = a.tile_words + 1;
+        EgoParamsF2& p = h.p;
+        p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
+        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
+        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
+        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;
+        p.clear_ds_cap = mx.clear_ds_cap;
+        p.inv_den = __builtin_amdgcn_rcpf((float)den);
+        p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
+        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.pad0 = 0.f; }
+        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+        p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
+        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.pitch_bytes = pitch * 8;   // a row of (clearance, bitmap) word pairs
+        p.occ_off = 0;
+        p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
+        p.exact_all = 0;
+        *reinterpret_cast<EgoRecHdr*>(rec) = h;
+    }
+    F1P_PPH();
+#ifdef F1P_PRO_PHASES
+    if (lane == 0 && mx.dbg_cost32) { for (int k = 0; k + 1 < npp; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 32 + k] = (float)(pph[k + 1] - pph[k]); mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 31] = (float)(pph[0] & 0xffffff); }
+#endif
+}
+
+// candidate_goal for a queue entry, from the ego's record in LDS: the SAME fp64 operations in the same order -- the per-row ones
+// (sincos of the path heading, the goal heading's remainder) were done once per row by k_lattice_prologue
+__device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, int c, const volatile EgoRecHdr* h, const double* cen, int nl,
+                                                   const GoalFrame32* gf, double& gx, double& gy, double& gth) {
+    const int l = c / cfg.n_width, k = c - l * cfg.n_width;
+    if (!gf[l].ok) { gx = 0.0; gy = 0.0; gth = 0.0; return false; }
+    const double w = cfg.width[k];
+    const double sp = cen[2 * nl + l], cp = cen[3 * nl + l];
+    const double mx_ = cen[l] + w * (-sp);
+    const double my_ = cen[nl + l] + w * cp;
+    const double dx = mx_ - h->px, dy = my_ - h->py;
+    const double ct = h->ct, st = h->st;
+    gx = ct * dx + st * dy;
+    gy = -st * dx + ct * dy;
+    gth = cen[4 * nl + l];
+    return true;
+}
+
+template <int CR>
+__global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int pitch = a.tile_words + 1;
+    const unsigned tile_bytes = (unsigned)(a.tile_rows + 1) * (unsigned)pitch * 4u;
+    uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);
+    const int nl = cfg.n_lookahead;
+    const size_t rec_bytes = ego_rec_stride(nl);
+    unsigned char* rec = lds_raw + (((size_t)tile_bytes * 2 + 15) & ~(size_t)15);
+    EgoRecHdr* hdr = reinterpret_cast<EgoRecHdr*>(rec);
+    double* cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
+    GoalFrame32* gfr = reinterpret_cast<GoalFrame32*>(cen + 5 * (size_t)nl);
+    double* wtab = reinterpret_cast<double*>(rec + rec_bytes);   // [64] lateral offsets (LDS copy: indexed per lane)
+    float* red_f = reinterpret_cast<float*>(wtab + F1P_MAX_WIDTHS);   // [4]
+    int* cnt = reinterpret_cast<int*>(red_f + 4);                // [4]: refine count, queue base
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int C = nl * cfg.n_width;
+    const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
+    const int nc = c1 - c0;
+    float* c_lo = reinterpret_cast<float*>(cnt + 4);             // [nc] per-candidate lower bound of the fp64 cost
+    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_lo + nc);          // [nc] state
+    // a workgroup takes egos blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher sizes the grid: F1P_MIX_F3_EGOS_PER_WG egos each)
+#if F1P_MIX_F3_EGOS_PER_WG > 1
+    for (int e = a.e0 + blockIdx.x; e < a.E; e += gridDim.x) {
+#else
+    {
+    const int e = a.e0 + blockIdx.x;                             // (no loop in the default build: under the 64-register cap its live ranges spill)
+    if (e >= a.E) return;
+#endif
+    // ---- the ego's record: one coalesced copy into LDS ----------------------------------------------------------------------------
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(recs + (size_t)e * rec_bytes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(rec);
+        for (int q = tid; q < (int)(rec_bytes >> 2); q += blockDim.x) dst[q] = src[q];
+    }
+    // ---- the tiles (their origin: two integers the prologue left beside the ego's cell transform -- round 3 recomputed it from the
+    // pose in fp64, ~25 slow-class instructions per thread) ------------------------------------------------------------------------
+    {
+        const int tile_gx0 = mx.xf[e].tile_gx0, tile_gy0 = mx.xf[e].tile_gy0;
+        const int lsh = pitch <= 8 ? 3 : 4, lw = 1 << lsh;
+        const int j = tid & (lw - 1);
+        const int gw = (tile_gx0 >> 5) + j;
+        const bool col_ok = j < a.tile_words && gw >= 0 && gw < a.grid.wwords;
+        if (j < pitch) {
+            for (int r = tid >> lsh; r <= a.tile_rows; r += (int)blockDim.x >> lsh) {
+                const int gy = tile_gy0 + r;
+                const bool guard = j >= a.tile_words || r >= a.tile_rows;
+                uint32_t v = 0xffffffffu, vo = guard ? 0u : 0xffffffffu;   // guard: (not clear, not occupied) = undecided; off the map: occupied
+                if (col_ok && r < a.tile_rows && gy >= 0 && gy < a.grid.h) {
+                    v = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];
+                    vo = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
+                }
+                reinterpret_cast<uint2*>(tile)[r * pitch + j] = make_uint2(v, vo);   // clearance word | bitmap word, side by side
+            }
+        }
+    }
+    if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0) {     // an ego that itself stands in a cell that is not clear would leave every candidate undecided: its workgroup tests every station against the real bitmap
+        const float tx0 = hdr->p.tx0, ty0 = hdr->p.ty0;
+        const int lx0 = cvt_flr_i32_f32(tx0), ly0 = cvt_flr_i32_f32(ty0);
+        uint32_t cd = 1u;
+        if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) cd = (tile[2 * (ly0 * pitch + (lx0 >> 5))] >> (lx0 & 31)) & 1u;
+        hdr->p.exact_all = (int)cd;
+    }
+    __syncthreads();
+
+    // ---- every candidate in f32: state + [lo, hi] ---------------------------------------------------------------------------------
+    float t_min = __builtin_huge_valf();                          // min hi over this thread's FREE candidates
+    const float inv_nw = 1.0f / (float)cfg.n_width;
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
+        const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
+        Filt32 o;
+        int dbg_code = -1;
+        o.cost = __builtin_huge_valf(); o.lo = __builtin_huge_valf(); o.hi = __builtin_huge_valf(); o.state = F1P_ST_BAD; o.xe = 0.f; o.ye = 0.f; o.ebound = 0.f;
+        float gx = 0.f, gy = 0.f;
+        if (gf->ok) {
+            const double w = ((const F1P_LDS(double)*)wtab)[k];
+            gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+            const float r2 = gx * gx + gy * gy;
+            if (r2 > 1e-8f && r2 < 1e20f) {
+                const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
+                if (f.ok) o = station_loop_f2<CR>(f, (const F1P_LDS(EgoParamsF2)*)&hdr->p, (const F1P_LDS(unsigned char)*)lds_raw, mx.sim_s2, mx.sim_s3, mx.sim_s4);
+                else { o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); dbg_code = f.why; }
+            } else {                                                      // tiny, huge or NaN in f32: the fp64 tests decide (g1_fit rejects r <= 1e-12)
+                o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf();
+            }
+        }
+        c_lo[c - c0] = o.lo;
+        c_st[c - c0] = (unsigned char)o.state;
+        if (o.state == F1P_ST_FREE) t_min = fminf(t_min, o.hi);
+#ifdef F1P_MIX_DEBUG_END
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = (o.state != F1P_ST_BAD && dbg_code < 0) ? __builtin_sqrtf((gx - o.xe) * (gx - o.xe) + (gy - o.ye) * (gy - o.ye)) : 0.0f;
+        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+#elif !defined(F1P_PRO_PHASES)
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
+        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+#endif
+        if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : (o.state == F1P_ST_UNSURE && o.lo == -__builtin_huge_valf() ? 5 : o.state);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t_min = fminf(t_min, __shfl_xor(t_min, m, 64));
+    if (lane == 0) red_f[wave] = t_min;
+    __syncthreads();
+    t_min = red_f[0];
+    for (int w = 1; w < nwaves; ++w) t_min = fminf(t_min, red_f[w]);
+
+    // ---- the candidates only fp64 can rank: count, reserve queue space, write the entries (goals by the fp64 arithmetic of candidate_goal)
+    const bool none_free = !(t_min < __builtin_huge_valf());
+    int mine = 0;
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        const int st = c_st[c - c0];
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        mine += (need | (none_free & (c == c0))) ? 1 : 0;
+    }
+    int pos = 0;
+    if (mine) pos = atomicAdd(&cnt[0], mine);
+    __syncthreads();
+    if (tid == 0) {
+        const int n = cnt[0];
+        const unsigned int sh = (unsigned int)e % F1P_MIX_QSHARDS;
+        const unsigned int base = sh * mx.q_shard_cap + atomicAdd(&mx.qcount[sh * 32u], (unsigned int)n);
+        cnt[1] = (int)base;
+        mx.ego_base[e] = (int)base; mx.ego_n[e] = n;
+    }
+    // (one candidate per thread, the usual case: the entry's fp64 goal is formed while thread 0's queue-reserving atomic is on its way)
+    const bool one_pass = c0 + (int)blockDim.x >= c1;            // workgroup-uniform
+    double g1x = 0.0, g1y = 0.0, g1th = 0.0;
+    int ok1 = 0;
+    bool need1 = false;
+    if (one_pass && c0 + tid < c1) {
+        const int c = c0 + tid, st = c_st[c - c0];
+        need1 = (((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min)) | (none_free & (c == c0));
+        if (need1) {
+            const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
+            ok1 = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0;
+        }
+    }
+    __syncthreads();
+    const int base = cnt[1];
+    if (one_pass) {
+        if (need1) {
+            RefEntry r;
+            r.e = e; r.c = c0 + tid; r.gx = g1x; r.gy = g1y; r.gth = g1th;
+            // ok: 0 = no goal (infeasible), -1 = evaluate, -2 = evaluate, certainly collision-free (the occupancy test is skipped)
+            r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = ok1; r.pad = 0;
+            mx.q[base + pos] = r;
+        }
+    } else
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + tid;
+        if (c >= c1) continue;
+        const int st = c_st[c - c0];
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        if (need | (none_free & (c == c0))) {
+            double gx = 0.0, gy = 0.0, gth = 0.0;
+            const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
+            RefEntry r;
+            r.e = e; r.c = c; r.gx = gx; r.gy = gy; r.gth = gth;
+            r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0; r.pad = 0;
+            mx.q[base + pos] = r;
+            ++pos;
+        }
+    }
+#if F1P_MIX_F3_EGOS_PER_WG > 1
+    __syncthreads();                                             // the LDS blocks are reused by the workgroup's next ego
+#endif
+    }
+}
+
+// Per-ego constants of the fp64 occupancy test (the tile-relative cell arithmetic of k_lattice step 3, folded as in EgoParams)
+
+
+// WAVE per queue entry: the fp64 evaluation of k_lattice for that candidate -- the arithmetic of k_lattice in the same order,
+// hence the same bits -- with the independent parts spread over the 64 lanes instead of run as one 6000-instruction chain:
+//   * fit: every lane runs the scalar prologue (g1_begin); lane j evaluates quadrature node j (phase, sincos_core); lanes 0..11
+//     each accumulate ONE of the twelve moments over the nodes in node order (the fma chain of fit_moments); every lane then runs
+//     g1_step on the gathered moments.  A fit that needs panels or a second model step falls back to the scalar g1_fit (rare).
+//   * stations: one lane per station interval (piece_state_at + interval_increment, as emit_and_track does), positions by the
+//     sequential prefix sum of the evaluation loop, one lane per station for heading / curvature / occupancy (global bitmap through
+//     the ego's tile-relative cell arithmetic); the running sums of station_loop are then formed in station order.
+// A candidate the filter proved collision-free (no station near a cell boundary, none occupied) skips positions and occupancy.
+// Measured alternatives: one THREAD per entry (the scalar chain, one wave per SIMD) is latency-bound at ~70 us for ~7000 entries;
+// evaluating an ego's entries inside its k_lattice_select wave serialises them (72 us).
+// (Measured, round 3: 32 lanes per entry under a 128-register cap -- twice the waves, four per SIMD resident -- takes 43.5 us against 26.6:
+// the cap spills 192 B per lane into the fit and the station passes.)
+// GS = lanes per entry: 16 (four entries per wave: the scalar prologue / epilogue -- atan2, the model's Newton steps, interval_setup, the
+// sequential sums -- is a third of the work and is shared by four entries then) or 64 (one wave per entry: when four per-entry LDS
+// blocks per wave do not fit, i.e. very long station counts).  Lanes of a group hold identical per-entry values.
+template <int GS, bool FOOT = false>
+__global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int GPW = 64 / GS;                                 // groups (entries) per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
+    const int S = cfg.n_stations;
+    double* ncs = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * (64 + 4 * (size_t)S);   // [32] cos at the nodes
+    double* nsn = ncs + 32;                                                                    // [32] sin at the nodes
+    double* inc_x = nsn + 32;                                                                  // [S]
+    double* inc_y = inc_x + S;                                                                 // [S]
+    double* akv = inc_y + S;                                                                   // [S] |kappa| per station (station positions x before the cost phase)
+    double* simv = akv + S;                                                                    // [S] similarity term per station (station positions y before the cost phase)
+    // the 16-node rule's nodes and weight table (the rule of all but pathological goals) in LDS, once per workgroup: a lane's
+    // sixteen-step moment chain then reads its operands from LDS with all reads in flight together -- from constant memory every step was
+    // a dependent global round trip (16 x ~500 cycles: most of the fit's time, tools/refine_phases.py)
+    __shared__ double s_gl_wu[16][6];
+    __shared__ double s_gl_x[16];
+    if (tid < 96) s_gl_wu[tid / 6][tid % 6] = c_gl_wu[tid / 6][tid % 6];
+    else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
+    __syncthreads();
+#ifdef F1P_MIX_PHASES
+    long long rph[8]; int nrp = 0;
+#define F1P_RPH() do { rph[nrp++] = clock64(); } while (0)
+#else
+#define F1P_RPH() do {} while (0)
+#endif
+    F1P_RPH();
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    const int sim_m = S - cfg.n_shift - cfg.n_cull;
+    // group g works on shard g % shards, entries g / shards, + groups / shards, ... (the launcher makes the group count a multiple of the shard count)
+    const unsigned int ngroups_total = gridDim.x * (blockDim.x >> 6) * GPW;
+    const unsigned int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * GPW + grp;
+    const unsigned int sh = g0 % F1P_MIX_QSHARDS, lstride = ngroups_total / F1P_MIX_QSHARDS;
+    const unsigned int n = mx.qcount[sh * 32u];
+    for (unsigned int ib = 0, li = g0 / F1P_MIX_QSHARDS; ; ib += ngroups_total, li += lstride) {
+        const unsigned int i = sh * mx.q_shard_cap + li;
+        const bool live = li < n;
+        (void)ib;
+        if (!__any(live)) break;                                     // wave-uniform exit; groups past the end idle through the barriers
+        RefEntry r;
+        r.ok = 0; r.e = 0; r.c = 0; r.gx = 0; r.gy = 0; r.gth = 0; r.cost = 0; r.k0 = 0; r.dk = 0; r.L = 0; r.pad = 0;
+        // (the entry is requested together with the shard's count, not after it: slots past the count hold stale entries of earlier
+        // plans -- readable memory, masked below)
+        if (li < mx.q_shard_cap) r = mx.q[i];
+        if (!live) { r.ok = 0; r.e = a.e0; r.c = 0; }
+        F1P_RPH();
+        const bool work = live && r.ok != 0;                         // ok == 0: no goal -- the filter wrote cost = +inf, zero clothoid
+        const int e = r.e;
+        const bool check_occ = collide_on && r.ok != -2;
+        // what the station phases need from memory is requested now, behind the entry, and arrives while the fit runs
+        EgoXform xf = {};
+        if (work && check_occ) xf = mx.xf[e];                        // the ego -> tile-relative cell transform of the filter's setup thread (fp64)
+        const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+        double pv[4] = {0.0, 0.0, 0.0, 0.0};                         // previous headings of this lane's first four stations
+        if (work && prev) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int q = gl + k * GS; if (q < sim_m) pv[k] = prev[q + cfg.n_shift]; }
+        }
+        // ---- fit ------------------------------------------------------------------------------------------------------------
+        Clothoid cl;
+        cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
+        G1State g;
+        g.r = 0; g.phi0 = 0; g.delta = 0; g.A = 0;
+        bool fitting = work && g1_begin(r.gx, r.gy, r.gth, g);
+        double c0 = 0.0;
+        bool ok = false;
+        for (int it = 0; it < 20 && __any(fitting); ++it) {          // g1_fit's own iteration (one pass in all but pathological goals)
+            const double fa = g.A, fb = g.delta - g.A, fc = g.phi0;
+            const double exc = fabs(fa) + fabs(fb);
+            int off = 88, cnt = 32, panels = 1;                      // fit_moments' choice of rule
+            if (exc <= 8.0) { off = 0; cnt = 16; }
+            else if (exc <= 14.0) { off = 16; cnt = 20; }
+            else if (exc <= 21.0) { off = 36; cnt = 24; }
+            else if (exc <= 29.0) { off = 60; cnt = 28; }
+            else if (!(exc <= 36.0)) {
+                const double pn = __builtin_ceil(exc * (1.0 / 36.0));
+                panels = pn <= 1024.0 ? (int)pn : 1024;
+            }
+            if (!fitting) { cnt = 0; panels = 1; }
+            double acc = 0.0;                                        // group lanes 0..5: m.c[gl], 6..11: m.s[gl - 6]
+            const int k = gl < 6 ? gl : gl - 6;
+            int max_panels = panels;
+#pragma unroll
+            for (int m_ = 32; m_ >= 1; m_ >>= 1) { const int o = __shfl_xor(max_panels, m_, 64); max_panels = o > max_panels ? o : max_panels; }
+            if (max_panels == 1) {
+                const bool rule16 = cnt == 16;                       // off == 0: the tables in LDS
+                for (int j = gl; j < cnt; j += GS) {
+                    const double tau = rule16 ? s_gl_x[j] : c_gl_x[off + j];
+                    const double ph = __builtin_fma(__builtin_fma(fa, tau, fb), tau, fc);
+                    double sn, cs;
+                    sincos_core(ph, &sn, &cs);
+                    ncs[j] = cs; nsn[j] = sn;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (gl < 12) {
+                    const double* v = gl < 6 ? ncs : nsn;
+                    if (rule16) {                                    // the same sixteen fma in the same order, operands read ahead
+                        double w[16], u[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) { w[j] = s_gl_wu[j][k]; u[j] = v[j]; }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc = __builtin_fma(w[j], u[j], acc);
+                    } else {                                         // 20 .. 32 nodes: four at a time
+                        for (int j0 = 0; j0 < cnt; j0 += 4) {
+                            const double w0 = c_gl_wu[off + j0][k], w1 = c_gl_wu[off + j0 + 1][k], w2 = c_gl_wu[off + j0 + 2][k], w3 = c_gl_wu[off + j0 + 3][k];
+                            const double u0 = v[j0], u1 = v[j0 + 1], u2 = v[j0 + 2], u3 = v[j0 + 3];
+                            acc = __builtin_fma(w0, u0, acc); acc = __builtin_fma(w1, u1, acc); acc = __builtin_fma(w2, u2, acc); acc = __builtin_fma(w3, u3, acc);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {                                                 // panels of the 32-node rule: `m[k] += w u^k (cos, sin)` in (panel, node) order
+                const double h = 1.0 / (double)panels;
+                for (int p = 0; p < max_panels; ++p) {
+                    const bool mine = fitting && p < panels;
+                    if (mine && panels == 1) {                       // a single-rule entry sharing the wave with a panel entry: its rule once
+                        for (int j = gl; j < cnt; j += GS) {
+                            const double tau = c_gl_x[off + j];
+                            const double ph = __builtin_fma(__builtin_fma(fa, tau, fb), tau, fc);
+                            double sn, cs;
+                            sincos_core(ph, &sn, &cs);
+                            ncs[j] = cs; nsn[j] = sn;
+                        }
+                    } else if (mine) {
+                        const double t0 = (double)p * h;
+                        for (int j = gl; j < cnt; j += GS) {
+                            const double tau = __builtin_fma(h, c_gl_x[off + j], t0);
+                            const double ph = __builtin_fma(__builtin_fma(fa, tau, fb), tau, fc);
+                            double sn, cs;
+                            sincos_core(ph, &sn, &cs);
+                            const double w = h * c_gl_w[off + j];
+                            ncs[j] = w * cs; nsn[j] = w * sn;
+                            akv[j] = __builtin_fma(tau, tau, -tau);      // u (akv is free until the station phase)
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (mine && gl < 12) {
+                        const double* v = gl < 6 ? ncs : nsn;
+                        if (panels == 1) {
+                            for (int j = 0; j < cnt; ++j) acc = __builtin_fma(c_gl_wu[off + j][k], v[j], acc);
+                        } else {
+                            for (int j = 0; j < cnt; ++j) {
+                                double t = v[j];
+                                for (int q = 0; q < k; ++q) t *= akv[j];     // wc *= u, k times: the scalar loop's own products
+                                acc += t;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            FitMoments m;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { m.c[q] = shfl_d(acc, gbase + q); m.s[q] = shfl_d(acc, gbase + 6 + q); }
+            if (fitting) {
+                const int st = g1_step(m, g, c0);
+                if (st != 0) { fitting = false; ok = st > 0; }
+            }
+        }
+        if (ok) cl = g1_finish(g, c0);
+        F1P_RPH();
+        // ---- stations -------------------------------------------------------------------------------------------------------
+        double cost = __builtin_huge_val();
+        const bool run = cl.ok;
+        const double k0 = cl.k0, dk = cl.dk, L = run ? cl.L : 1.0;
+        const double ds = L / (double)den;
+        bool hit = false;
+        const bool occ_pass = run && check_occ;
+        // the station increments: needed here by the occupancy pass, and by k_lattice_select for whichever entry wins -- handed over
+        // through mx.inc (the selection's own interval_setup + piece_state_at + interval_increment was 41 % of its wave's lifetime);
+        // an entry the filter proved collision-free computes them only for that hand-over, beside the other groups' occupancy passes
+        const bool store_inc = run && mx.inc != nullptr && li < mx.inc_cap;
+        const bool inc_pass = occ_pass || store_inc;
+        if (__any(inc_pass)) {
+            if (inc_pass) {
+                const IntervalCoef ic = interval_setup(k0, dk, L, ds);
+                // a lane takes CONSECUTIVE intervals: the phasor state leaving interval q is the state entering q + 1 (that is how the
+                // evaluation loop runs, re-anchoring inside interval_increment), so one piece_state_at per lane instead of one per
+                // interval -- three anchors (six fp64 sincos) and their advances fewer in the usual 49 intervals over 16 lanes
+                const int per = (S - 1 + GS - 1) / GS, q0 = gl * per, q1 = q0 + per < S - 1 ? q0 + per : S - 1;
+                if (q0 < q1) {
+                    PieceState st = piece_state_at(k0, dk, ds, q0, ic);
+                    for (int q = q0; q < q1; ++q) {
+                        double dx, dy;
+                        interval_increment(k0, dk, (double)q * ds, q * ic.nsub, ic, st, dx, dy);
+                        inc_x[q] = dx; inc_y[q] = dy;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            F1P_RPH();
+            // the station POSITIONS go to the selection (mx.inc block of this entry: x [S] | y [S]): its own running sums over the increments
+            // were a third of its instructions
+            double* gp = store_inc ? mx.inc + ((size_t)sh * mx.inc_cap + li) * 2 * (size_t)S : nullptr;
+            double* pos_x = akv; double* pos_y = simv;               // (free until the cost phase)
+            if (inc_pass) {
+                // positions by the evaluation loop's own running sums (x_q = ((inc_0 + inc_1) + ...) + inc_{q-1}), formed ONCE per entry and
+                // left in LDS.  Eight increments are read ahead of their eight additions: read-then-add per element was one LDS round trip
+                // per station (~100 cycles x 49: a quarter of an entry's lifetime).  Past the last interval the sums take + 0.0, an
+                // identity (they start at + 0.0 and can never be - 0.0), so the loop has no per-element branch.
+                double x = 0.0, y = 0.0;
+                if (gl == 0) { pos_x[0] = 0.0; pos_y[0] = 0.0; }
+                for (int j0 = 0; j0 < S - 1; j0 += 8) {
+                    double dx[8], dy[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u < S - 1 ? j0 + u : S - 2;
+                        dx[u] = inc_x[j]; dy[u] = inc_y[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = j0 + u < S - 1;
+                        x += in ? dx[u] : 0.0; y += in ? dy[u] : 0.0;
+                        if (in && gl == 0) { pos_x[j0 + u + 1] = x; pos_y[j0 + u + 1] = y; }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (inc_pass) {
+                // the cell words of a lane's stations (gl, gl + GS, ...) are requested together: one global round trip per entry
+                constexpr int NSL = 4;                               // stations per lane handled in registers; a longer horizon loops
+                for (int qb = 0; qb < S; qb += NSL * GS) {
+                    double xs[NSL], ys[NSL];
+#pragma unroll
+                    for (int k = 0; k < NSL; ++k) { const int q = qb + k * GS + gl; xs[k] = q < S ? pos_x[q] : 0.0; ys[k] = q < S ? pos_y[q] : 0.0; }
+                    // the cell word of a point (NaN / off-map: occupied): k_lattice's own arithmetic on the ego's tile-relative transform
+                    auto cell = [&](double qx, double qy, uint32_t& word, int& bit) {
+                        word = 0xffffffffu; bit = 0;
+                        const double lxf = __builtin_floor(__builtin_fma(xf.txx, qx, __builtin_fma(xf.txy, qy, xf.tx0)));
+                        const double lyf = __builtin_floor(__builtin_fma(xf.tyx, qx, __builtin_fma(xf.tyy, qy, xf.ty0)));
+                        const double gxf = lxf + (double)xf.tile_gx0, gyf = lyf + (double)xf.tile_gy0;
+                        if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
+                            const int cgx = (int)gxf, cgy = (int)gyf;
+                            word = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
+                            bit = cgx & 31;
+                        }
+                    };
+                    if (gp) {
+#pragma unroll
+                        for (int k = 0; k < NSL; ++k) { const int q = qb + k * GS + gl; if (q < S) { gp[q] = xs[k]; gp[S + q] = ys[k]; } }
+                    }
+                    if (!occ_pass) continue;
+                    if (!FOOT || mx.n_disc == 0) {
+                        uint32_t word[NSL]; int bit[NSL]; bool have[NSL];
+#pragma unroll
+                        for (int k = 0; k < NSL; ++k) {
+                            have[k] = qb + k * GS + gl < S;
+                            word[k] = 0u; bit[k] = 0;
+                            if (have[k]) cell(xs[k], ys[k], word[k], bit[k]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NSL; ++k) hit |= have[k] && ((word[k] >> bit[k]) & 1u);
+                    } else {                                         // oriented footprint: the disc centres of station_loop<.., FOOT>
+#pragma unroll
+                        for (int k = 0; k < NSL; ++k) {
+                            const int q = qb + k * GS + gl;
+                            if (q < S) {
+                                const double sq = (double)q * ds;
+                                const double th = sq * (k0 + 0.5 * sq * dk);
+                                double sn_h, cs_h;
+                                sincos_fast(th, &sn_h, &cs_h);
+                                for (int d = 0; d < mx.n_disc; ++d) {
+                                    const double o = mx.disc_off[d];
+                                    uint32_t word; int bit;
+                                    cell(xs[k] + o * cs_h, ys[k] + o * sn_h, word, bit);
+                                    hit |= (word >> bit) & 1u;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // the positions were read: akv / simv are free for the cost phase
+            __builtin_amdgcn_wave_barrier();
+        }
+        F1P_RPH();
+        if (run) {
+            for (int q = gl; q < S; q += GS) {
+                const double s = (double)q * ds;
+                akv[q] = fabs(k0 + dk * s);
+                double sv = 0.0;
+                if (prev && q < sim_m) {
+                    const int kq = (q - gl) / GS;
+                    const double pq = kq < 4 ? (kq == 0 ? pv[0] : (kq == 1 ? pv[1] : (kq == 2 ? pv[2] : pv[3]))) : prev[q + cfg.n_shift];
+                    const double th = s * (k0 + 0.5 * s * dk); const double d = th - pq; sv = d * d;
+                }
+                simv[q] = sv;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long hm = __ballot(hit);
+        const bool any_hit = ((hm >> gbase) & (GS == 64 ? ~0ull : (1ull << (GS & 63)) - 1ull)) != 0ull;
+        if (run) {
+            double sumk = 0.0, sim = 0.0;
+            for (int q = 0; q < S; ++q) sumk += akv[q];               // station order, like `sumk += ak` of the loop
+            if (prev) for (int q = 0; q < sim_m; ++q) sim += simv[q];  // ... and `sim += d * d`
+            const double maxk = __builtin_fmax(fabs(k0 + dk * (0.0 * ds)), fabs(k0 + dk * ((double)(S - 1) * ds)));
+            cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
+            cost += cfg.w_length * (1.0 / L);
+            cost += cfg.w_max_kappa * maxk;
+            cost += cfg.w_mean_kappa * (sumk / (double)S);
+            cost += cfg.w_similarity * sim;
+            if (any_hit) cost = __builtin_huge_val();
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (work && gl == 0) {
+            RefEntry o = r;
+            o.cost = cost; o.k0 = cl.k0; o.dk = cl.dk; o.L = cl.L; o.ok = cl.ok ? 1 : 0; o.pad = store_inc ? 1 : 0;
+            mx.q[i] = o;
+        }
+#ifdef F1P_MIX_PHASES
+        F1P_RPH();
+        if (ib == 0 && live && gl == 0 && mx.dbg_state && (size_t)i * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width) {
+            for (int k = 0; k + 1 < nrp; ++k) mx.dbg_state[(size_t)i * 8 + k] = (int)(rph[k + 1] - rph[k]);
+            mx.dbg_state[(size_t)i * 8 + 7] = nrp;
+        }
+#endif
+    }
+}
+
+// wave per ego: select() over the refined candidates, winner re-emission, tracking (the tail of k_lattice_eval)
+__global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = a.e0 + blockIdx.x * 4 + wave;
+    if (blockIdx.x == 0 && tid < F1P_MIX_QSHARDS) mx.qcount[tid * 32u] = 0u;   // the refinement kernel is done with them: ready for the next plan
+    if (e >= a.E) return;
+    const int S = cfg.n_stations;
+    double* tr_x = reinterpret_cast<double*>(lds_raw) + (size_t)wave * 4 * S;
+    double* tr_y = tr_x + S;
+    double* inc_x = tr_y + S;
+    double* inc_y = inc_x + S;
+#ifdef F1P_MIX_PHASES
+    long long sph[8]; sph[0] = clock64();
+#endif
+    const int base = mx.ego_base[e], n = mx.ego_n[e], ni = mx.ego_ni[e];
+    const int c0 = cfg.cand_begin;
+    // Round 4: ONE round trip for everything the usual ego needs.  Lane j takes the WHOLE record of entry j (cost, index, clothoid) -- the
+    // winner's clothoid then comes by shuffle, not by a second dependent load -- and, alongside, every lane requests its station of the
+    // position blocks of the ego's first two entries (1-2 entries per ego is the rule): after the argmin the winner's positions are
+    // already in registers.  More than 64 entries (a blocked ego) or a winner beyond the second entry take the loads they took before.
+    double bc = __builtin_huge_val(); int bi = 0x7fffffff, bslot = -1;
+    double my_k0 = 0.0, my_dk = 0.0, my_L = 0.0; int my_ok = 0, my_pad = 0;
+    if (lane < n) {
+        const RefEntry* q = mx.q + base + lane;
+        bc = q->cost; bi = q->c; bslot = base + lane;
+        my_k0 = q->k0; my_dk = q->dk; my_L = q->L; my_ok = q->ok; my_pad = q->pad;
+    }
+    double sx0 = 0.0, sy0 = 0.0, sx1 = 0.0, sy1 = 0.0;              // station `lane` of the first / second entry's position block
+    const unsigned int sh0 = (unsigned int)base / mx.q_shard_cap, li0 = (unsigned int)base - sh0 * mx.q_shard_cap;   // (an ego's entries are contiguous in one shard)
+    const bool spec = mx.inc != nullptr && S <= 64 && a.mode != LATTICE_EVAL;
+    if (spec && lane < S) {
+        if (n >= 1 && li0 < mx.inc_cap) { const double* gp = mx.inc + ((size_t)sh0 * mx.inc_cap + li0) * 2 * (size_t)S; sx0 = gp[lane]; sy0 = gp[S + lane]; }
+        if (n >= 2 && li0 + 1 < mx.inc_cap) { const double* gp = mx.inc + ((size_t)sh0 * mx.inc_cap + li0 + 1) * 2 * (size_t)S; sx1 = gp[lane]; sy1 = gp[S + lane]; }
+    }
+    for (int j = lane + 64; j < n; j += 64) {
+        const double cost = mx.q[base + j].cost;
+        const int c = mx.q[base + j].c;
+        if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; bslot = base + j; }
+    }
+    int src = 0;
+    {   // wave argmin carrying the slot (candidate indices are unique per ego)
+        double d = bc; int i = bi;
+        wave_argmin(d, i);
+        const unsigned long long m = __ballot((bi == i) & (bslot >= 0));
+        src = m ? __ffsll((long long)m) - 1 : 0;
+        bslot = __shfl(bslot, src, 64);
+        bc = d; bi = i;
+    }
+    Clothoid cl;
+    cl.ok = false; cl.k0 = 0; cl.dk = 0; cl.L = 0;
+    if (!(bc < __builtin_huge_val()) && !(bc != bc)) {
+        // everything refined is +inf, i.e. everything is blocked: the exhaustive loop's answer is the shard's first candidate
+        bi = c0; bslot = -1;
+        for (int j = lane; j < n; j += 64) if (mx.q[base + j].c == c0) bslot = base + j;
+        const unsigned long long m = __ballot(bslot >= 0);
+        bslot = m ? __shfl(bslot, __ffsll((long long)m) - 1, 64) : -1;
+    }
+#ifdef F1P_MIX_PHASES
+    sph[1] = clock64();
+#endif
+    bool have_inc = false;
+    if (bslot >= 0) {
+        if (bslot - base < 64) {                                     // the winner's record sits in lane bslot - base
+            const int w = bslot - base;
+            cl.k0 = shfl_d(my_k0, w); cl.dk = shfl_d(my_dk, w); cl.L = shfl_d(my_L, w);
+            cl.ok = __shfl(my_ok, w, 64) == 1;
+            have_inc = cl.ok && __shfl(my_pad, w, 64) == 1 && mx.inc != nullptr;
+        } else {
+            const RefEntry r = mx.q[bslot]; cl.k0 = r.k0; cl.dk = r.dk; cl.L = r.L; cl.ok = r.ok == 1; have_inc = cl.ok && r.pad == 1 && mx.inc != nullptr;
+        }
+    }
+    if (lane == 0) {
+        if (a.best_idx) a.best_idx[e] = bi;
+        if (a.best_cost) a.best_cost[e] = bc;
+        if (a.near_idx) a.near_idx[e] = ni;
+    }
+    if (a.mode == LATTICE_EVAL) return;
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    if (have_inc) {                                                  // wave-uniform: the winner's station positions as k_lattice_refine formed them
+        const int w = bslot - base;
+        if (spec && (w == 0 || w == 1)) {
+            if (lane < S) { tr_x[lane] = w == 0 ? sx0 : sx1; tr_y[lane] = w == 0 ? sy0 : sy1; }
+        } else {
+            const unsigned int sh = (unsigned int)bslot / mx.q_shard_cap, li = (unsigned int)bslot - sh * mx.q_shard_cap;
+            const double* gp = mx.inc + ((size_t)sh * mx.inc_cap + li) * 2 * (size_t)S;
+            for (int i = lane; i < S; i += 64) { tr_x[i] = gp[i]; tr_y[i] = gp[S + i]; }
+        }
+    }
+#ifdef F1P_MIX_PHASES
+    sph[2] = clock64();
+    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3);
+    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3);
+    sph[5] = clock64();
+    if (lane == 0 && mx.dbg_cost32 && (size_t)e * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width)
+        for (int k = 0; k < 5; ++k) mx.dbg_cost32[(size_t)a.E * cfg.n_lookahead * cfg.n_width / 2 + (size_t)e * 8 + k] = (float)(sph[k + 1] - sph[k]);
+#else
+    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
+    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
+#endif
+}
+
+// audit: one thread per audited ego compares every output of the mixed plan with the all-fp64 plan of the same ego, bit for bit
+// (NaN == NaN; f32 trajectories against the fp64 reference rounded once)
+__global__ void k_lattice_audit_compare(int n, int S, const double* steer, const double* speed, const int32_t* idx, const double* cost,
+                                        const int32_t* status, const int32_t* near_idx, const double* traj, const float* traj32,
+                                        const double* r_steer, const double* r_speed, const int32_t* r_idx, const double* r_cost,
+                                        const int32_t* r_status, const int32_t* r_near, const double* r_traj, unsigned long long* counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        auto same = [](double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b); };
+        if (steer) bad |= !same(steer[i], r_steer[i]);
+        if (speed) bad |= !same(speed[i], r_speed[i]);
+        bad |= idx[i] != r_idx[i];
+        if (cost) bad |= !same(cost[i], r_cost[i]);
+        if (status) bad |= status[i] != r_status[i];
+        if (near_idx) bad |= near_idx[i] != r_near[i];
+        if (traj) for (int k = 0; k < 4 * S; ++k) bad |= !same(traj[(size_t)i * 4 * S + k], r_traj[(size_t)i * 4 * S + k]);
+        if (traj32) for (int k = 0; k < 4 * S; ++k) { const float a = traj32[(size_t)i * 4 * S + k], b = (float)r_traj[(size_t)i * 4 * S + k]; bad |= !(a == b || (a != a && b != b)); }
+    }
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[2], (unsigned long long)__builtin_popcountll(m));
+    if (i == 0) { atomicAdd(&counters[0], 1ull); atomicAdd(&counters[1], (unsigned long long)n); }
+}
+
+static int lattice_audit(f1p_ctx* ctx, const double* d_poses, const double* d_prev_theta, int E, const f1p_lattice_cfg* cfg,
+                         double* d_steer, double* d_speed, int32_t* d_best_idx, double* d_best_cost, int32_t* d_status,
+                         int32_t* d_near_idx, double* d_best_traj, float* d_best_traj32) {
+    const int n = ctx->audit_egos < E ? ctx->audit_egos : E;
+    const int S = cfg->n_stations;
+    // the window [w0, w0 + n): a multiplicative hash of the plan counter, so that every ego is covered over time
+    const unsigned long long h = (ctx->audit_plans * 0x9E3779B97F4A7C15ull) >> 20;
+    const int w0 = E > n ? (int)(h % (unsigned long long)(E - n + 1)) : 0;
+    const size_t need = 256 * 8 + (size_t)n * (8 + 8 + 4 + 8 + 4 + 4) + (size_t)n * S * 32;
+    if (!ctx->d_audit) {
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_audit, 3 * sizeof(unsigned long long)));
+        F1P_HIP(ctx, hipMemsetAsync(ctx->d_audit, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    }
+    if (need > ctx->audit_buf_bytes) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_audit_buf) (void)hipFree(ctx->d_audit_buf);
+        ctx->d_audit_buf = nullptr; ctx->audit_buf_bytes = 0;
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_audit_buf, need));
+        ctx->audit_buf_bytes = need;
+    }
+    char* b = ctx->d_audit_buf;
+    auto take = [&](size_t bytes) { char* p = b; b += (bytes + 255) & ~(size_t)255; return p; };
+    double* r_steer = (double*)take(8 * (size_t)n); double* r_speed = (double*)take(8 * (size_t)n);
+    int32_t* r_idx = (int32_t*)take(4 * (size_t)n); double* r_cost = (double*)take(8 * (size_t)n);
+    int32_t* r_status = (int32_t*)take(4 * (size_t)n); int32_t* r_near = (int32_t*)take(4 * (size_t)n);
+    double* r_traj = (double*)take((size_t)n * S * 32);
+    f1p_lattice_cfg ref_cfg = *cfg;
+    ref_cfg.prune = 0;                                              // the plain exhaustive loop
+    const int mixed = ctx->lattice_mixed;
+    ctx->lattice_mixed = 0; ctx->auditing = true;
+    const int rc = launch_lattice(ctx, LATTICE_FULL, d_poses + 4 * (size_t)w0, nullptr, d_prev_theta ? d_prev_theta + (size_t)w0 * S : nullptr, n, &ref_cfg,
+                                  nullptr, nullptr, r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj, nullptr, nullptr, nullptr);
+    ctx->lattice_mixed = mixed; ctx->auditing = false;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lattice_audit_compare, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, S,
+                       d_steer ? d_steer + w0 : nullptr, d_speed ? d_speed + w0 : nullptr, d_best_idx + w0, d_best_cost ? d_best_cost + w0 : nullptr,
+                       d_status ? d_status + w0 : nullptr, d_near_idx ? d_near_idx + w0 : nullptr,
+                       d_best_traj ? d_best_traj + (size_t)w0 * S * 4 : nullptr, d_best_traj32 ? d_best_traj32 + (size_t)w0 * S * 4 : nullptr,
+                       r_steer, r_speed, r_idx, r_cost, r_status, r_near, r_traj, ctx->d_audit);
+    return check_hip(ctx, hipGetLastError(), "k_lattice_audit_compare launch");
+}
+
+// The mixed-precision schedule of one plan: decides whether it applies (*handled), sizes the scratch, launches prologue -> filter ->
+// refinement -> selection (and the runtime audit).  Called by launch_lattice (k_lattice.hip) with the plan's LatticeArgs filled in.
+int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cfg, int mode, int E, bool foot, bool cubic,
+                         double* d_pose_copy, bool* handled) {
+    *handled = false;
+    const int S = cfg->n_stations;
+    const int n_cand = cfg->cand_count > 0 ? cfg->cand_count : cfg->n_lookahead * cfg->n_width;
+    const double *d_poses = a.poses, *d_prev_theta = a.prev_theta;
+    double *d_all_traj = a.all_traj, *d_all_cost = a.all_cost;
+    double *d_steer = a.steer, *d_speed = a.speed, *d_best_cost = a.best_cost, *d_best_traj = a.best_traj;
+    int32_t *d_best_idx = a.best_idx, *d_status = a.status, *d_near_idx = a.near_idx;
+    float* d_best_traj32 = a.best_traj32;
+    // ---- mixed-precision schedule: f32 filter over every candidate-step, fp64 decision (see k_lattice_filter) -----------------
+    auto fin = [](double v) { return v == v && v < HUGE_VAL && v > -HUGE_VAL; };
+    const bool weights_finite = fin(cfg->w_length) && fin(cfg->w_max_kappa) && fin(cfg->w_mean_kappa) && fin(cfg->w_similarity);
+    // (an oriented footprint runs here only in the filter's clearance mode: decided below, before anything is launched)
+    double clear_ds_cap = 0.0, clear_dist = 0.0;
+    bool clear_ok = false;
+    int clear_r_eff = 0;
+    if (a.has_grid && cfg->check_collision && !a.goals && ctx->lattice_clear_r > 0 && ctx->lattice_clear_r <= 2) {
+        double la = 0.0, wd = 0.0;
+        for (int l = 0; l < cfg->n_lookahead; ++l) la = fmax(la, fabs(cfg->lookahead[l]));
+        for (int k = 0; k < cfg->n_width; ++k) wd = fmax(wd, fabs(cfg->width[k]));
+        const int den = S - 1 > 1 ? S - 1 : 1;
+        clear_ds_cap = 1.2 * hypot(la, wd) / (double)den;              // clothoids to the sampled goals are rarely longer; longer ones go to fp64
+        if (foot) {                                                    // + the rotation of the largest disc offset at a typical curvature bound
+            double mo = 0.0;
+            for (int d = 0; d < ctx->n_disc; ++d) mo = fmax(mo, fabs(ctx->disc_off[d]));
+            clear_ds_cap *= 1.0 + mo * 1.0;                            // kappa up to 1 / m without losing the clearance mode (sharper candidates: fp64)
+        }
+        // worthwhile while the clearance zone is small against the tile (a coarse map or very long candidates: a smaller r, then the plain test)
+        for (clear_r_eff = ctx->lattice_clear_r; clear_r_eff >= 1 && !clear_ok; --clear_r_eff) {
+            clear_dist = (double)clear_r_eff * clear_ds_cap * 1.001 * ctx->inv_res + 1.41422 + 1.0;
+            clear_ok = clear_dist == clear_dist && clear_dist <= 0.25 * (double)a.tile_rows;
+            if (clear_ok) break;
+        }
+    }
+    if (ctx->lattice_mixed && (!foot || clear_ok) && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
+        (E >= F1P_MIX_MIN_EGOS || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
+        const size_t tile_bytes = sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
+        size_t lds_f = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS) + sizeof(EgoParams) + sizeof(EgoParams32) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
+                       sizeof(float) * 4 + sizeof(int) * (2 + 64 + 256) + (size_t)n_cand * 5 + 16 + 2 * tile_bytes;
+        lds_f = (lds_f + 15) & ~(size_t)15;
+        const size_t lds_r16 = sizeof(double) * 16 * (64 + 4 * (size_t)S), lds_r64 = sizeof(double) * 4 * (64 + 4 * (size_t)S);
+        const size_t lds_r_static = 1024;                          // k_lattice_refine's static tables (s_gl_wu, s_gl_x) count against the same limit
+        const size_t lds_s = sizeof(double) * 16 * (size_t)S;
+        // every instantiation that may be launched below is checked (and configured for > 64 KB of dynamic LDS) by lds_fits -- the
+        // footprint variants included (only refine<64> had been, so a FOOT plan with > 496 stations could fail between the
+        // filter and the selection kernel and leave the queue counter armed)
+        const bool groups16 = foot ? lds_fits(ctx, k_lattice_refine<16, true>, lds_r16 + lds_r_static) : lds_fits(ctx, k_lattice_refine<16>, lds_r16 + lds_r_static);
+        const bool refine_fits = groups16 || (foot ? lds_fits(ctx, k_lattice_refine<64, true>, lds_r64 + lds_r_static) : lds_fits(ctx, k_lattice_refine<64>, lds_r64 + lds_r_static));
+        if (lds_fits(ctx, k_lattice_filter<0>, lds_f) && lds_fits(ctx, k_lattice_filter<1>, lds_f) && lds_fits(ctx, k_lattice_filter<2>, lds_f) && lds_fits(ctx, k_lattice_filter<1, true>, lds_f) && lds_fits(ctx, k_lattice_filter<2, true>, lds_f) && refine_fits && lds_fits(ctx, k_lattice_select, lds_s)) {
+            MixArgs mx;
+            mx.margin_rel = F1P_MIX_MARGIN_REL; mx.margin_abs = F1P_MIX_MARGIN_ABS; mx.edge0 = F1P_MIX_EDGE0; mx.edge1 = F1P_MIX_EDGE1;
+            if (ctx->dbg_margins) { mx.margin_rel = ctx->dbg_margin_rel; mx.margin_abs = ctx->dbg_margin_abs; }   // test hook (f1p_lattice_debug_margins)
+            mx.dbg_cost32 = ctx->d_dbg_lat_cost32; mx.dbg_state = ctx->d_dbg_lat_state; mx.dbg_bound = ctx->d_dbg_lat_bound;
+            {   // sum_{j < sim_m} j^2, j^3, j^4: exact in fp64 for every admissible station count (validate_lattice caps S)
+                double s2 = 0.0, s3 = 0.0, s4 = 0.0;
+                for (int j = 0; j < S - cfg->n_shift - cfg->n_cull; ++j) { const double fj = (double)j; s2 += fj * fj; s3 += fj * fj * fj; s4 += (fj * fj) * (fj * fj); }
+                mx.sim_s2 = s2; mx.sim_s3 = s3; mx.sim_s4 = s4;
+            }
+            // clearance mode of the filter's occupancy test (device-sampled goals: the station spacing is bounded by the configuration)
+            mx.clear_bits = nullptr; mx.clear_r = 0; mx.clear_ds_cap = 0.f;
+            mx.n_disc = 0;
+            for (int d = 0; d < 4; ++d) mx.disc_off[d] = 0.0;
+            if (clear_ok && ensure_clear_map(ctx, clear_dist) == F1P_OK) {
+                mx.clear_bits = ctx->d_bits_clear; mx.clear_r = clear_r_eff; mx.clear_ds_cap = (float)clear_ds_cap;
+                if (foot) { mx.n_disc = ctx->n_disc; for (int d = 0; d < 4; ++d) mx.disc_off[d] = ctx->disc_off[d]; }
+            }
+            const bool prof = ctx->lattice_profile && ctx->ev_prof[0];
+            const dim3 fb(F1P_MIX_FILTER_BLOCK);
+            // round 3: the rebuilt filter for the headline configuration (device-sampled goals, clearance mode, point footprint) ...
+            const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
+            // ... as two kernels (prologue: one wave per ego; filter3: candidates only)
+            const size_t rec_stride = ego_rec_stride(cfg->n_lookahead);
+            size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 4 + sizeof(int) * 4 + (size_t)n_cand * 5 + 16;
+            lds_f3 = (lds_f3 + 15) & ~(size_t)15;
+            const bool v3 = F1P_MIX_FILTER_V3 && !a.goals && mx.n_disc == 0 && (mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
+                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) : lds_fits(ctx, k_lattice_filter3<2>, lds_f3));
+            // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the
+            // first (it waits for the first prologue): one chunk's latency-bound kernels (prologue, refinement, selection: a few waves
+            // per SIMD) run beside the other's VALU-bound candidate kernel instead of after it.  Every chunk has its own queue region
+            // and counters; per-ego arrays are indexed by the absolute ego.  The caller's stream is joined at both ends, so the
+            // call keeps its in-order semantics.  Per-kernel profiling (f1p_lattice_profile) runs unpipelined.
+            int nch = 1;
+            if (v3 && !prof) nch = ctx->lattice_chunks > 0 ? ctx->lattice_chunks : (E >= F1P_PIPE_MIN_EGOS ? F1P_PIPE_CHUNKS : 1);
+            if (nch > 8) nch = 8;
+            int ce = ((E + nch - 1) / nch + 3) & ~3;                  // egos per chunk: the prologue / selection kernels take four egos per workgroup
+            if (ce < 4) ce = 4;
+            nch = (E + ce - 1) / ce;
+            const size_t shard_cap = (size_t)((ce + F1P_MIX_QSHARDS - 1) / F1P_MIX_QSHARDS + 1) * n_cand;   // egos e with e % shards == s, per chunk
+            const size_t region = shard_cap * F1P_MIX_QSHARDS;       // queue entries of one chunk
+            const size_t qc_chunk = sizeof(unsigned int) * 32 * F1P_MIX_QSHARDS;
+            const size_t qc_bytes = qc_chunk * 8;                    // counters of up to 8 chunks
+            // increment blocks for the first F1P_MIX_INC_PER_EGO entries per ego of every shard (the usual 1-2 entries per ego all get one)
+            size_t inc_cap = (size_t)((ce + F1P_MIX_QSHARDS - 1) / F1P_MIX_QSHARDS + 1) * F1P_MIX_INC_PER_EGO;
+            if (inc_cap > shard_cap) inc_cap = shard_cap;
+            const size_t inc_block = 2 * (size_t)(S > 0 ? S : 1) * sizeof(double);
+            const size_t inc_bytes = F1P_MIX_INC_PER_EGO > 0 ? inc_cap * F1P_MIX_QSHARDS * inc_block : 0;
+            const size_t need = qc_bytes + sizeof(int32_t) * 3 * (size_t)E + 256 + sizeof(EgoXform) * (size_t)E + 256 + sizeof(RefEntry) * region * nch + 256 + inc_bytes * nch;
+            bool fresh = false;
+            if (need > ctx->mix_scratch_bytes) {
+                fresh = true;
+                F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->d_mix_scratch) (void)hipFree(ctx->d_mix_scratch);
+                ctx->d_mix_scratch = nullptr; ctx->mix_scratch_bytes = 0;
+                F1P_HIP(ctx, hipMalloc((void**)&ctx->d_mix_scratch, need));
+                ctx->mix_scratch_bytes = need;
+            }
+            mx.qcount = reinterpret_cast<unsigned int*>(ctx->d_mix_scratch);
+            mx.q_shard_cap = (unsigned int)shard_cap;
+            mx.ego_base = reinterpret_cast<int32_t*>(ctx->d_mix_scratch + qc_bytes);
+            mx.ego_n = mx.ego_base + E; mx.ego_ni = mx.ego_n + E;
+            const size_t xf_off = (qc_bytes + sizeof(int32_t) * 3 * (size_t)E + 255) & ~(size_t)255;
+            mx.xf = reinterpret_cast<EgoXform*>(ctx->d_mix_scratch + xf_off);
+            mx.q = reinterpret_cast<RefEntry*>(ctx->d_mix_scratch + ((xf_off + sizeof(EgoXform) * (size_t)E + 255) & ~(size_t)255));
+            {
+                const size_t q_off = (xf_off + sizeof(EgoXform) * (size_t)E + 255) & ~(size_t)255;
+                const size_t inc_off = (q_off + sizeof(RefEntry) * region * nch + 255) & ~(size_t)255;
+                mx.inc = inc_bytes ? reinterpret_cast<double*>(ctx->d_mix_scratch + inc_off) : nullptr;
+                mx.inc_cap = (unsigned int)inc_cap;
+            }
+            // k_lattice_select re-arms the counters at the end of every plan; a plan that failed after its filter ran leaves them dirty
+            if (fresh || ctx->mix_q_dirty) F1P_HIP(ctx, hipMemsetAsync(mx.qcount, 0, qc_bytes, ctx->stream));
+            ctx->mix_q_dirty = true;                                 // until the selection kernels of THIS plan are enqueued
+            if (v3) {
+                const size_t need_rec = rec_stride * (size_t)E;
+                if (need_rec > ctx->rec_scratch_bytes) {
+                    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (ctx->d_rec_scratch) (void)hipFree(ctx->d_rec_scratch);
+                    ctx->d_rec_scratch = nullptr; ctx->rec_scratch_bytes = 0;
+                    F1P_HIP(ctx, hipMalloc((void**)&ctx->d_rec_scratch, need_rec));
+                    ctx->rec_scratch_bytes = need_rec;
+                }
+            }
+            if (nch > 1) {                                           // even chunks on the caller's stream, odd chunks on ONE side stream: two cross-stream edges per plan
+                if (!ctx->pipe_stream[0]) F1P_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[0], hipStreamNonBlocking));
+                for (int j = 0; j < 2; ++j) if (!ctx->ev_pipe[j]) F1P_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe[j], hipEventDisableTiming));
+            }
+            if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[0], ctx->stream));
+            if (prof && !v3) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[1], ctx->stream));   // no separate prologue kernel: an empty interval
+            const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+            int rc = F1P_OK;
+            for (int k = 0; k < nch && rc == F1P_OK; ++k) {
+                hipStream_t st = (k & 1) ? ctx->pipe_stream[0] : ctx->stream;
+                LatticeArgs ak = a;
+                ak.e0 = k * ce; ak.E = ak.e0 + ce < E ? ak.e0 + ce : E;
+                const int Ek = ak.E - ak.e0;
+                MixArgs mk = mx;
+                mk.qcount = mx.qcount + (size_t)k * 32 * F1P_MIX_QSHARDS;
+                mk.q = mx.q + (size_t)k * region;
+                if (mx.inc) mk.inc = mx.inc + (size_t)k * (inc_bytes / sizeof(double));
+                if (v3) {
+                    ak.pose_copy = d_pose_copy;
+                    hipLaunchKernelGGL(k_lattice_prologue, dim3((Ek + 3) / 4), dim3(256), 0, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
+                    if (d_pose_copy) { ak.poses = d_pose_copy; ak.pose_copy = nullptr; }      // the kernels behind the prologue read HBM
+                    if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[1], st));
+                    if (nch > 1 && k == 0) {                         // the side stream starts one stage behind (and after everything the caller enqueued before this plan)
+                        F1P_HIP(ctx, hipEventRecord(ctx->ev_pipe[0], st));
+                        F1P_HIP(ctx, hipStreamWaitEvent(ctx->pipe_stream[0], ctx->ev_pipe[0], 0));
+                    }
+                    const unsigned f3_grid = (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
+                    if (mk.clear_r == 1) hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                    else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                }
+                else if (mk.n_disc > 0 && mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter<1, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
+                else if (mk.n_disc > 0 && mk.clear_r == 2) hipLaunchKernelGGL((k_lattice_filter<2, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
+                else if (mk.clear_r == 1) hipLaunchKernelGGL(k_lattice_filter<1>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
+                else if (mk.clear_r == 2) hipLaunchKernelGGL(k_lattice_filter<2>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
+                else hipLaunchKernelGGL(k_lattice_filter<0>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
+                if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_filter launch"))) break;
+                if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[2], st));
+                size_t rb = (region + 3) / 4;                            // grid-stride over the queue: a few entries per ego in the usual case
+                rb = (rb + 15) & ~(size_t)15;                            // groups (4 or 16 per workgroup) a multiple of the shard count
+                const size_t rb_max = (size_t)cus * (groups16 ? 4 : 8) / (nch > 1 ? 2 : 1);
+                if (rb > rb_max) rb = rb_max;
+                rb = rb & ~(size_t)15;
+                if (rb < 16) rb = 16;
+                if (groups16) {
+                    if (mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine<16, true>), dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
+                    else hipLaunchKernelGGL(k_lattice_refine<16>, dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
+                } else {
+                    if (mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine<64, true>), dim3((unsigned)rb), dim3(256), lds_r64, st, ak, *cfg, mk);
+                    else hipLaunchKernelGGL(k_lattice_refine<64>, dim3((unsigned)rb), dim3(256), lds_r64, st, ak, *cfg, mk);
+                }
+                if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_refine launch"))) break;
+                if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[3], st));
+                hipLaunchKernelGGL(k_lattice_select, dim3((Ek + 3) / 4), dim3(256), lds_s, st, ak, *cfg, mk);
+                rc = check_hip(ctx, hipGetLastError(), "k_lattice_select launch");
+            }
+            if (nch > 1) {                                           // join: the caller's stream continues after the side stream
+                F1P_HIP(ctx, hipEventRecord(ctx->ev_pipe[1], ctx->pipe_stream[0]));
+                F1P_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pipe[1], 0));
+            }
+            if (rc == F1P_OK) ctx->mix_q_dirty = false;
+            if (prof && rc == F1P_OK) { F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[4], ctx->stream)); ctx->lattice_profile_valid = true; }
+            // runtime audit (f1p_lattice_set_audit): this plan's outputs on a window of egos against the all-fp64 exhaustive kernel
+            if (rc == F1P_OK && ctx->audit_every > 0 && !ctx->auditing && mode == LATTICE_FULL && !a.goals && cfg->cand_count == 0) {
+                if (ctx->audit_plans++ % (unsigned long long)ctx->audit_every == 0)
+                    rc = lattice_audit(ctx, d_poses, d_prev_theta, E, cfg, d_steer, d_speed, d_best_idx, d_best_cost, d_status, d_near_idx, d_best_traj, d_best_traj32);
+            }
+            *handled = true;
+            return rc;
+        }
+    }
+    return F1P_OK;
+}
+
+}  // namespace f1p

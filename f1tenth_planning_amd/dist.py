@@ -71,8 +71,18 @@ def argmin_allreduce(cost, idx, group=None):
 def init_rccl(ctx, rank, world, group=None):
     """Create the RCCL communicator of `ctx`: rank 0 draws the unique id, torch.distributed (any backend) broadcasts it."""
     import torch.distributed as dist
-    box = [ctx.comm_unique_id() if rank == 0 else None]
+    # rank 0 ALWAYS completes the broadcast -- with the id, or with the error that kept it from drawing one (librccl missing, a dlsym
+    # failure): a rank 0 that raised before it would leave the other ranks inside broadcast_object_list while it moves on to the next
+    # collective of the same group, i.e. mismatched collectives (ADVICE r3); every rank then raises the same error
+    box = [None]
+    if rank == 0:
+        try:
+            box = [ctx.comm_unique_id()]
+        except Exception as exc:   # noqa: BLE001 -- travels to every rank and is raised there
+            box = [("error", f"{type(exc).__name__}: {exc}")]
     dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], tuple) and box[0] and box[0][0] == "error":
+        raise RuntimeError("rank 0 could not create the RCCL unique id: " + box[0][1])
     ctx.comm_init(box[0], world, rank)
 
 

@@ -604,6 +604,18 @@ class Context:
         self._check(self.lib.f1p_comm_info(self.h, C.byref(n), C.byref(r)))
         return n.value, r.value
 
+    def comm_set_exchange(self, mode=0):
+        """form of the cross-rank argmin: 0 = two RCCL all-reduces (default), 1 = one all-gather of (key, index) + a local minimum"""
+        self._check(self.lib.f1p_comm_set_exchange(self.h, int(mode)))
+
+    def argmin_gather_reduce(self, cost, idx):
+        """the local kernels of exchange form 1 on N emulated ranks: cost / idx [N, E] -> (idx [E], cost [E])"""
+        cost = _f64(cost); idx = np.ascontiguousarray(idx, np.int32)
+        N, E = cost.shape
+        io = np.empty(E, np.int32); co = np.empty(E)
+        self._check(self.lib.f1p_argmin_gather_reduce_batch(self.h, _ptr(cost), _ptr(idx), N, E, _ptr(io), _ptr(co)))
+        return io, co
+
     def comm_argmin_dev(self, d_cost, d_idx, E):
         self._check(self.lib.f1p_comm_argmin_dev(self.h, d_cost.ptr, d_idx.ptr, int(E)))
 

@@ -513,6 +513,13 @@ int f1p_comm_info(f1p_ctx* ctx, int32_t* nranks, int32_t* rank);
  * np.argmin's ordering including its NaN rule (a NaN cost wins, the first one by index): the cost is reduced as a
  * monotone unsigned 64-bit key (NaN -> 0), so both collectives are integer all-reduce(min) and every rank agrees. */
 int f1p_comm_argmin_dev(f1p_ctx* ctx, double* d_cost, int32_t* d_idx, int32_t E);
+/* Form of the exchange inside f1p_comm_argmin_dev.  0 (default): two dependent RCCL all-reduces -- min over the u64 cost keys, then min over
+ * the i32 indices of the ranks holding that key (12 B per ego on the wire, two collective latencies).  1: ONE all-gather of (key, index)
+ * records (16 B per ego and rank) and a local minimum by the same (key, index) order on every rank -- the same result bit for bit, one
+ * collective latency; the better trade once the exchange is latency-bound (4096 egos x 8 ranks = 512 KB gathered per rank).
+ * f1p_argmin_gather_reduce_batch runs the local kernels of form 1 on host arrays of N emulated ranks (cost / idx [N][E]): the test hook. */
+int f1p_comm_set_exchange(f1p_ctx* ctx, int32_t mode);
+int f1p_argmin_gather_reduce_batch(f1p_ctx* ctx, const double* cost, const int32_t* idx, int32_t N, int32_t E, int32_t* idx_out, double* cost_out);
 /* The two local steps of that exchange on host arrays (the collective in between is the caller's), so the key map can be
  * checked against np.argmin on a single GPU:  keys [E] <- key(cost);  masked_idx [E] <- idx where own_keys == min_keys
  * else INT32_MAX, cost_out [E] <- the cost min_keys encodes. */

@@ -133,6 +133,7 @@ rank = int(os.environ["RANK"]); case = os.environ["F1P_CASE"]
 
 class Stub:                                   # the two calls Ranks.init_rccl makes on a context
     def comm_unique_id(self):
+        if case == "raise_id": raise RuntimeError("stub: librccl.so not found")     # rank 0 fails BEFORE the broadcast
         return b"u" * 128
     def comm_init(self, uid, nranks, r):
         assert bytes(uid) == b"u" * 128 and nranks == 2 and r == rank
@@ -173,6 +174,9 @@ def test_bench_ranks_agree_on_the_communicator():
     bad = _run_rccl_case("raise", 60)
     assert not bad[0]["ok"] and not bad[1]["ok"] and not bad[0]["hung"] and not bad[1]["hung"]
     assert "another rank" in bad[0]["note"] and "stub: no communicator" in bad[1]["note"]
+    early = _run_rccl_case("raise_id", 60)        # rank 0 raises before the id broadcast: a clean skip on BOTH ranks, promptly
+    assert not early[0]["ok"] and not early[1]["ok"] and not early[0]["hung"] and not early[1]["hung"]
+    assert "librccl.so not found" in early[0]["note"] and "librccl.so not found" in early[1]["note"]
     hung = _run_rccl_case("hang", 3)
     assert not hung[0]["ok"] and not hung[1]["ok"] and hung[1]["hung"] and not hung[0]["hung"]
     assert "did not return" in hung[1]["note"]

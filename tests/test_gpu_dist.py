@@ -93,13 +93,23 @@ def test_exchange_kernels_follow_np_argmin_with_nan_inf_and_ties():
         gmin = keys.min(axis=0)
         res = [ctx.argmin_mask(keys[r], gmin, idx[r]) for r in range(W)]
         got_i = np.minimum.reduce([m for m, _ in res]); got_c = res[0][1]
-        # 1-rank communicator: the collective path itself with NaN / inf costs (identity on one rank)
+        # the single-collective form (f1p_comm_set_exchange 1): pack + local reduction over the 8 emulated ranks' records
+        ag_i, ag_c = ctx.argmin_gather_reduce(cost, idx)
+        # 1-rank communicator: the collective path itself with NaN / inf costs (identity on one rank), both forms
         _one_rank_comm_or_skip(ctx, stack)
-        d_c, d_i = ctx.to_device(cost[3]), ctx.to_device(idx[3])
-        ctx.comm_argmin_dev(d_c, d_i, E)
-        one_c = d_c.download(np.float64, (E,)); one_i = d_i.download(np.int32, (E,))
-    np.testing.assert_array_equal(one_i, idx[3])
-    assert np.array_equal(one_c, cost[3], equal_nan=True)
+        ones = []
+        for mode in (0, 1):
+            ctx.comm_set_exchange(mode)
+            d_c, d_i = ctx.to_device(cost[3]), ctx.to_device(idx[3])
+            ctx.comm_argmin_dev(d_c, d_i, E)
+            ones.append((d_c.download(np.float64, (E,)), d_i.download(np.int32, (E,))))
+        ctx.comm_set_exchange(0)
+    for one_c, one_i in ones:
+        np.testing.assert_array_equal(one_i, idx[3])
+        c3 = np.where(cost[3] == 0.0, 0.0, cost[3])           # (-0.0 and +0.0 are one key: np.argmin treats them as equal)
+        assert np.array_equal(np.where(one_c == 0.0, 0.0, one_c), c3, equal_nan=True)
+    np.testing.assert_array_equal(ag_i, got_i)
+    assert np.array_equal(ag_c, got_c, equal_nan=True)
     for e in range(E):                                        # np.argmin over all ranks' candidates in index order
         order = np.argsort(idx[:, e], kind="stable")
         j = order[int(np.argmin(cost[order, e]))]
@@ -180,13 +190,13 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
     assert line["multi_process_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "zero_on_every_rank": True}
     if workload == "lattice":
-        assert line["rccl_ranks"] == 2 and line["exchange_us_p50"] > 0
+        assert line["rccl_ranks"] is None and line["exchange_us_p50"] > 0     # no RCCL communicator exists under the test hook: null, not the world size
         assert line["scaling"] == "weak" and line["config"]["egos_per_gpu"] == 4096
         assert abs(line["value"] - 2 * line["per_gpu_value"]) < 1e-6 * line["value"]
         # the candidate-sharded leg with TWO real ranks (each evaluates its half of the 512 candidates, host stand-in for the collective):
         # every rank's seven outputs bit-identical to the unsharded plan; the exchange rule against np.argmin incl. NaN costs
         cs = line["candidate_sharded"]
-        assert cs["rccl_ranks"] == 2 and cs["candidates_per_rank"] == 256 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
+        assert cs["rccl_ranks"] is None and cs["ranks"] == 2 and cs["candidates_per_rank"] == 256 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
         assert line["exchange_selftest"]["matches_np_argmin_on_every_rank"] is True and line["exchange_selftest"]["nan_costs"] > 0
         assert line["kmpc_c4"]["generated_in_kernel"]["rollout_steps_per_s"] > 0
 
@@ -205,4 +215,4 @@ def test_candidate_sharded_mode_with_two_ranks_on_one_gpu():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     cs = line["candidate_sharded"]
-    assert cs["rccl_ranks"] == 2 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
+    assert cs["rccl_ranks"] is None and cs["ranks"] == 2 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
