@@ -959,6 +959,15 @@ int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side) {
     return F1P_OK;
 }
 
+int f1p_lattice_debug_queue(f1p_ctx* ctx, int32_t* entries_per_ego, int32_t E) {
+    F1P_ENTER(ctx);
+    if (!entries_per_ego || E < 1) return set_error(ctx, F1P_EINVAL, "entries_per_ego is NULL or E < 1");
+    if (!ctx->d_mix_scratch || ctx->mix_last_E != E) return set_error(ctx, F1P_ESTATE, "no mixed-schedule plan of this batch size has run");
+    F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    F1P_HIP(ctx, hipMemcpy(entries_per_ego, ctx->d_mix_scratch + ctx->mix_ego_n_off, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost));
+    return F1P_OK;
+}
+
 int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound) {
     if (!ctx) return F1P_EINVAL;
     ctx->d_dbg_lat_bound = d_bound;

@@ -75,6 +75,8 @@ struct f1p_ctx {
     int lattice_mixed = 1;
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;
+    int mix_last_E = 0;                // batch size of the last mixed-schedule plan (f1p_lattice_debug_queue)
+    size_t mix_ego_n_off = 0;          // byte offset of its ego_n [E] array in d_mix_scratch
     char* d_rec_scratch = nullptr;     // per-ego records of k_lattice_prologue
     size_t rec_scratch_bytes = 0;
     // runtime audit of the mixed schedule (f1p_lattice_set_audit): every audit_every-th mixed plan re-plans a random window of

@@ -427,6 +427,12 @@ class Context:
         """f32 filter's occupancy test: one station in 2 r + 1 against the clearance map (r > 0) or every station against the bitmap (0)"""
         self._check(self.lib.f1p_lattice_set_clearance(self.h, int(stations_each_side)))
 
+    def lattice_debug_queue(self, E):
+        """entries per ego the last mixed-schedule plan of E egos handed to the fp64 refinement (numpy int32 [E])"""
+        out = np.empty(int(E), np.int32)
+        self._check(self.lib.f1p_lattice_debug_queue(self.h, _ptr(out), int(E)))
+        return out
+
     def lattice_debug_bound(self, d_bound=None):
         """test hook: [E][C] f32 device buffer for the f32 filter's per-candidate a-priori cost error bounds (None = off)"""
         self._check(self.lib.f1p_lattice_debug_bound(self.h, None if d_bound is None else d_bound.ptr))

@@ -352,6 +352,9 @@ int f1p_lattice_audit_read(f1p_ctx* ctx, uint64_t out[3], int32_t reset);
  * while enable != 0.  Margins below the filter's real error (e.g. negative ones) make the mixed schedule return WRONG winners:
  * that is what tests/test_gpu_audit.py uses it for -- to show that the audit above fires.  enable = 0 restores the defaults. */
 int f1p_lattice_debug_margins(f1p_ctx* ctx, int32_t enable, float margin_rel, float margin_abs);
+/* TEST / MEASUREMENT HOOK: entries_per_ego [E] (host) <- how many candidates of each ego the LAST mixed-schedule plan of E egos handed to the
+ * fp64 refinement (the f32 winner plus whatever the brackets could not rank; synchronises the stream). */
+int f1p_lattice_debug_queue(f1p_ctx* ctx, int32_t* entries_per_ego, int32_t E);
 /* TEST HOOK: d_bound [E][C] f32 (device pointer, nullable) receives every candidate's A-PRIORI cost error bound of the following
  * mixed plans (the running bound of DESIGN.md 5c that widens the candidate's bracket when it exceeds the calibrated margin); the tests
  * check bound >= |cost32 - cost64| candidate by candidate. */

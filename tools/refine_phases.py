@@ -9,7 +9,7 @@ E, C, S = 4096, 256, 50
 rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
 poses = synth.make_egos(rl, E, seed=1)
 cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
-names = ["queue count + entry load", "fp64 fit", "xform + interval increments", "prefix sums + occupancy reads", "cost terms + reduce + store"]
+names = ["queue count + entry load", "fp64 fit", "xform + interval increments", "prefix sums + occupancy reads", "cost terms + reduce + store/publish + ticket", "selection: argmin / winner data", "selection: emit + track"]
 with Context(0) as ctx:
     ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
     d_poses = ctx.to_device(poses)
@@ -18,9 +18,11 @@ with Context(0) as ctx:
     ctx.lattice_set_mode(2, d_c, d_s)
     for _ in range(5): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
     st = d_s.download(np.int32, (E * C // 8, 8))
-    ok = st[:, 7] == 6
-    ph = st[ok][:, :5].astype(np.float64)
+    ok = st[:, 7] >= 6
+    npz = int(st[ok][:, 7].max()) - 1
+    ph = st[ok][:, :npz].astype(np.float64)
     print("entries stamped:", int(ok.sum()))
     tot = ph.sum(1).mean()
-    for k in range(5): print(f"{names[k]:34s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %")
-    print(f"entry lifetime {tot:.0f} ticks")
+    for k in range(ph.shape[1]): print(f"{names[k]:48s} {ph[:, k].mean():8.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %   p99 {np.percentile(ph[:, k], 99):8.0f}  max {ph[:, k].max():8.0f}")
+    life = ph.sum(1)
+    print(f"entry lifetime mean {tot:.0f} ticks, p90 {np.percentile(life, 90):.0f}, p99 {np.percentile(life, 99):.0f}, max {life.max():.0f}")
