@@ -71,9 +71,6 @@ namespace f1p {
 #ifndef F1P_MIX_FILTER_V3
 #define F1P_MIX_FILTER_V3 1          // prologue + candidate kernel (k_lattice_prologue, k_lattice_filter3) where it applies; 0: the one-kernel k_lattice_filter everywhere (A/B builds)
 #endif
-#ifndef F1P_MIX_FUSE_SELECT
-#define F1P_MIX_FUSE_SELECT 0        // the selection inside k_lattice_refine (see group16_ballot); 0: k_lattice_select as its own kernel (A/B builds)
-#endif
 #ifndef F1P_MIX_F3_EGOS_PER_WG
 #define F1P_MIX_F3_EGOS_PER_WG 1     // egos a k_lattice_filter3 workgroup evaluates one after the other (grid = egos / this)
 #endif
@@ -141,7 +138,6 @@ struct MixArgs {
     int32_t* ego_base;            // [E] first entry of the ego
     int32_t* ego_n;               // [E] number of entries
     int32_t* ego_ni;              // [E] nearest raceline segment
-    unsigned int* ego_done;       // [E] tickets of the fused selection: entries of the ego whose refinement is finished (zeroed by k_lattice_prologue)
     struct EgoXform* xf;          // [E] ego -> tile-relative cell transform (fp64; written by the filter's setup thread, read by k_lattice_refine)
     const uint32_t* clear_bits;   // clearance map of the collision bitmap (k_grid.hip ensure_clear_map) when clear_r > 0
     int clear_r;                  // a tested station in a clear cell proves clear_r stations on each side free (0: every station against the bitmap)
@@ -1202,11 +1198,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     __shared__ int s_pairs[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = a.e0 + blockIdx.x * 4 + wave;
-    // the refinement queue's counters and the selection tickets are re-armed here, ahead of the kernels that count with them (the
-    // fused refinement + selection has no kernel behind it to do it, as k_lattice_select did)
-    if (blockIdx.x == 0 && threadIdx.x < F1P_MIX_QSHARDS) mx.qcount[threadIdx.x * 32u] = 0u;
     if (e >= a.E) return;                                        // wave-uniform
-    if (lane == 0 && mx.ego_done) mx.ego_done[e] = 0u;
     const int nl = cfg.n_lookahead, S = cfg.n_stations;
     double* cen_x = s_cen[wave]; double* cen_y = cen_x + F1P_MAX_LOOKAHEADS; double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
     int* cen_ok = s_ok[wave];
@@ -1519,164 +1511,6 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 // Per-ego constants of the fp64 occupancy test (the tile-relative cell arithmetic of k_lattice step 3, folded as in EgoParams)
 
 
-// ---------------------------------------------------------------------------------------------------
-// Round 4: the SELECTION fused into the refinement (k_lattice_refine<16, FOOT, true>).  78 % of the egos of the bench scene hand exactly
-// ONE candidate to the refinement (tools/queue_stats.py: mean 1.5, 98 % <= 4, a 1 % tail of wall-hugging egos with 50-200): the 16-lane
-// group that refined it holds everything the selection needs -- cost, clothoid, station positions -- so it emits the winner's rows and
-// tracks them itself, with no hand-over through memory and no second kernel (k_lattice_select re-read all of it: entry costs, the
-// winner's record, its position block -- three dependent round trips of a lone wave, ~10 us per plan).  An ego with several entries
-// counts its finished entries with a ticket; the group that takes the LAST ticket selects: np.argmin's rule over the ego's entries, the
-// winner's clothoid and positions from the winner's own group through memory.  Inter-workgroup visibility follows the guide's rules
-// (cdna_hip_programming.md, Guideline 16): the payload is stored write-through (relaxed agent-scope atomic stores, 8 B each), every
-// storing wave drains its stores (s_waitcnt vmcnt(0)) before its ticket (agent-scope atomic add), and the selector reads other groups'
-// data with agent-scope atomic loads only -- never through a possibly stale cache line.  The tickets are zeroed by k_lattice_prologue.
-// The 16-lane tracker below is wave_pursuit / wave_intersect (f1p_device.h) lane for lane -- the scan advances 16 segments per step
-// instead of 64, the first hit in scan order is the same -- so steering and speed are the same bits.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned group16_ballot(bool p, int gbase) { return (unsigned)((__ballot(p) >> gbase) & 0xffffull); }
-
-__device__ __forceinline__ void group16_argmin(double& d, int& i) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-        const double od = shfl_xor_d(d, m);
-        const int oi = __shfl_xor(i, m, F1P_WAVE);
-        if (argmin_better(od, oi, d, i)) { d = od; i = oi; }
-    }
-}
-
-__device__ __forceinline__ void st_agent(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double* p) {
-    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ int ld_agent_i(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// intersect_point(origin, radius, path, tstart, wrap = True) by groups of 16 lanes; `act`: this group takes part (group-uniform).
-// wave_intersect's scan order and hit rule; every lane of an active group returns the same result.
-__device__ __forceinline__ Intersect group16_intersect(bool act, int gl, int gbase, double radius, const double* wx, const double* wy, int n, double tstart) {
-    const int start_i = (int)tstart;
-    const double start_t = tstart - __builtin_trunc(tstart);
-    Intersect r;
-    r.found = false; r.i = 0; r.t = 0.0; r.x = 0.0; r.y = 0.0;
-    bool scanning = act;
-    for (int base = start_i; __any(scanning && base < n - 1); base += 16) {            // :84
-        const int i = base + gl;
-        SegHit h;
-        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
-        if (scanning && i < n - 1) h = seg_hit(0.0, 0.0, radius, wx[i], wy[i], wx[i + 1], wy[i + 1], i == start_i, start_t);
-        const unsigned m = group16_ballot(h.hit, gbase);
-        if (scanning && m) {
-            const int first = __ffs((int)m) - 1;
-            r.found = true; r.i = base + first;
-            r.t = shfl_d(h.t, gbase + first); r.x = shfl_d(h.x, gbase + first); r.y = shfl_d(h.y, gbase + first);
-            scanning = false;
-        }
-        if (base + 16 >= n - 1) scanning = false;
-    }
-    scanning = act && !r.found;                                                           // :124-149, the wrap loop
-    for (int base = -1; __any(scanning && base < start_i); base += 16) {
-        const int i = base + gl;
-        SegHit h;
-        h.hit = false; h.t = 0; h.x = 0; h.y = 0;
-        if (scanning && i < start_i) {
-            const int i0 = i < 0 ? i + n : i;
-            int i1 = i + 1; if (i1 >= n) i1 -= n;
-            h = seg_hit(0.0, 0.0, radius, wx[i0], wy[i0], wx[i1], wy[i1], false, 0.0);
-        }
-        const unsigned m = group16_ballot(h.hit, gbase);
-        if (scanning && m) {
-            const int first = __ffs((int)m) - 1;
-            r.found = true; r.i = base + first;                                           // may be -1
-            r.t = shfl_d(h.t, gbase + first); r.x = shfl_d(h.x, gbase + first); r.y = shfl_d(h.y, gbase + first);
-            scanning = false;
-        }
-        if (base + 16 >= start_i) scanning = false;
-    }
-    return r;
-}
-
-// steps 6-7 of the plan for ONE ego by a group of 16 lanes: emit_and_track<F1P_GEN_CLOTHOID, true> (lattice_device.h) with the stations
-// dealt over 16 lanes.  tr_x / tr_y [S] (LDS): the winner's station positions (zeros when !cl.ok).  `act` is group-uniform.
-__device__ __forceinline__ void group16_emit_and_track(bool act, const LatticeArgs& a, const f1p_lattice_cfg& cfg, int e, int gl, int gbase, int ni,
-                                                       const Clothoid& cl, double bc, const double* tr_x, const double* tr_y) {
-    const int S = cfg.n_stations;
-    const int den = S - 1 > 1 ? S - 1 : 1;
-    if (act) {
-        double* bt = a.best_traj ? a.best_traj + (size_t)e * S * 4 : nullptr;
-        float4* bt32 = a.best_traj32 ? reinterpret_cast<float4*>(a.best_traj32) + (size_t)e * S : nullptr;
-        double* tho = a.theta_out ? a.theta_out + (size_t)e * S : nullptr;
-        const double ds = cl.ok ? cl.L / (double)den : 0.0;
-        if (bt || bt32 || tho) {
-            for (int i = gl; i < S; i += 16) {
-                const double x = tr_x[i], y = tr_y[i];
-                const double s = (double)i * ds;
-                const double th = cl.ok ? s * (cl.k0 + 0.5 * s * cl.dk) : 0.0;
-                const double ak = cl.ok ? fabs(cl.k0 + cl.dk * s) : 0.0;
-                if (bt) {
-                    reinterpret_cast<double2*>(bt)[2 * i] = make_double2(x, y);
-                    reinterpret_cast<double2*>(bt)[2 * i + 1] = make_double2(th, ak);
-                }
-                if (bt32) bt32[i] = make_float4((float)x, (float)y, (float)th, (float)ak);
-                if (tho) tho[i] = th;
-            }
-        }
-    }
-    // ---- 7. track the winner: PurePursuitPlanner.plan(0, 0, 0, L, best_traj) in the ego frame -----------------------------------
-    const bool trk = act && cl.ok && bc < __builtin_huge_val();
-    // nearest_point of the origin on a path that starts at the origin is (segment 0, t = 0, d = 0) by the arithmetic itself (see
-    // emit_and_track); a non-finite vertex or a zero-length segment takes the scan
-    bool plain = true;
-    if (trk) {
-        for (int i = gl; i < S - 1; i += 16) {
-            const double ax = tr_x[i], ay = tr_y[i], dx = tr_x[i + 1] - ax, dy = tr_y[i + 1] - ay;
-            const double l2 = dx * dx + dy * dy;
-            plain &= (l2 > 0.0) & (l2 < __builtin_huge_val()) & (fabs(ax) < __builtin_huge_val()) & (fabs(ay) < __builtin_huge_val());
-        }
-    }
-    plain = group16_ballot(!plain, gbase) == 0u;
-    if (trk) plain = plain && tr_x[0] == 0.0 && tr_y[0] == 0.0 && S >= 2;
-    double td = 0.0, tt = 0.0; int ti = 0;
-    if (__any(trk && !plain)) {
-        const bool sc = trk && !plain;
-        double bd = __builtin_huge_val(); int bi = 0x7fffffff;
-        if (sc) nearest_scan(0.0, 0.0, tr_x, tr_y, S, gl, 16, bd, bi);
-        group16_argmin(bd, bi);
-        if (sc) {
-            const SegProj ts = seg_project(0.0, 0.0, tr_x[bi], tr_y[bi], tr_x[bi + 1], tr_y[bi + 1]);
-            ti = bi; tt = ts.t; td = ts.d;
-        }
-    }
-    // wave_pursuit (f1p_device.h) at pose (0, 0, 0), constant speed column
-    Track o;
-    o.steer = 0.0; o.speed = 0.0; o.la_idx = F1P_LA_NONE; o.status = F1P_ST_ALL_BLOCKED;
-    const bool want_int = trk && td < cfg.track_lookahead;                               // pure_pursuit.py:70
-    const Intersect it = group16_intersect(want_int, gl, gbase, cfg.track_lookahead, tr_x, tr_y, S, (double)ti + tt);
-    if (trk) {
-        const double v_const = a.wv[ni];
-        o.status = F1P_ST_NO_LOOKAHEAD;
-        double cx = 0.0, cy = 0.0;
-        bool have = false;
-        if (want_int) {
-            if (it.found) {                                                              // :71-78
-                o.la_idx = it.i;
-                const int r = it.i < 0 ? it.i + S : it.i;
-                cx = tr_x[r]; cy = tr_y[r]; have = true;
-                o.status = F1P_ST_INTERSECT;
-            }
-        } else if (td < cfg.max_reacquire) {                                             // :80-81
-            cx = tr_x[ti]; cy = tr_y[ti]; have = true;
-            o.status = F1P_ST_REACQUIRE;
-        }
-        if (have) get_actuation(0.0, cx, cy, v_const, 0.0, 0.0, cfg.track_lookahead, cfg.wheelbase, o.speed, o.steer);   // :116-120
-    }
-    if (act && gl == 0) {
-        a.steer[e] = o.steer;
-        a.speed[e] = o.speed;
-        if (a.status) a.status[e] = o.status;
-    }
-}
-
 // WAVE per queue entry: the fp64 evaluation of k_lattice for that candidate -- the arithmetic of k_lattice in the same order,
 // hence the same bits -- with the independent parts spread over the 64 lanes instead of run as one 6000-instruction chain:
 //   * fit: every lane runs the scalar prologue (g1_begin); lane j evaluates quadrature node j (phase, sincos_core); lanes 0..11
@@ -1693,23 +1527,19 @@ __device__ __forceinline__ void group16_emit_and_track(bool act, const LatticeAr
 // GS = lanes per entry: 16 (four entries per wave: the scalar prologue / epilogue -- atan2, the model's Newton steps, interval_setup, the
 // sequential sums -- is a third of the work and is shared by four entries then) or 64 (one wave per entry: when four per-entry LDS
 // blocks per wave do not fit, i.e. very long station counts).  Lanes of a group hold identical per-entry values.
-// FUSE (GS = 16 only): the selection runs in this kernel (see above); per-group LDS grows by the two position arrays the tracker reads.
-template <int GS, bool FOOT = false, bool FUSE = false>
+template <int GS, bool FOOT = false>
 __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
-    static_assert(!FUSE || GS == 16, "the fused selection is written for groups of 16 lanes");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int GPW = 64 / GS;                                 // groups (entries) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
     const int S = cfg.n_stations;
-    double* ncs = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * (64 + (FUSE ? 6 : 4) * (size_t)S);   // [32] cos at the nodes
+    double* ncs = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * (64 + 4 * (size_t)S);   // [32] cos at the nodes
     double* nsn = ncs + 32;                                                                    // [32] sin at the nodes
     double* inc_x = nsn + 32;                                                                  // [S]
     double* inc_y = inc_x + S;                                                                 // [S]
     double* akv = inc_y + S;                                                                   // [S] |kappa| per station (station positions x before the cost phase)
     double* simv = akv + S;                                                                    // [S] similarity term per station (station positions y before the cost phase)
-    double* pos_x = FUSE ? simv + S : akv;                                                     // [S] station positions: arrays of their own when the selection
-    double* pos_y = FUSE ? pos_x + S : simv;                                                   //     (tracker) reads them after the cost phase
     // the 16-node rule's nodes and weight table (the rule of all but pathological goals) in LDS, once per workgroup: a lane's
     // sixteen-step moment chain then reads its operands from LDS with all reads in flight together -- from constant memory every step was
     // a dependent global round trip (16 x ~500 cycles: most of the fit's time, tools/refine_phases.py)
@@ -1719,7 +1549,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
     __syncthreads();
 #ifdef F1P_MIX_PHASES
-    long long rph[10]; int nrp = 0;
+    long long rph[8]; int nrp = 0;
 #define F1P_RPH() do { rph[nrp++] = clock64(); } while (0)
 #else
 #define F1P_RPH() do {} while (0)
@@ -1749,8 +1579,6 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         const int e = r.e;
         const bool check_occ = collide_on && r.ok != -2;
         // what the station phases need from memory is requested now, behind the entry, and arrives while the fit runs
-        int n_e = 1, ni_e = 0, base_e = 0;
-        if (FUSE && live) { n_e = mx.ego_n[e]; ni_e = mx.ego_ni[e]; base_e = mx.ego_base[e]; }
         EgoXform xf = {};
         if (work && check_occ) xf = mx.xf[e];                        // the ego -> tile-relative cell transform of the filter's setup thread (fp64)
         const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
@@ -1874,9 +1702,8 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         // the station increments: needed here by the occupancy pass, and by k_lattice_select for whichever entry wins -- handed over
         // through mx.inc (the selection's own interval_setup + piece_state_at + interval_increment was 41 % of its wave's lifetime);
         // an entry the filter proved collision-free computes them only for that hand-over, beside the other groups' occupancy passes
-        // FUSE: the positions are needed in LDS by this group's own selection; the block in memory only by ANOTHER group's (egos with several entries)
-        const bool store_inc = run && mx.inc != nullptr && li < mx.inc_cap && (!FUSE || n_e > 1);
-        const bool inc_pass = FUSE ? run : (occ_pass || store_inc);
+        const bool store_inc = run && mx.inc != nullptr && li < mx.inc_cap;
+        const bool inc_pass = occ_pass || store_inc;
         if (__any(inc_pass)) {
             if (inc_pass) {
                 const IntervalCoef ic = interval_setup(k0, dk, L, ds);
@@ -1899,6 +1726,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
             // the station POSITIONS go to the selection (mx.inc block of this entry: x [S] | y [S]): its own running sums over the increments
             // were a third of its instructions
             double* gp = store_inc ? mx.inc + ((size_t)sh * mx.inc_cap + li) * 2 * (size_t)S : nullptr;
+            double* pos_x = akv; double* pos_y = simv;               // (free until the cost phase)
             if (inc_pass) {
                 // positions by the evaluation loop's own running sums (x_q = ((inc_0 + inc_1) + ...) + inc_{q-1}), formed ONCE per entry and
                 // left in LDS.  Eight increments are read ahead of their eight additions: read-then-add per element was one LDS round trip
@@ -1942,12 +1770,9 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
                             bit = cgx & 31;
                         }
                     };
-                    if (gp) {                                        // (FUSE: read by another workgroup of THIS launch -> write-through stores)
+                    if (gp) {
 #pragma unroll
-                        for (int k = 0; k < NSL; ++k) {
-                            const int q = qb + k * GS + gl;
-                            if (q < S) { if (FUSE) { st_agent(gp + q, xs[k]); st_agent(gp + S + q, ys[k]); } else { gp[q] = xs[k]; gp[S + q] = ys[k]; } }
-                        }
+                        for (int k = 0; k < NSL; ++k) { const int q = qb + k * GS + gl; if (q < S) { gp[q] = xs[k]; gp[S + q] = ys[k]; } }
                     }
                     if (!occ_pass) continue;
                     if (!FOOT || mx.n_disc == 0) {
@@ -2014,141 +1839,15 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
             if (any_hit) cost = __builtin_huge_val();
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!FUSE) {
-            if (work && gl == 0) {
-                RefEntry o = r;
-                o.cost = cost; o.k0 = cl.k0; o.dk = cl.dk; o.L = cl.L; o.ok = cl.ok ? 1 : 0; o.pad = store_inc ? 1 : 0;
-                mx.q[i] = o;
-            }
-        } else {
-            // ---- the selection (see the comment above group16_ballot) ------------------------------------------------------------
-            // an entry without a goal (ok == 0) carries the filter's cost = +inf, zero clothoid
-            const double my_cost = work ? cost : __builtin_huge_val();
-            const bool multi = live && n_e > 1;
-            if (multi && work && gl == 0) {                              // publish: what ANOTHER group's selection may need of this entry
-                RefEntry* o = mx.q + i;
-                st_agent(&o->cost, my_cost); st_agent(&o->k0, cl.k0); st_agent(&o->dk, cl.dk); st_agent(&o->L, cl.L);
-                __hip_atomic_store(reinterpret_cast<long long*>(&o->ok), (long long)(unsigned int)(cl.ok ? 1 : 0) | ((long long)(store_inc ? 1 : 0) << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ok, pad) as one 8-byte store
-            }
-            bool sel = live && n_e == 1;                                 // a single entry: this group selects, nothing to wait for
-            if (__any(multi)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores before its ticket
-                unsigned int t = 0u;
-                if (multi && gl == 0) t = __hip_atomic_fetch_add(mx.ego_done + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t = (unsigned int)__shfl((int)t, gbase, F1P_WAVE);
-                if (multi && t + 1u == (unsigned int)n_e) sel = true;    // the LAST ticket of the ego
-            }
-            F1P_RPH();
-            if (__any(sel)) {
-                Clothoid wcl = cl;                                       // the winner: this entry unless the argmin says otherwise
-                if (!work) { wcl.ok = false; wcl.k0 = 0; wcl.dk = 0; wcl.L = 0; }
-                double bc = my_cost; int bi = r.c;
-                bool own = true;
-                const bool argm = sel && multi;
-                if (__any(argm)) {
-                    // np.argmin over the ego's entries (costs by agent-scope loads: other groups of this launch wrote them)
-                    // (four entries per lane requested together: a wall-hugging ego hands 50-200 entries over, and a dependent round trip per
-                    // sixteen of them -- twice, with the all-blocked rule's own pass -- was the kernel's tail; the rule's slot is found in the same pass)
-                    double d = __builtin_huge_val(); int ci = 0x7fffffff, slot = -1, slot0 = -1;
-                    if (argm) {
-                        for (int j0 = gl; j0 < n_e; j0 += 64) {
-                            double cj[4]; int cc[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int j = j0 + 16 * k < n_e ? j0 + 16 * k : j0;
-                                const RefEntry* q = mx.q + base_e + j;
-                                cj[k] = ld_agent(&q->cost); cc[k] = ld_agent_i(&q->c);
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (j0 + 16 * k < n_e) {
-                                    if (argmin_better(cj[k], cc[k], d, ci)) { d = cj[k]; ci = cc[k]; slot = base_e + j0 + 16 * k; }
-                                    if (cc[k] == cfg.cand_begin) slot0 = base_e + j0 + 16 * k;
-                                }
-                            }
-                        }
-                    }
-                    double gd = d; int gi = ci;
-                    group16_argmin(gd, gi);
-                    {   // the slot travels with the winner (candidate indices are unique per ego)
-                        const unsigned m = group16_ballot(argm && ci == gi && slot >= 0, gbase);
-                        const int src = m ? __ffs((int)m) - 1 : 0;
-                        slot = __shfl(slot, gbase + src, F1P_WAVE);
-                        const unsigned m0 = group16_ballot(argm && slot0 >= 0, gbase);
-                        slot0 = m0 ? __shfl(slot0, gbase + __ffs((int)m0) - 1, F1P_WAVE) : -1;
-                    }
-                    if (argm && !(gd < __builtin_huge_val()) && !(gd != gd)) {
-                        // everything refined is +inf, i.e. everything is blocked: the exhaustive loop's answer is the shard's first candidate
-                        gi = cfg.cand_begin; slot = slot0;
-                    }
-                    if (argm) {
-                        bc = gd; bi = gi;
-                        own = slot == (int)i;
-                        if (!own) {
-                            wcl.ok = false; wcl.k0 = 0; wcl.dk = 0; wcl.L = 0;
-                            bool have_pos = false;
-                            if (slot >= 0) {
-                                const RefEntry* q = mx.q + slot;
-                                const long long okpad = __hip_atomic_load(reinterpret_cast<const long long*>(&q->ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                wcl.k0 = ld_agent(&q->k0); wcl.dk = ld_agent(&q->dk); wcl.L = ld_agent(&q->L);
-                                wcl.ok = (int)(okpad & 0xffffffffll) == 1;
-                                have_pos = wcl.ok && (int)(okpad >> 32) == 1 && mx.inc != nullptr;
-                                if (have_pos) {
-                                    const unsigned int wli = (unsigned int)slot - sh * mx.q_shard_cap;   // (an ego's entries share its shard)
-                                    const double* wp = mx.inc + ((size_t)sh * mx.inc_cap + wli) * 2 * (size_t)S;
-                                    for (int q2 = gl; q2 < S; q2 += 16) { pos_x[q2] = ld_agent(wp + q2); pos_y[q2] = ld_agent(wp + S + q2); }
-                                }
-                            }
-                            if (!have_pos) {
-                                // (the winner has no position block -- beyond the per-shard budget: re-derive the positions from its clothoid with
-                                // this group's own interval code, the evaluation loop's arithmetic)
-                                if (wcl.ok) {
-                                    const double wds = wcl.L / (double)den;
-                                    const IntervalCoef ic = interval_setup(wcl.k0, wcl.dk, wcl.L, wds);
-                                    const int per = (S - 1 + 15) / 16, q0 = gl * per, q1 = q0 + per < S - 1 ? q0 + per : S - 1;
-                                    if (q0 < q1) {
-                                        PieceState st = piece_state_at(wcl.k0, wcl.dk, wds, q0, ic);
-                                        for (int q2 = q0; q2 < q1; ++q2) {
-                                            double dx, dy;
-                                            interval_increment(wcl.k0, wcl.dk, (double)q2 * wds, q2 * ic.nsub, ic, st, dx, dy);
-                                            inc_x[q2] = dx; inc_y[q2] = dy;
-                                        }
-                                    }
-                                } else {
-                                    for (int q2 = gl; q2 < S - 1; q2 += 16) { inc_x[q2] = 0.0; inc_y[q2] = 0.0; }
-                                }
-                            }
-                            // (wave-level LDS fence below, then the serial sums by lane 0 of the group)
-                            if (!have_pos) {
-                                __builtin_amdgcn_s_waitcnt(0xc07f);
-                                if (gl == 0) {
-                                    double x = 0.0, y = 0.0;
-                                    pos_x[0] = 0.0; pos_y[0] = 0.0;
-                                    for (int j = 0; j < S - 1; ++j) { x += inc_x[j]; y += inc_y[j]; pos_x[j + 1] = x; pos_y[j + 1] = y; }
-                                }
-                            }
-                        }
-                    }
-                }
-                if (sel && own && !wcl.ok) for (int q2 = gl; q2 < S; q2 += 16) { pos_x[q2] = 0.0; pos_y[q2] = 0.0; }   // an infeasible winner: zero rows
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (sel && gl == 0) {
-                    if (a.best_idx) a.best_idx[e] = bi;
-                    if (a.best_cost) a.best_cost[e] = bc;
-                    if (a.near_idx) a.near_idx[e] = ni_e;
-                }
-                F1P_RPH();
-                if (a.mode != LATTICE_EVAL) group16_emit_and_track(sel, a, cfg, e, gl, gbase, ni_e, wcl, bc, pos_x, pos_y);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-            }
+        if (work && gl == 0) {
+            RefEntry o = r;
+            o.cost = cost; o.k0 = cl.k0; o.dk = cl.dk; o.L = cl.L; o.ok = cl.ok ? 1 : 0; o.pad = store_inc ? 1 : 0;
+            mx.q[i] = o;
         }
 #ifdef F1P_MIX_PHASES
         F1P_RPH();
         if (ib == 0 && live && gl == 0 && mx.dbg_state && (size_t)i * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width) {
-            for (int k = 0; k + 1 < nrp && k < 7; ++k) mx.dbg_state[(size_t)i * 8 + k] = (int)(rph[k + 1] - rph[k]);
+            for (int k = 0; k + 1 < nrp; ++k) mx.dbg_state[(size_t)i * 8 + k] = (int)(rph[k + 1] - rph[k]);
             mx.dbg_state[(size_t)i * 8 + 7] = nrp;
         }
 #endif
@@ -2372,9 +2071,6 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
         // every instantiation that may be launched below is checked (and configured for > 64 KB of dynamic LDS) by lds_fits -- the
         // footprint variants included (only refine<64> had been, so a FOOT plan with > 496 stations could fail between the
         // filter and the selection kernel and leave the queue counter armed)
-        // the fused refinement + selection (k_lattice_refine<16, false, true>): with the prologue (it re-arms the tickets), point footprint
-        const size_t lds_r16f = sizeof(double) * 16 * (64 + 6 * (size_t)S);
-        const bool fuse_fits = F1P_MIX_FUSE_SELECT && !foot && lds_fits(ctx, k_lattice_refine<16, false, true>, lds_r16f + lds_r_static);
         const bool groups16 = foot ? lds_fits(ctx, k_lattice_refine<16, true>, lds_r16 + lds_r_static) : lds_fits(ctx, k_lattice_refine<16>, lds_r16 + lds_r_static);
         const bool refine_fits = groups16 || (foot ? lds_fits(ctx, k_lattice_refine<64, true>, lds_r64 + lds_r_static) : lds_fits(ctx, k_lattice_refine<64>, lds_r64 + lds_r_static));
         if (lds_fits(ctx, k_lattice_filter<0>, lds_f) && lds_fits(ctx, k_lattice_filter<1>, lds_f) && lds_fits(ctx, k_lattice_filter<2>, lds_f) && lds_fits(ctx, k_lattice_filter<1, true>, lds_f) && lds_fits(ctx, k_lattice_filter<2, true>, lds_f) && refine_fits && lds_fits(ctx, k_lattice_select, lds_s)) {
@@ -2425,7 +2121,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             if (inc_cap > shard_cap) inc_cap = shard_cap;
             const size_t inc_block = 2 * (size_t)(S > 0 ? S : 1) * sizeof(double);
             const size_t inc_bytes = F1P_MIX_INC_PER_EGO > 0 ? inc_cap * F1P_MIX_QSHARDS * inc_block : 0;
-            const size_t need = qc_bytes + sizeof(int32_t) * 4 * (size_t)E + 256 + sizeof(EgoXform) * (size_t)E + 256 + sizeof(RefEntry) * region * nch + 256 + inc_bytes * nch;
+            const size_t need = qc_bytes + sizeof(int32_t) * 3 * (size_t)E + 256 + sizeof(EgoXform) * (size_t)E + 256 + sizeof(RefEntry) * region * nch + 256 + inc_bytes * nch;
             bool fresh = false;
             if (need > ctx->mix_scratch_bytes) {
                 fresh = true;
@@ -2435,13 +2131,12 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 F1P_HIP(ctx, hipMalloc((void**)&ctx->d_mix_scratch, need));
                 ctx->mix_scratch_bytes = need;
             }
-            ctx->mix_last_E = E; ctx->mix_ego_n_off = qc_bytes + sizeof(int32_t) * (size_t)E;
+            ctx->mix_last_E = E; ctx->mix_ego_n_off = qc_bytes + sizeof(int32_t) * (size_t)E;   // (f1p_lattice_debug_queue)
             mx.qcount = reinterpret_cast<unsigned int*>(ctx->d_mix_scratch);
             mx.q_shard_cap = (unsigned int)shard_cap;
             mx.ego_base = reinterpret_cast<int32_t*>(ctx->d_mix_scratch + qc_bytes);
             mx.ego_n = mx.ego_base + E; mx.ego_ni = mx.ego_n + E;
-            mx.ego_done = reinterpret_cast<unsigned int*>(mx.ego_ni + E);
-            const size_t xf_off = (qc_bytes + sizeof(int32_t) * 4 * (size_t)E + 255) & ~(size_t)255;
+            const size_t xf_off = (qc_bytes + sizeof(int32_t) * 3 * (size_t)E + 255) & ~(size_t)255;
             mx.xf = reinterpret_cast<EgoXform*>(ctx->d_mix_scratch + xf_off);
             mx.q = reinterpret_cast<RefEntry*>(ctx->d_mix_scratch + ((xf_off + sizeof(EgoXform) * (size_t)E + 255) & ~(size_t)255));
             {
@@ -2451,10 +2146,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 mx.inc_cap = (unsigned int)inc_cap;
             }
             // k_lattice_select re-arms the counters at the end of every plan; a plan that failed after its filter ran leaves them dirty
-            // (with the prologue in the schedule the counters are re-armed by it; the fused schedule has no selection kernel to do it
-            // at the end of a plan, so it leaves them "dirty" for a following plan that runs WITHOUT a prologue)
-            const bool will_fuse = v3 && fuse_fits && mx.n_disc == 0;
-            if ((fresh || ctx->mix_q_dirty) && !v3) F1P_HIP(ctx, hipMemsetAsync(mx.qcount, 0, qc_bytes, ctx->stream));
+            if (fresh || ctx->mix_q_dirty) F1P_HIP(ctx, hipMemsetAsync(mx.qcount, 0, qc_bytes, ctx->stream));
             ctx->mix_q_dirty = true;                                 // until the selection kernels of THIS plan are enqueued
             if (v3) {
                 const size_t need_rec = rec_stride * (size_t)E;
@@ -2509,13 +2201,6 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 if (rb > rb_max) rb = rb_max;
                 rb = rb & ~(size_t)15;
                 if (rb < 16) rb = 16;
-                const bool fused = will_fuse;
-                if (fused) {
-                    hipLaunchKernelGGL((k_lattice_refine<16, false, true>), dim3((unsigned)rb), dim3(256), lds_r16f, st, ak, *cfg, mk);
-                    if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_refine (fused selection) launch"))) break;
-                    if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[3], st));     // (no separate selection kernel: an empty interval)
-                    continue;
-                }
                 if (groups16) {
                     if (mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine<16, true>), dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
                     else hipLaunchKernelGGL(k_lattice_refine<16>, dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
@@ -2532,7 +2217,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 F1P_HIP(ctx, hipEventRecord(ctx->ev_pipe[1], ctx->pipe_stream[0]));
                 F1P_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pipe[1], 0));
             }
-            if (rc == F1P_OK) ctx->mix_q_dirty = will_fuse;
+            if (rc == F1P_OK) ctx->mix_q_dirty = false;
             if (prof && rc == F1P_OK) { F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[4], ctx->stream)); ctx->lattice_profile_valid = true; }
             // runtime audit (f1p_lattice_set_audit): this plan's outputs on a window of egos against the all-fp64 exhaustive kernel
             if (rc == F1P_OK && ctx->audit_every > 0 && !ctx->auditing && mode == LATTICE_FULL && !a.goals && cfg->cand_count == 0) {
