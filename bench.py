@@ -1207,8 +1207,11 @@ def main_kmpc(args):
                                      "the figure is then a cache-stream rate, not HBM evidence") if stream else
                                     "controls are generated in registers: no per-rollout byte ever exists in memory, the kernel is VALU-bound "
                                     "(Philox4x32-10 + the packed-f32 rollout) and the HBM fraction is reported as the tiny number it is; see valu"}}
-        pmc = None if stream else load_pmc({"workload": "kmpc", "egos": E, "rollouts": R, "horizon": T, "controls": "generated"})
-        if pmc and pmc.get("SQ_INSTS_VALU"):
+        pmc = load_pmc({"workload": "kmpc", "egos": E, "rollouts": R, "horizon": T, "controls": "streamed" if stream else "generated"})
+        if pmc and stream and pmc.get("FETCH_SIZE_KiB") is not None and pmc.get("WRITE_SIZE_KiB") is not None:
+            out["roofline"]["traffic"] = int((pmc["FETCH_SIZE_KiB"] * 2 + pmc["WRITE_SIZE_KiB"]) * 1024)   # gfx950 wide-read correction x2
+            out["roofline"]["traffic_source"] = pmc["source"]
+        if pmc and not stream and pmc.get("SQ_INSTS_VALU"):
             tl = pmc["SQ_INSTS_VALU"] * 64.0 / (kernel_ms * 1e-3) / 1e12
             out["roofline"]["valu"] = {"kernel": pmc["kernel"], "achieved": tl, "peak": VALU_PEAK_F32_GUIDE, "unit": "T lane-instr/s",
                                        "frac": tl / VALU_PEAK_F32_GUIDE,
