@@ -166,21 +166,28 @@ __device__ __forceinline__ void nearest_scan(double px, double py, const double*
 // the computed minimum and the (value, index) argmin is unchanged -- the result is bit-identical to nearest_scan.
 // Surviving chunks are dealt round-robin to the waves.  `nthreads` must be a multiple of 64 and every lane of every
 // wave must call this (ballot inside).
+// best_t (optional): the projection parameter of the lane's best segment, so that a caller that needs nearest_point's `t` after the
+// cross-lane argmin can take it from the owning lane by shuffle instead of loading the segment again and projecting a second time.
 __device__ __forceinline__ void nearest_scan_boxed(double px, double py, const double* __restrict__ wx,
                                                    const double* __restrict__ wy, const double* __restrict__ box, int n,
-                                                   int tid, int nthreads, double& best_d, int& best_i) {
+                                                   int tid, int nthreads, double& best_d, int& best_i, double* best_t = nullptr) {
 #if !F1P_NEAREST_PRUNE
     nearest_scan(px, py, wx, wy, n, tid, nthreads, best_d, best_i);
+    if (best_t) *best_t = best_i != 0x7fffffff ? seg_project(px, py, wx[best_i], wy[best_i], wx[best_i + 1], wy[best_i + 1]).t : 0.0;
     return;
 #endif
     best_d = __builtin_huge_val();
     best_i = 0x7fffffff;
+    double bt = 0.0;
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     const int nseg = n - 1;
     const int nchunk = (nseg + 63) >> 6;
     const int stride = (n + 63) >> 6;
     int j = lane * stride;
     if (j > n - 1) j = n - 1;
+    // the first 64 chunk boxes are requested together with the samples (they do not depend on the bound): one round trip, not two
+    double b0x = 0.0, b0X = 0.0, b0y = 0.0, b0Y = 0.0;
+    if (lane < nchunk) { b0x = box[4 * lane]; b0X = box[4 * lane + 1]; b0y = box[4 * lane + 2]; b0Y = box[4 * lane + 3]; }
     const double ex = px - wx[j], ey = py - wy[j];
     double ub2 = ex * ex + ey * ey;
 #pragma unroll
@@ -191,7 +198,8 @@ __device__ __forceinline__ void nearest_scan_boxed(double px, double py, const d
         const int c = cb + lane;
         bool keep = false;
         if (c < nchunk) {
-            const double xmin = box[4 * c], xmax = box[4 * c + 1], ymin = box[4 * c + 2], ymax = box[4 * c + 3];
+            double xmin = b0x, xmax = b0X, ymin = b0y, ymax = b0Y;
+            if (cb > 0) { xmin = box[4 * c]; xmax = box[4 * c + 1]; ymin = box[4 * c + 2]; ymax = box[4 * c + 3]; }
             const double dx = __builtin_fmax(__builtin_fmax(xmin - px, px - xmax), 0.0);
             const double dy = __builtin_fmax(__builtin_fmax(ymin - py, py - ymax), 0.0);
             keep = !(dx * dx + dy * dy > thr);      // NaN anywhere keeps the chunk
@@ -204,12 +212,13 @@ __device__ __forceinline__ void nearest_scan_boxed(double px, double py, const d
                 const int i = ((cb + b) << 6) + lane;
                 if (i < nseg) {
                     const SegProj s = seg_project(px, py, wx[i], wy[i], wx[i + 1], wy[i + 1]);
-                    if (argmin_better(s.d, i, best_d, best_i)) { best_d = s.d; best_i = i; }
+                    if (argmin_better(s.d, i, best_d, best_i)) { best_d = s.d; best_i = i; bt = s.t; }
                 }
             }
             if (++turn == nw) turn = 0;
         }
     }
+    if (best_t) *best_t = bt;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -181,11 +181,15 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     float mc[6], ms[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
+    // The rule is symmetric about 1/2: nodes j and 15 - j share u = tau^2 - tau and the weight, i.e. the whole row w u^k -- so the
+    // two nodes' cosines (sines) are added first and ONE row of six fma serves both: 8 x 12 fma instead of 16 x 12 (round 4).  Each
+    // node's phase is still formed from the tabulated node itself, so the a-priori bound below holds with room (fewer roundings).
 #pragma unroll F1P_MIX_FIT_UNROLL
-    for (int j = 0; j < 16; ++j) {
-        const float tau = c_gl16_xf[j];
+    for (int j = 0; j < 8; ++j) {
+        const float tau = c_gl16_xf[j], tau2 = c_gl16_xf[15 - j];
         const float ph = __builtin_fmaf(__builtin_fmaf(ar, tau, br), tau, cr);
-        const float sn = __builtin_amdgcn_sinf(ph), cs = __builtin_amdgcn_cosf(ph);
+        const float ph2 = __builtin_fmaf(__builtin_fmaf(ar, tau2, br), tau2, cr);
+        const float sn = __builtin_amdgcn_sinf(ph) + __builtin_amdgcn_sinf(ph2), cs = __builtin_amdgcn_cosf(ph) + __builtin_amdgcn_cosf(ph2);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             mc[k] = __builtin_fmaf(c_gl16_wuf[j][k], cs, mc[k]);
@@ -936,7 +940,7 @@ struct EgoParamsF2 {
     float w_len, w_maxk, w_meank, w_sim;
     float margin_rel, margin_abs, edge0, edge1;
     float clear_ds_cap, inv_den, inv_S, fS;
-    float cells_per_m, pad0;      // |(txx, txy)|: cells per metre of the ego -> tile transform (the position bound in cells)
+    float cells_per_m, sqrt_S;    // |(txx, txy)|: cells per metre of the ego -> tile transform (the position bound in cells); sqrt(S)
     const double* prev;
     // moments of the previous path's heading column p_j = prev[j + n_shift], j < sim_m (k_lattice_prologue, fp64): with them the similarity
     // term sum_j (theta_j - p_j)^2 of a candidate whose theta_j = A j + B j^2 is a closed form -- no per-station loop in the filter
@@ -1151,7 +1155,7 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
             const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
             const float rs = __builtin_sqrtf(sim);
             const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel + U * (4.0f * TH + rs);
-            e4 = fabsf(ep->w_sim) * (2.0f * e_th * __builtin_sqrtf(fS) * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
+            e4 = fabsf(ep->w_sim) * (2.0f * e_th * ep->sqrt_S * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
         }
         const float bound = 1.25f * ((e1 + e2) + (e3 + e4)) + 8.0f * U * ((fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)));
         o.ebound = bound;
@@ -1227,10 +1231,18 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     F1P_PPH();
     // ---- nearest segment and look-ahead centres: the arithmetic of k_lattice (fp64: these decide indices), one wave ---------------
     double nd; int ni;
-    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, lane, 64, nd, ni);
+    double my_t = 0.0;
+    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, lane, 64, nd, ni, &my_t);
     F1P_PPH();
-    wave_argmin(nd, ni);
-    const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
+    // nearest_point's t of the winning segment: the lane that projected it still holds it (the same seg_project call, the same bits) --
+    // round 3 loaded the segment again and projected a second time, a dependent round trip + ~60 fp64 instructions per ego
+    SegProj ns;
+    {
+        const int my_i = ni;
+        wave_argmin(nd, ni);
+        const unsigned long long own = __ballot(my_i == ni);
+        ns.t = shfl_d(my_t, own ? __ffsll((long long)own) - 1 : 0); ns.d = nd; ns.qx = 0.0; ns.qy = 0.0;
+    }
     F1P_PPH();
 #ifdef F1P_PRO_PHASES
     int lstat[4] = {0, 0, 0, 0};
@@ -1299,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         p.clear_ds_cap = mx.clear_ds_cap;
         p.inv_den = __builtin_amdgcn_rcpf((float)den);
         p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
-        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.pad0 = 0.f; }
+        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
         p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
         p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
         p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.pitch_bytes = pitch * 8;   // a row of (clearance, bitmap) word pairs
