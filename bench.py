@@ -126,6 +126,7 @@ def main(argv=None):
     # every rank, however it was launched (self-launch above, or the driver's own torchrun): dmabuf IPC before anything loads
     # HIP -- RCCL across processes fails with `hipIpcGetMemHandle: invalid argument` on this pool without it
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the CPU-baseline oracle's idle OpenMP workers sleep instead of spinning beside the GPU legs
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, argv))
     sys.path.insert(0, ROOT)
@@ -808,11 +809,13 @@ def main_lattice(args):
         selftest = leg_exchange_selftest(rk, ctx)
     elif not rk.rccl_ok:
         selftest = {"skipped": rk.rccl_note}
-    if secondary and not cand_sharded:
-        kmpc_c4 = leg_kmpc_c4(rk, args, max(10, min(args.steps, 100)))
+    # (before any leg that runs the OpenMP oracle: its worker threads spin for a while after a parallel region and would compete with the
+    # thread that issues these launches -- seen once as 0.40 ms per plan instead of 0.07)
     two_in_flight = None
     if secondary and not cand_sharded and not (args.all_fp64 or args.prune):
         two_in_flight = leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, max(20, min(args.steps, 200)))
+    if secondary and not cand_sharded:
+        kmpc_c4 = leg_kmpc_c4(rk, args, max(10, min(args.steps, 100)))
 
     if rank == 0:
         steps_total = float(E) * C * S * args.steps * (1 if cand_sharded else world)
