@@ -1032,6 +1032,11 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
 #endif
         edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
         if (!(edge == edge)) edge = 2.0f;                                  // NaN: nothing is "away from an edge"
+        // In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station
+        // is within the ONE cell of slack the clearance map was built with: the a-priori position bound is three orders
+        // inside it for every trusted candidate, but nothing compared the two -- a candidate whose bound reaches 0.8 cells decides nothing
+        // by its positions (never observed: the fuzz runs and the audit are green without it)
+        unsure |= !(edge < 0.8f);
     }
     const float edge_hi = 1.0f - edge;
     auto test = [&]() {                                                      // the station at (x, y)

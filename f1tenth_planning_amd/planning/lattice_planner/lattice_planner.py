@@ -310,6 +310,27 @@ class LatticePlanner():
         mc.set_waypoints_cached(self.waypoints)
         return mc.lattice_plan(poses, self._cfg(), prev_theta=prev_theta, want_traj=want_traj, traj_dtype=traj_dtype)
 
+    def set_closed_loop(self, on=True):
+        """Batched closed loop: every plan_batch / step_batch keeps its winners' headings on the device and the next one (same batch
+        shape, prev_theta=None) uses them as the previous path of get_similarity_cost (lattice_planner.py:287-296) -- what the single-
+        vehicle plan() does on the host with self.prev_traj.  (Re)arming forgets the previous path."""
+        self._context().lattice_set_closed_loop(on)
+
+    def step_batch(self, poses, waypoints=None, keep_traj=False):
+        """One control step for E vehicles: poses [E, 4] -> dict(steer, speed, status) (page-locked arrays owned by the context, valid
+        until the next step).  Always a link of a closed loop (previous headings stay on the device); nothing but the poses and the
+        three result columns touches host memory, and no copy is submitted (f1p_lattice_step_batch).  keep_traj=True keeps the winners'
+        rows on the device: fetch_traj() returns them."""
+        ctx = self._bind(waypoints)
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+        self._step_shape = (poses.shape[0], self._cfg().n_stations)
+        return ctx.lattice_step(poses, self._cfg(), keep_traj=keep_traj)
+
+    def fetch_traj(self):
+        """the winners' rows [E, S, 4] of the last step_batch(keep_traj=True)"""
+        E, S = self._step_shape
+        return self._context().lattice_fetch_traj(E, S)
+
     def _multi(self, devices):
         from ...runtime import MultiContext
         key = "all" if isinstance(devices, str) else tuple(int(d) for d in devices)

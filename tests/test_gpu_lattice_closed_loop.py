@@ -190,3 +190,32 @@ def test_step_batch_is_the_chain_without_copies(scene, E):
             a.lattice_step(poses, sh)
     finally:
         a.close(); b.close()
+
+
+def test_planner_class_closed_loop(scene):
+    """LatticePlanner.set_closed_loop / step_batch / fetch_traj: the batched counterpart of what plan() does for one vehicle with
+    self.prev_traj (the reference carries best_traj from call to call for get_similarity_cost)"""
+    from f1tenth_planning.planning.lattice_planner.lattice_planner import LatticePlanner
+    rl, img, origin = scene
+    E = 350
+    poses0 = synth.make_egos(rl, E, seed=77, pos_sigma=0.3)
+
+    def make():
+        lp = LatticePlanner(waypoints=rl)
+        lp.configure(lookahead_distances=np.linspace(0.6, 3.0, 8), widths=np.linspace(-1.0, 1.0, 16), num_stations=40, weights=(0.25, 0.25, 0.25, 0.25))
+        lp.set_map(img, 0.058, origin, occupied_thresh=0.2)
+        return lp
+    a, b, c = make(), make(), make()
+    a.set_closed_loop(True)
+    prev = None
+    for k in range(3):
+        poses = _drive(poses0, rl, k)
+        want = b.plan_batch(poses, prev_theta=prev)                     # explicit chain
+        got = a.plan_batch(poses)                                      # closed loop on the device
+        st = c.step_batch(poses, keep_traj=(k == 2))                   # the control-step form
+        for n in NAMES:
+            np.testing.assert_array_equal(got[n], want[n], err_msg=f"plan {k} {n}")
+        for n in ("steer", "speed", "status"):
+            np.testing.assert_array_equal(st[n], want[n], err_msg=f"step {k} {n}")
+        prev = want["best_traj"][:, :, 2].copy()
+    np.testing.assert_array_equal(c.fetch_traj(), want["best_traj"])
