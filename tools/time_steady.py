@@ -12,9 +12,11 @@ cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S); poses = synth.make_egos(r
 with Context(0) as ctx:
     ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
     d_poses = ctx.to_device(poses)
+    PIPE = int(os.environ.get("PIPE", "0"))
+    ctx.lattice_set_pipeline(PIPE)
     b = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
     for _ in range(300): ctx.lattice_plan_dev(d_poses, E, cfg, *b)          # clocks up
-    line = [os.path.basename(os.environ.get("F1P_LIBRARY", "default"))]
+    line = [os.path.basename(os.environ.get("F1P_LIBRARY", "default")) + " pipe=%d" % PIPE]
     for state in ("first", "steady"):
         ctx.lattice_set_closed_loop(state == "steady")
         for _ in range(20): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
@@ -26,5 +28,9 @@ with Context(0) as ctx:
         for _ in range(50):
             ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
         ctx.lattice_profile(False)
-        line.append("%s %.4f ms [pro %.1f flt %.1f ref %.1f sel %.1f us]" % ((state, ms) + tuple(1e3 * acc / 50)))
+        import time
+        ts = []
+        for _ in range(100):                                   # one plan at a time: launch + sync
+            t1 = time.perf_counter(); ctx.lattice_plan_dev(d_poses, E, cfg, *b); ctx.sync(); ts.append(time.perf_counter() - t1)
+        line.append("%s %.4f ms (one at a time, host: p50 %.4f) [pro %.1f flt %.1f ref %.1f sel %.1f us]" % ((state, ms, 1e3 * float(np.median(ts))) + tuple(1e3 * acc / 50)))
     print("  ".join(line))
