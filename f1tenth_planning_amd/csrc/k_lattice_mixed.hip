@@ -71,6 +71,9 @@ namespace f1p {
 #ifndef F1P_MIX_FILTER_V3
 #define F1P_MIX_FILTER_V3 1          // prologue + candidate kernel (k_lattice_prologue, k_lattice_filter3) where it applies; 0: the one-kernel k_lattice_filter everywhere (A/B builds)
 #endif
+#ifndef F1P_MIX_COOP_MAX
+#define F1P_MIX_COOP_MAX 4           // selected candidates per wave up to which the station pass runs wave-cooperatively (station_pass_wave), one after the other
+#endif
 #ifndef F1P_MIX_F3_EGOS_PER_WG
 #define F1P_MIX_F3_EGOS_PER_WG 1     // egos a k_lattice_filter3 workgroup evaluates one after the other (grid = egos / this)
 #endif
@@ -933,7 +936,7 @@ __device__ __forceinline__ int cvt_flr_i32_f32(float v) {      // floor + satura
     return r;
 }
 
-// workgroup-uniform parameters of the station loop (LDS): floats land in VGPRs (the cheap operand class), integers go through
+// workgroup-uniform parameters of the candidate kernel (LDS): floats land in VGPRs (the cheap operand class), integers go through
 // readfirstlane
 struct EgoParamsF2 {
     float txx, txy, tx0, tyx, tyy, ty0;
@@ -945,16 +948,25 @@ struct EgoParamsF2 {
     // moments of the previous path's heading column p_j = prev[j + n_shift], j < sim_m (k_lattice_prologue, fp64): with them the similarity
     // term sum_j (theta_j - p_j)^2 of a candidate whose theta_j = A j + B j^2 is a closed form -- no per-station loop in the filter
     double M0, M1, M2;             // sum p^2, sum j p, sum j^2 p
-    int tile_w, tile_h, pitch_bytes, occ_off, S, sim_m, n_shift, exact_all;
+    int tile_w, tile_h;            // extent [cells] of the ego's occupancy window (the f32 cell arithmetic is relative to its origin)
+    int tile_gx0, tile_gy0;        // ... and its origin on the map (tile_gx0 a multiple of 32)
+    int S, sim_m, n_shift;
+    int exact_all;                 // the ego itself stands in a cell that is not clear: every station against the real bitmap (k_lattice_prologue)
 };
 
+// Round 4, second step: the candidate kernel evaluates LAZILY.  A candidate's four cost terms (1 / L, max |kappa|, mean |kappa|, similarity:
+// lattice_planner.py:262-296) and their bracket depend on the fitted clothoid alone; the station positions decide one thing only, whether
+// the candidate is collision-free -- and that matters only for candidates whose bracket reaches below T = min hi over the FREE ones: on
+// the bench scene 1.5 of 256 per ego (tools/lazy_stats.py; 96.9 % of the egos need only the 1.2 cheapest).  So every candidate gets
+// bracket_f2 (fit -> cost, [lo, hi], what is already known about its state), and station_pass_f2 -- positions, look-ups -- runs in
+// rounds on the few candidates that can still matter (k_lattice_filter3).  The states and brackets of the candidates that reach the
+// refinement queue are the ones the every-candidate loop produced, so the queue -- and every output -- is unchanged.
+#define F1P_ST_PENDING 4           // bracket known, collision state not looked at (yet)
+struct Brk32 { float cost, lo, hi, edge, ebound; int state; bool never_free; };
+
 template <int R>
-__device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(unsigned char)* tile,
-                                                  double sim_s2, double sim_s3, double sim_s4) {
-    Filt32 o;
-    const int S = __builtin_amdgcn_readfirstlane(ep->S);
-    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
-    const unsigned pitch_bytes = (unsigned)__builtin_amdgcn_readfirstlane(ep->pitch_bytes);   // bytes per tile row: (tile_words + 1) word PAIRS
+__device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, double sim_s2, double sim_s3, double sim_s4) {
+    Brk32 o;
     const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
     const float k0 = f.k0, dk = f.dk, L = f.L;
     const float ds = L * ep->inv_den, h = 0.5f * ds;
@@ -973,12 +985,124 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
     const float hp = gm * h, bp = (gm * gm) * b;                             // the piece's half-length and quadratic phase coefficient
     const bool untrusted = !(kmax * hp <= 0.4f) || !(fabsf(bp) <= 0.05f);    // outside the one-piece series' range the positions decide nothing
     bool unsure = untrusted || !(ds <= ep->clear_ds_cap);                    // ... nor beyond the spacing the clearance map was built for (NaN: unsure)
+    // "away from every cell edge" = farther than the f32 POSITION error: the calibrated band (edge0 + edge1 L: 5-10x the measured
+    // end-point error, tools/mixed_endpoint_error.py) or, when larger, this candidate's a-priori bound (DESIGN.md 5c):
+    //   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
+    //   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
+    //   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
+    float edge;
+    {
+        const float U = 6.0e-8f;
+        const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+        const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel;
+        const float zm = (kmax * hp) * (kmax * hp);                           // of the piece actually integrated (hp = G h in the macro mode)
+        // the one-piece series keeps P = 2 - z/3 + z^2/60 - b^2/5 and Q = 2 b (1/3 - z/10) of int_{-1}^{1} exp(j (a t + b t^2)) dt; the first
+        // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
+        const float abp = fabsf(bp);
+        const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
+        const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
+        o.ebound = e_pos;                                                  // (F1P_MIX_DEBUG_END: the end-point tool compares the measured miss with this bound [m])
+        edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
+        if (!(edge == edge)) edge = 2.0f;                                  // NaN: nothing is "away from an edge"
+        // In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station
+        // is within the ONE cell of slack the clearance map was built with (DESIGN.md 5a): the a-priori position bound is three orders
+        // inside it for every trusted candidate, but nothing compared the two -- a candidate whose bound reaches 0.8 cells decides nothing
+        // by its positions (ADVICE r3; never observed: the fuzz runs and the audit are green without it)
+        unsure |= !(edge < 0.8f);
+    }
+    o.edge = edge;
+    float sim = 0.f;
+    const double* prev = ep->prev;
+    if (prev) {
+        // Similarity to the previous winner's headings (get_similarity_cost, lattice_planner.py:287-296) in CLOSED FORM (round 4).  The
+        // station headings of a clothoid are a polynomial in the station index, theta_j = A j + B j^2 with A = k0 ds, B = dk ds^2 / 2, so
+        //   sum_j (theta_j - p_j)^2 = A^2 S2 + 2 A B S3 + B^2 S4 - 2 A M1 - 2 B M2 + M0
+        // with S_k = sum j^k (constants of the configuration) and the per-EGO moments M0 = sum p^2, M1 = sum j p, M2 = sum j^2 p that
+        // k_lattice_prologue forms once per ego: ~12 fp64 instructions per candidate instead of a 48-iteration loop with a global load
+        // each (round 3: ~300 VALU + 48 VMEM per candidate).  Evaluated in fp64 -- the expansion cancels (similar paths: the sum is small
+        // against its terms), which f32 could not afford; in fp64 the cancellation error is <= 6e-16 (S TH^2 + M0), far inside the bound e4
+        // below, whose terms fS e_th^2 >= 5.8e-14 fS TH^2 and 2 fS U sim dominate it in every regime (M0 <= 2 (S TH^2 + sim)).  The fp64
+        // refinement keeps the reference's sequential order.
+        const double dA = (double)k0 * (double)ds, dB = (0.5 * (double)dk) * ((double)ds * (double)ds);
+        double sv = __builtin_fma(dA, __builtin_fma(dA, sim_s2, __builtin_fma(2.0 * dB, sim_s3, -2.0 * ep->M1)),
+                                  __builtin_fma(dB, __builtin_fma(dB, sim_s4, -2.0 * ep->M2), ep->M0));
+        sv = sv < 0.0 ? 0.0 : sv;                                            // (NaN stays NaN: a NaN / inf previous path sends the candidate to fp64)
+        sim = (float)sv;
+    }
+    // sum_i |k0 + g i|, g = dk ds, in closed form (two arithmetic series around the sign change of the linear curvature)
+    const float fS = ep->fS;
+    float sumk;
+    {
+        const float g = dk * ds, kl = __builtin_fmaf(g, fS - 1.0f, k0);
+        if (!(k0 * kl < 0.0f)) {
+            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
+        } else {
+            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));      // last station on kappa_0's side of zero
+            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
+            const float n1 = is + 1.0f, n2 = fS - n1;
+            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
+        }
+    }
+    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (fS - 1.0f) * ds, k0)));
+    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * ep->inv_S), t4 = ep->w_sim * sim;
+    o.cost = ((t1 + t2) + t3) + t4;
+    // the bracket: the calibrated margin (rel * sum|terms| + abs, 30x the measured error) or, when larger, this candidate's own
+    // a-priori bound (DESIGN.md 5c): first-order propagation of the fit's error bounds through the four cost terms
+    //   1/L: relative eLrel;  any kappa(s) = k0 + dk s, s <= L (s itself scales with L): e_kap = ek0 + L edk + |dk| L eLrel;
+    //   max|kappa| and mean|kappa| (closed form: a station within e_kap of kappa = 0 on the other side of the sign change moves the
+    //   sum by < 2 e_kap) both within e_kap;  theta(s) within e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, TH = |k0| L + |dk| L^2 / 2,
+    //   and sum (theta_i - prev_i)^2 moves by <= 2 e_th sqrt(S sum) + S e_th^2 (Cauchy-Schwarz), the f32 copy of prev by u (TH + sqrt(sum))
+    float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
+    {
+        const float U = 6.0e-8f;
+        const float e_kap = f.ek0 + L * f.edk + fabsf(dk) * L * f.eLrel;
+        const float e1 = fabsf(t1) * (f.eLrel + 3.0f * U);
+        const float e2 = fabsf(ep->w_maxk) * e_kap, e3 = fabsf(ep->w_meank) * (e_kap * (1.0f + 2.0f * ep->inv_S));
+        float e4 = 0.0f;
+        if (prev) {
+            const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+            const float rs = __builtin_sqrtf(sim);
+            const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel + U * (4.0f * TH + rs);
+            e4 = fabsf(ep->w_sim) * (2.0f * e_th * ep->sqrt_S * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
+        }
+        const float bound = 1.25f * ((e1 + e2) + (e3 + e4)) + 8.0f * U * ((fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)));
+#ifndef F1P_MIX_DEBUG_END
+        o.ebound = bound;
+#endif
+        if (!(ep->margin_rel < 0.0f)) {                                   // (a negative margin only comes from the test hook that BREAKS the filter on purpose)
+            m = fmaxf(m, bound);
+            if (!(bound == bound)) m = __builtin_huge_valf();             // (the cost itself is then NaN as well and handled below)
+        }
+    }
+    o.lo = o.cost - m; o.hi = o.cost + m;
+    // what is known without the positions: outside the series' range nothing they say counts (UNSURE, final); a candidate beyond the
+    // clearance map's spacing or with a position bound beyond its slack can still turn out a certain HIT, never FREE
+    o.state = untrusted ? F1P_ST_UNSURE : F1P_ST_PENDING;
+    o.never_free = unsure;
+    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.never_free = true; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }   // no bracket: HIT or UNSURE
+    return o;
+}
+
+// The collision state of ONE clothoid in f32: station positions by integrated pieces, one look-up per tested station against the ego's
+// LDS tile.  Runs for the few candidates per ego that k_lattice_filter3's rounds select.  (Look-ups straight from global memory -- no
+// tile -- were measured: ~1 000 cycles per dependent look-up, 14.7 k cycles per pass, and 50 of them for an ego that tests every
+// station: the kernel's tail grew to 54 us.)
+template <int R>
+__device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
+                                               const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, float& xe, float& ye) {
+    const int S = __builtin_amdgcn_readfirstlane(ep->S);
+    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
+    const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
+    const float ds = L * ep->inv_den, h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;
+    constexpr int G = 2 * R + 1;
+    const bool macro = F1P_MIX_MACRO && !exact_all && G > 1;
     // per-candidate polynomial coefficients in u = (interval index + 1/2):
     //   midpoint heading [rev]  thr(u) = u (alpha + beta u),  alpha = ds k0 / 2 pi,  beta = ds^2 dk / 4 pi
     //   a(u) = kappa(s_mid) h   = A0 + A1 u
     //   h P = c0 + z (c1 + z c2),  h Q = d0 + d1 z,  z = a^2      (P = 2 - z/3 + z^2/60 - b^2/5,  Q = 2 b (1/3 - z/10))
     const float alpha = ds * (k0 * F1P_INV_2PI_F), beta = (ds * ds) * (0.5f * dk * F1P_INV_2PI_F);
-    float A0, A1, c0, c1, c2, d0, d1;                                        // of the piece in use (one set live at a time: the 64-register budget)
+    float A0, A1, c0, c1, c2, d0, d1;                                        // of the piece in use
     auto set_piece = [&](float m) {                                          // m intervals per piece: half-length m h, quadratic coefficient m^2 b
         const float hm = m * h, bm = (m * m) * b;
         A0 = k0 * hm; A1 = (dk * ds) * hm;
@@ -989,7 +1113,7 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
     const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
     float x = 0.f, y = 0.f;
     uint32_t flags = 0u;                                                     // bit 0: a tested station decided nothing; bit 1: a tested station is inside an occupied cell
-    auto step = [&](float u) {                                               // one interval: 12 plain VGPR instructions + sin + cos
+    auto step = [&](float u) {                                               // one piece: 12 plain VGPR instructions + sin + cos
         const float thr = u * __builtin_fmaf(beta, u, alpha);
         const float a = __builtin_fmaf(A1, u, A0);
         const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
@@ -1003,41 +1127,9 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
         asm("v_fmac_f32 %0, %1, %2" : "+v"(y) : "v"(cs), "v"(Qh));
     };
     // One look-up, no branch: the tile interleaves the clearance word and the bitmap word of every 32 cells (one ds_read_b64), the
-    // guard column / row read (not clear, not occupied) = "undecided".  In this scene a wave nearly always holds a candidate that
-    // runs along a wall, so the round-2 split into a cheap "clear" test and a branch to the exact test executed BOTH at almost every
-    // look-up (~40 instructions); evaluated together they are 23.
+    // guard column / row read (not clear, not occupied) = "undecided".
     //   normal mode:  bit 0 (undecided) = not clear;  bit 1 (certain hit) = not clear & occupied & away from every cell edge
     //   exact_all:    every station is tested against the bitmap: bit 0 = near a cell edge or off the tile, bit 1 = occupied & not near
-    // "away from every cell edge" = farther than the f32 POSITION error: the calibrated band (edge0 + edge1 L: 5-10x the measured
-    // end-point error, tools/mixed_endpoint_error.py) or, when larger, this candidate's a-priori bound (DESIGN.md 5c):
-    //   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
-    //   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
-    //   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
-#ifdef F1P_MIX_DEBUG_END
-    float epos_dbg = 0.f;
-#endif
-    float edge;
-    {
-        const float U = 6.0e-8f;
-        const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
-        const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel;
-        const float zm = (kmax * hp) * (kmax * hp);                           // of the piece actually integrated (hp = G h in the macro mode)
-        // the one-piece series keeps P = 2 - z/3 + z^2/60 - b^2/5 and Q = 2 b (1/3 - z/10) of int_{-1}^{1} exp(j (a t + b t^2)) dt; the first
-        // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
-        const float abp = fabsf(bp);
-        const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
-        const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
-#ifdef F1P_MIX_DEBUG_END
-        epos_dbg = e_pos;
-#endif
-        edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
-        if (!(edge == edge)) edge = 2.0f;                                  // NaN: nothing is "away from an edge"
-        // In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station
-        // is within the ONE cell of slack the clearance map was built with (DESIGN.md 5a): the a-priori position bound is three orders
-        // inside it for every trusted candidate, but nothing compared the two -- a candidate whose bound reaches 0.8 cells decides nothing
-        // by its positions (ADVICE r3; never observed: the fuzz runs and the audit are green without it)
-        unsure |= !(edge < 0.8f);
-    }
     const float edge_hi = 1.0f - edge;
     auto test = [&]() {                                                      // the station at (x, y)
         const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0));
@@ -1105,78 +1197,95 @@ __device__ __forceinline__ Filt32 station_loop_f2(const Fit32& f, const F1P_LDS(
             if (i + 1 < S) step(ub);
         }
     }
-    float sim = 0.f;
-    const double* prev = ep->prev;
-    if (prev) {
-        // Similarity to the previous winner's headings (get_similarity_cost, lattice_planner.py:287-296) in CLOSED FORM (round 4).  The
-        // station headings of a clothoid are a polynomial in the station index, theta_j = A j + B j^2 with A = k0 ds, B = dk ds^2 / 2, so
-        //   sum_j (theta_j - p_j)^2 = A^2 S2 + 2 A B S3 + B^2 S4 - 2 A M1 - 2 B M2 + M0
-        // with S_k = sum j^k (constants of the configuration) and the per-EGO moments M0 = sum p^2, M1 = sum j p, M2 = sum j^2 p that
-        // k_lattice_prologue forms once per ego: ~12 fp64 instructions per candidate instead of a 48-iteration loop with a global load
-        // each (round 3: ~300 VALU + 48 VMEM per candidate).  Evaluated in fp64 -- the expansion cancels (similar paths: the sum is small
-        // against its terms), which f32 could not afford; in fp64 the cancellation error is <= 6e-16 (S TH^2 + M0), far inside the bound e4
-        // below, whose terms fS e_th^2 >= 5.8e-14 fS TH^2 and 2 fS U sim dominate it in every regime (M0 <= 2 (S TH^2 + sim)).  The fp64
-        // refinement keeps the reference's sequential order.
-        const double dA = (double)k0 * (double)ds, dB = (0.5 * (double)dk) * ((double)ds * (double)ds);
-        double sv = __builtin_fma(dA, __builtin_fma(dA, sim_s2, __builtin_fma(2.0 * dB, sim_s3, -2.0 * ep->M1)),
-                                  __builtin_fma(dB, __builtin_fma(dB, sim_s4, -2.0 * ep->M2), ep->M0));
-        sv = sv < 0.0 ? 0.0 : sv;                                            // (NaN stays NaN: a NaN / inf previous path sends the candidate to fp64)
-        sim = (float)sv;
-    }
-    bool hit_sure = (flags & 2u) != 0u && !untrusted;
-    unsure |= (flags & 1u) != 0u;
+    bool hit_sure = (flags & 2u) != 0u;
+    bool unsure = never_free | ((flags & 1u) != 0u);
     if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }          // a NaN anywhere in the rows is sticky in x / y: nothing was decided
-    // sum_i |k0 + g i|, g = dk ds, in closed form (two arithmetic series around the sign change of the linear curvature)
-    const float fS = ep->fS;
-    float sumk;
-    {
-        const float g = dk * ds, kl = __builtin_fmaf(g, fS - 1.0f, k0);
-        if (!(k0 * kl < 0.0f)) {
-            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
-        } else {
-            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));      // last station on kappa_0's side of zero
-            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
-            const float n1 = is + 1.0f, n2 = fS - n1;
-            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
-        }
-    }
-    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (fS - 1.0f) * ds, k0)));
-    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * ep->inv_S), t4 = ep->w_sim * sim;
-    o.cost = ((t1 + t2) + t3) + t4;
-    // the bracket: the calibrated margin (rel * sum|terms| + abs, 30x the measured error) or, when larger, this candidate's own
-    // a-priori bound (DESIGN.md 5c): first-order propagation of the fit's error bounds through the four cost terms
-    //   1/L: relative eLrel;  any kappa(s) = k0 + dk s, s <= L (s itself scales with L): e_kap = ek0 + L edk + |dk| L eLrel;
-    //   max|kappa| and mean|kappa| (closed form: a station within e_kap of kappa = 0 on the other side of the sign change moves the
-    //   sum by < 2 e_kap) both within e_kap;  theta(s) within e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, TH = |k0| L + |dk| L^2 / 2,
-    //   and sum (theta_i - prev_i)^2 moves by <= 2 e_th sqrt(S sum) + S e_th^2 (Cauchy-Schwarz), the f32 copy of prev by u (TH + sqrt(sum))
-    float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
-    {
-        const float U = 6.0e-8f;
-        const float e_kap = f.ek0 + L * f.edk + fabsf(dk) * L * f.eLrel;
-        const float e1 = fabsf(t1) * (f.eLrel + 3.0f * U);
-        const float e2 = fabsf(ep->w_maxk) * e_kap, e3 = fabsf(ep->w_meank) * (e_kap * (1.0f + 2.0f * ep->inv_S));
-        float e4 = 0.0f;
-        if (prev) {
-            const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
-            const float rs = __builtin_sqrtf(sim);
-            const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel + U * (4.0f * TH + rs);
-            e4 = fabsf(ep->w_sim) * (2.0f * e_th * ep->sqrt_S * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
-        }
-        const float bound = 1.25f * ((e1 + e2) + (e3 + e4)) + 8.0f * U * ((fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)));
-        o.ebound = bound;
-#ifdef F1P_MIX_DEBUG_END
-        o.ebound = epos_dbg;                                              // the end-point tool compares the measured miss with the a-priori POSITION bound [m]
-#endif
-        if (!(ep->margin_rel < 0.0f)) {                                   // (a negative margin only comes from the test hook that BREAKS the filter on purpose)
-            m = fmaxf(m, bound);
-            if (!(bound == bound)) m = __builtin_huge_valf();             // (the cost itself is then NaN as well and handled below)
-        }
-    }
-    o.lo = o.cost - m; o.hi = o.cost + m;
-    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
-    o.xe = x; o.ye = y;
-    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
-    return o;
+    xe = x; ye = y;
+    return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+}
+
+// The same verdict for ONE candidate by a whole WAVE: lane q takes test point q -- the piece that leads to it (its increment is a closed
+// form of the piece's midpoint, nothing sequential), an inclusive DPP scan of the increments for the position, the look-up.  ~110
+// instructions with short dependence chains instead of a ~450-instruction chain on one lane: the usual one or two selected candidates
+// of an ego no longer hold the workgroup's other waves at the barrier behind them (measured: the lane-per-candidate pass alone cost
+// 11 us of a 44 us kernel, with a third of the waves running it).  Test points and pieces as in station_pass_f2: station R by one piece of
+// R intervals (there: R single intervals), then every G-th station by pieces of G, the last station by a shorter piece when the tested
+// ones do not cover it; exact_all: every station, single intervals.  Positions differ from the sequential sums by roundings only (fewer:
+// a scan adds log-many terms into each), which the a-priori position bound already covers.  Everything but `lane` is wave-uniform.
+struct PassPlan { int nt, nm, first_m, tail_m, tail_pos; };      // test points; pieces of G; intervals of the first / the tail piece; station the tail starts at
+
+template <int R>
+__device__ __forceinline__ PassPlan pass_plan(int S, bool exact_all) {
+    constexpr int G = 2 * R + 1;
+    PassPlan p;
+    p.nm = 0; p.tail_m = 0; p.tail_pos = 0;
+    if (exact_all) { p.nt = S; p.first_m = 0; return p; }
+    if (!(G < S)) { p.first_m = R < S - 1 ? R : S - 1; p.nt = 1; return p; }
+    p.first_m = R;
+    p.nm = (S - 1 - R) / G;
+    p.tail_pos = R + p.nm * G;
+    p.tail_m = S - 1 > p.tail_pos + R ? S - 1 - p.tail_pos : 0;
+    p.nt = 1 + p.nm + (p.tail_m > 0 ? 1 : 0);
+    return p;
+}
+
+__device__ __forceinline__ float wave_scan_add(float v) {          // inclusive sum over the 64 lanes (all active)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));   // row_shr:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+template <int R>
+__device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
+                                                 const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
+    constexpr int G = 2 * R + 1;
+    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
+    const float ds = L * ep->inv_den, h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;
+    const float alpha = ds * (k0 * F1P_INV_2PI_F), beta = (ds * ds) * (0.5f * dk * F1P_INV_2PI_F);
+    // this lane's piece: m intervals ending at its test point, midpoint u (in interval units, u = index + 1/2 for a single interval)
+    float fm, um;
+    if (exact_all) { fm = lane > 0 ? 1.0f : 0.0f; um = (float)lane - 0.5f; }
+    else if (lane == 0) { fm = (float)pl.first_m; um = 0.5f * fm; }
+    else if (lane <= pl.nm) { fm = (float)G; um = (float)R + (float)G * ((float)lane - 0.5f); }
+    else { fm = (float)pl.tail_m; um = (float)pl.tail_pos + 0.5f * fm; }
+    const bool mine = lane < pl.nt;
+    const float hm = fm * h, bm = (fm * fm) * b;
+    const float A0 = k0 * hm, A1 = (dk * ds) * hm;
+    const float c0 = hm * __builtin_fmaf(bm * bm, -0.2f, 2.0f), c1 = hm * (-1.0f / 3.0f), c2 = hm * (1.0f / 60.0f);
+    const float d0 = (2.0f * bm) * (hm * (1.0f / 3.0f)), d1 = (2.0f * bm) * (hm * -0.1f);
+    const float thr = um * __builtin_fmaf(beta, um, alpha);
+    const float a = __builtin_fmaf(A1, um, A0);
+    const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
+    const float z = a * a;
+    const float Ph = __builtin_fmaf(z, __builtin_fmaf(z, c2, c1), c0);
+    const float Qh = __builtin_fmaf(z, d1, d0);
+    float dx = __builtin_fmaf(cs, Ph, -(sn * Qh)), dy = __builtin_fmaf(sn, Ph, cs * Qh);
+    if (!mine) { dx = 0.f; dy = 0.f; }
+    const float x = wave_scan_add(dx), y = wave_scan_add(dy);
+    // the look-up of station_pass_f2's test()
+    const float edge_hi = 1.0f - edge;
+    const float lxf = __builtin_fmaf(ep->txx, x, __builtin_fmaf(ep->txy, y, ep->tx0));
+    const float lyf = __builtin_fmaf(ep->tyx, x, __builtin_fmaf(ep->tyy, y, ep->ty0));
+    const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
+    const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
+    const unsigned addr = __umul24(lyc, pitch_bytes) + ((lxc >> 2) & ~7u);
+    const unsigned long long w = *reinterpret_cast<const F1P_LDS(unsigned long long)*>(tile + addr);   // low: clearance word, high: bitmap word
+    const uint32_t nc = __builtin_amdgcn_ubfe((uint32_t)w, lxc, 1u), oc = __builtin_amdgcn_ubfe((uint32_t)(w >> 32), lxc, 1u);
+    const float rx = __builtin_amdgcn_fractf(lxf), ry = __builtin_amdgcn_fractf(lyf);
+    const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
+    bool undecided, hitc;
+    if (!exact_all) { undecided = nc != 0u; hitc = !near && (nc & oc) != 0u; }
+    else { const bool off = (lx != (int)lxc) | (ly != (int)lyc); undecided = near | off; hitc = !undecided && oc != 0u; }
+    const bool nanpos = !(x == x) | !(y == y);                     // a NaN position converts to cell 0: nothing was decided
+    const bool any_nan = __ballot(mine & nanpos) != 0ull;
+    const bool hit_sure = __ballot(mine & hitc) != 0ull && !any_nan;
+    const bool unsure = never_free | (__ballot(mine & undecided) != 0ull) | any_nan;
+    return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
 }
 
 // ===================================================================================================================
@@ -1229,6 +1338,33 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         for (int j = lane; j < sim_m; j += 64) {
             const double p = pv[j], fj = (double)j;
             pm0 = __builtin_fma(p, p, pm0); pm1 = __builtin_fma(fj, p, pm1); pm2 = __builtin_fma(fj * fj, p, pm2);
+        }
+    }
+    // the ego's occupancy window (origin: a function of the position alone) and whether the ego itself stands in a cell that is not clear
+    // -- then no look-up of its candidates could say "clear", and the candidate kernel tests every station against the real bitmap
+    // (exact_all).  The word is requested here and consumed when the record is written.
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    int tile_gx0 = 0, tile_gy0 = 0;
+    double txo = 0.0, tyo = 0.0;                                 // the ego's position in cells, relative to the window origin
+    uint32_t own_word = 0xffffffffu;
+    int own_bit = -1;                                            // -1: outside the window (exact_all)
+    {
+        const double cxd = (px - a.grid.ox) * a.grid.inv_res, cyd = (py - a.grid.oy) * a.grid.inv_res;
+        if (collide_on) {
+            const double fx = __builtin_floor(cxd), fy = __builtin_floor(cyd);
+            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+            const int half = a.tile_rows / 2;
+            tile_gx0 = ((egx - half) >> 5) << 5;
+            tile_gy0 = egy - half;
+        }
+        txo = cxd - (double)tile_gx0; tyo = cyd - (double)tile_gy0;
+        if (lane == 0 && mx.clear_bits) {
+            const int lx0 = cvt_flr_i32_f32((float)txo), ly0 = cvt_flr_i32_f32((float)tyo);
+            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+                own_bit = lx0 & 31;
+                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
+                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) own_word = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];   // (off the map: not clear)
+            }
         }
     }
     double sn_t = 0.0, cs_t = 1.0;
@@ -1288,26 +1424,15 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     }
     F1P_PPH();
     if (lane == 0) {
-        const bool collide_on = cfg.check_collision && a.has_grid;
-        int tile_gx0 = 0, tile_gy0 = 0;
-        if (collide_on) {
-            const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
-            const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
-            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
-            const int half = a.tile_rows / 2;
-            tile_gx0 = ((egx - half) >> 5) << 5;
-            tile_gy0 = egy - half;
-        }
         EgoXform xf;
-        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
-        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
+        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = txo;
+        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = tyo;
         xf.tile_gx0 = tile_gx0; xf.tile_gy0 = tile_gy0;
         mx.xf[e] = xf;                                                        // the refinement kernel's fp64 cell arithmetic
         mx.ego_ni[e] = ni;
         EgoRecHdr h;
         h.px = px; h.py = py; h.theta = theta; h.ct = cs_t; h.st = sn_t;
         const int den = S - 1 > 1 ? S - 1 : 1;
-        const int pitch = a.tile_words + 1;
         EgoParamsF2& p = h.p;
         p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
         p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
@@ -1319,10 +1444,9 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
         p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
         p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
-        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.pitch_bytes = pitch * 8;   // a row of (clearance, bitmap) word pairs
-        p.occ_off = 0;
+        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = tile_gx0; p.tile_gy0 = tile_gy0;
         p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
-        p.exact_all = 0;
+        p.exact_all = own_bit < 0 ? 1 : (int)((own_word >> own_bit) & 1u);
         *reinterpret_cast<EgoRecHdr*>(rec) = h;
     }
     F1P_PPH();
@@ -1354,7 +1478,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int pitch = a.tile_words + 1;
     const unsigned tile_bytes = (unsigned)(a.tile_rows + 1) * (unsigned)pitch * 4u;
-    uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);
+    uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);       // (clearance word, bitmap word) pairs: (tile_rows + 1) x pitch, the last row / column the guard
     const int nl = cfg.n_lookahead;
     const size_t rec_bytes = ego_rec_stride(nl);
     unsigned char* rec = lds_raw + (((size_t)tile_bytes * 2 + 15) & ~(size_t)15);
@@ -1362,14 +1486,15 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     double* cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
     GoalFrame32* gfr = reinterpret_cast<GoalFrame32*>(cen + 5 * (size_t)nl);
     double* wtab = reinterpret_cast<double*>(rec + rec_bytes);   // [64] lateral offsets (LDS copy: indexed per lane)
-    float* red_f = reinterpret_cast<float*>(wtab + F1P_MAX_WIDTHS);   // [4]
-    int* cnt = reinterpret_cast<int*>(red_f + 4);                // [4]: refine count, queue base
+    float* red_f = reinterpret_cast<float*>(wtab + F1P_MAX_WIDTHS);   // [3 reductions][2 values][4 waves]
+    int* cnt = reinterpret_cast<int*>(red_f + 24);               // [4]: refine count, queue base
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int C = nl * cfg.n_width;
     const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
     const int nc = c1 - c0;
     float* c_lo = reinterpret_cast<float*>(cnt + 4);             // [nc] per-candidate lower bound of the fp64 cost
-    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_lo + nc);          // [nc] state
+    float* c_hi = c_lo + nc;                                     // [nc] ... and upper bound
+    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_hi + nc);          // [nc] state (bit 7: can no longer turn out FREE)
     // a workgroup takes egos blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher sizes the grid: F1P_MIX_F3_EGOS_PER_WG egos each)
 #if F1P_MIX_F3_EGOS_PER_WG > 1
     for (int e = a.e0 + blockIdx.x; e < a.E; e += gridDim.x) {
@@ -1384,10 +1509,73 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         uint32_t* dst = reinterpret_cast<uint32_t*>(rec);
         for (int q = tid; q < (int)(rec_bytes >> 2); q += blockDim.x) dst[q] = src[q];
     }
-    // ---- the tiles (their origin: two integers the prologue left beside the ego's cell transform -- round 3 recomputed it from the
-    // pose in fp64, ~25 slow-class instructions per thread) ------------------------------------------------------------------------
+    if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
+    if (tid == 0) cnt[0] = 0;
+#ifdef F1P_F3_PHASES
+    long long fph[10]; int nfp = 0;
+#define F1P_FPH() do { fph[nfp++] = clock64(); } while (0)
+#else
+#define F1P_FPH() do {} while (0)
+#endif
+    F1P_FPH();
+    __syncthreads();
+    F1P_FPH();
+    const F1P_LDS(EgoParamsF2)* ep = (const F1P_LDS(EgoParamsF2)*)&hdr->p;
+    const bool one_pass = c0 + (int)blockDim.x >= c1;            // one candidate per thread (workgroup-uniform): its fit stays in registers between the phases
+    // Thread -> candidate: rotated by a hash of the ego, a wave keeps 64 consecutive candidates.  The few candidates the station pass selects
+    // are neighbours in cost and mostly in index (the far look-ahead rows): with the identity mapping they sit in the SAME wave of every
+    // workgroup -- and wave w of every resident workgroup shares SIMD w, so one SIMD per CU ran every pass while three idled (measured:
+    // filter 53 us against 41 before the lazy pass).
+    const int ptid = blockDim.x == 256 ? (tid + (int)((((unsigned)e * 0x9E3779B1u) >> 30) << 6)) & 255 : tid;
+    const bool all_states = mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
+    const float inv_nw = 1.0f / (float)cfg.n_width;
+    const float INF = __builtin_huge_valf();
+
+    // ---- phase 1, every candidate in f32: goal -> G1 fit -> cost and bracket [lo, hi]; nothing looks at positions -------------------
+    float kf_k0 = 0.f, kf_dk = 0.f, kf_L = 0.f, kf_edge = 0.f;    // the one-pass thread's fit for the station pass
+    auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& edge, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
+        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
+        const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
+        int st = F1P_ST_BAD;
+        lo = INF; hi = INF; k0 = 0.f; dk = 0.f; L = 0.f; edge = 0.f; gx = 0.f; gy = 0.f; dbg_code = -1;
+        o.cost = INF; o.ebound = 0.f; o.never_free = true;
+        if (gf->ok) {
+            const double w = ((const F1P_LDS(double)*)wtab)[k];
+            gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+            const float r2 = gx * gx + gy * gy;
+            st = F1P_ST_UNSURE; lo = -INF;                                     // until a trusted bracket says otherwise: the fp64 tests decide
+            if (r2 > 1e-8f && r2 < 1e20f) {                                    // (tiny, huge or NaN in f32: g1_fit rejects r <= 1e-12 itself)
+                const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
+                if (f.ok) {
+                    o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
+                    st = o.state | (o.never_free ? 0x80 : 0);
+                    lo = o.lo; hi = o.hi; k0 = f.k0; dk = f.dk; L = f.L; edge = o.edge;
+                } else dbg_code = f.why;
+            }
+        }
+        return st;
+    };
+    float my_hi_p = INF;                                          // min hi over this thread's PENDING candidates
+    for (int cb = c0; cb < c1; cb += blockDim.x) {
+        const int c = cb + ptid;
+        if (c >= c1) continue;
+        float lo, hi, gx, gy; Brk32 o; int dbg_code;
+        const int st = bracket_of(c, kf_k0, kf_dk, kf_L, kf_edge, lo, hi, gx, gy, o, dbg_code);
+        c_lo[c - c0] = lo; c_hi[c - c0] = hi;
+        c_st[c - c0] = (unsigned char)st;
+        if ((st & 0x7f) == F1P_ST_PENDING) my_hi_p = fminf(my_hi_p, hi);
+#if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES)
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
+        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+#elif defined(F1P_MIX_DEBUG_END)
+        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = 0.0f;
+        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+#endif
+        if (mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
+    }
+    // ---- the tiles for the station pass: requested now, behind the candidates' arithmetic; the first reduction's barrier publishes them
     {
-        const int tile_gx0 = mx.xf[e].tile_gx0, tile_gy0 = mx.xf[e].tile_gy0;
+        const int tile_gx0 = __builtin_amdgcn_readfirstlane(ep->tile_gx0), tile_gy0 = __builtin_amdgcn_readfirstlane(ep->tile_gy0);
         const int lsh = pitch <= 8 ? 3 : 4, lw = 1 << lsh;
         const int j = tid & (lw - 1);
         const int gw = (tile_gx0 >> 5) + j;
@@ -1405,68 +1593,96 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
             }
         }
     }
-    if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
-    if (tid == 0) cnt[0] = 0;
-    __syncthreads();
-    if (tid == 0) {     // an ego that itself stands in a cell that is not clear would leave every candidate undecided: its workgroup tests every station against the real bitmap
-        const float tx0 = hdr->p.tx0, ty0 = hdr->p.ty0;
-        const int lx0 = cvt_flr_i32_f32(tx0), ly0 = cvt_flr_i32_f32(ty0);
-        uint32_t cd = 1u;
-        if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) cd = (tile[2 * (ly0 * pitch + (lx0 >> 5))] >> (lx0 & 31)) & 1u;
-        hdr->p.exact_all = (int)cd;
-    }
-    __syncthreads();
-
-    // ---- every candidate in f32: state + [lo, hi] ---------------------------------------------------------------------------------
-    float t_min = __builtin_huge_valf();                          // min hi over this thread's FREE candidates
-    const float inv_nw = 1.0f / (float)cfg.n_width;
-    for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
-        if (c >= c1) continue;
-        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
-        const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
-        Filt32 o;
-        int dbg_code = -1;
-        o.cost = __builtin_huge_valf(); o.lo = __builtin_huge_valf(); o.hi = __builtin_huge_valf(); o.state = F1P_ST_BAD; o.xe = 0.f; o.ye = 0.f; o.ebound = 0.f;
-        float gx = 0.f, gy = 0.f;
-        if (gf->ok) {
-            const double w = ((const F1P_LDS(double)*)wtab)[k];
-            gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
-            const float r2 = gx * gx + gy * gy;
-            if (r2 > 1e-8f && r2 < 1e20f) {
-                const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
-                if (f.ok) o = station_loop_f2<CR>(f, (const F1P_LDS(EgoParamsF2)*)&hdr->p, (const F1P_LDS(unsigned char)*)lds_raw, mx.sim_s2, mx.sim_s3, mx.sim_s4);
-                else { o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); dbg_code = f.why; }
-            } else {                                                      // tiny, huge or NaN in f32: the fp64 tests decide (g1_fit rejects r <= 1e-12)
-                o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf();
-            }
-        }
-        c_lo[c - c0] = o.lo;
-        c_st[c - c0] = (unsigned char)o.state;
-        if (o.state == F1P_ST_FREE) t_min = fminf(t_min, o.hi);
-#ifdef F1P_MIX_DEBUG_END
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = (o.state != F1P_ST_BAD && dbg_code < 0) ? __builtin_sqrtf((gx - o.xe) * (gx - o.xe) + (gy - o.ye) * (gy - o.ye)) : 0.0f;
-        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
-#elif !defined(F1P_PRO_PHASES)
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
-        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
-#endif
-        if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : (o.state == F1P_ST_UNSURE && o.lo == -__builtin_huge_valf() ? 5 : o.state);
-    }
+    // workgroup minimum of two values (slot = which of the three reductions: no barrier between them)
+    auto wg_min2 = [&](int slot, float& v0, float& v1) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) t_min = fminf(t_min, __shfl_xor(t_min, m, 64));
-    if (lane == 0) red_f[wave] = t_min;
-    __syncthreads();
-    t_min = red_f[0];
-    for (int w = 1; w < nwaves; ++w) t_min = fminf(t_min, red_f[w]);
+        for (int m = 32; m >= 1; m >>= 1) { v0 = fminf(v0, __shfl_xor(v0, m, 64)); v1 = fminf(v1, __shfl_xor(v1, m, 64)); }
+        float* r = red_f + slot * 8;
+        if (lane == 0) { r[wave] = v0; r[4 + wave] = v1; }
+        __syncthreads();
+        v0 = r[0]; v1 = r[4];
+        for (int w = 1; w < nwaves; ++w) { v0 = fminf(v0, r[w]); v1 = fminf(v1, r[4 + w]); }
+    };
+
+    // ---- phase 2, the station pass in rounds.  Needed: T = min hi over the FREE candidates, and the state of every candidate with
+    // lo <= T.  Round 1 looks at the candidates whose bracket reaches below the smallest hi (the apparent winner and whatever it cannot
+    // be told from); with a FREE one among them T1 = its hi bounds T, and round 2 looks at the remaining candidates below T1 (usually
+    // none: the round is skipped); without one, round 2 looks at everything left.  A wave with no selected lane skips its pass.
+    const bool exact_all_wg = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
+    const PassPlan plan = pass_plan<CR>(__builtin_amdgcn_readfirstlane(ep->S), exact_all_wg);
+    float t_free = INF;                                           // min hi over this thread's FREE candidates
+    float thr = my_hi_p, unused = INF;
+    F1P_FPH();
+    wg_min2(0, thr, unused);
+    F1P_FPH();
+    for (int round = 0; round < 2; ++round) {
+        float my_lo_p = INF;                                      // min lo over this thread's candidates still PENDING after the round
+        for (int cb = c0; cb < c1; cb += blockDim.x) {
+            const int c = cb + ptid;
+            const int st = c < c1 ? (int)c_st[c - c0] : F1P_ST_BAD;
+            const float lo = c < c1 ? c_lo[c - c0] : INF;
+#ifdef F1P_F3_NO_PASS
+            const bool sel = false && (st & 0x7f) == F1P_ST_PENDING && (all_states || !(lo > thr));   // timing experiment only: WRONG results
+#else
+            const bool sel = (st & 0x7f) == F1P_ST_PENDING && (all_states || !(lo > thr));
+#endif
+            const unsigned long long selm = __ballot(sel);
+            if (selm) {                                           // wave-uniform
+                float k0 = kf_k0, dk = kf_dk, L = kf_L, edge = kf_edge;
+                if (!one_pass && sel) {                           // several candidates per thread: the selected one is fitted again
+                    float lo2, hi2, gx, gy; Brk32 o; int dbg_code;
+                    (void)bracket_of(c, k0, dk, L, edge, lo2, hi2, gx, gy, o, dbg_code);
+                }
+                int ns = F1P_ST_PENDING;
+                [[maybe_unused]] float xe = 0.f, ye = 0.f;
+#ifndef F1P_MIX_DEBUG_END
+                if (F1P_MIX_MACRO && plan.nt <= 64 && __builtin_popcountll(selm) <= F1P_MIX_COOP_MAX) {
+                    // a few selected candidates: the whole wave takes them one at a time (lane = test point)
+                    for (unsigned long long m = selm; m; m &= m - 1) {
+                        const int sl = __ffsll((long long)m) - 1;
+                        const float uk0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k0), sl)), udk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), sl));
+                        const float uL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L), sl)), uedge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edge), sl));
+                        const bool unf = (__builtin_amdgcn_readlane(st, sl) & 0x80) != 0;
+                        const int r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, lane, plan, exact_all_wg);
+                        if (lane == sl) ns = r;
+                    }
+                } else
+#endif
+                if (sel) ns = station_pass_f2<CR>(k0, dk, L, edge, (st & 0x80) != 0, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, xe, ye);
+                if (sel) {
+                    c_st[c - c0] = (unsigned char)ns;
+                    if (ns == F1P_ST_FREE) t_free = fminf(t_free, c_hi[c - c0]);
+                    if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = ns;
+#ifdef F1P_MIX_DEBUG_END
+                    if (mx.dbg_cost32) {
+                        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;
+                        const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
+                        const double w = ((const F1P_LDS(double)*)wtab)[k];
+                        const float gx = (float)__builtin_fma(w, gf->nx, gf->cx), gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+                        mx.dbg_cost32[(size_t)e * C + c] = __builtin_sqrtf((gx - xe) * (gx - xe) + (gy - ye) * (gy - ye));
+                    }
+#endif
+                }
+            }
+            if (!sel && (st & 0x7f) == F1P_ST_PENDING) my_lo_p = fminf(my_lo_p, lo);
+        }
+        float t = t_free;
+        F1P_FPH();
+        wg_min2(1 + round, t, my_lo_p);
+        F1P_FPH();
+        thr = t < INF ? t : INF;                                  // round 2: below T1 -- or, with nothing FREE yet, everything left
+        t_free = t;
+        if (round == 0 && !(my_lo_p <= thr)) break;               // nothing PENDING reaches below T1 (or nothing is PENDING): done, workgroup-uniform
+    }
+    const float t_min = t_free;                                   // (after its reduction: the workgroup's T)
 
     // ---- the candidates only fp64 can rank: count, reserve queue space, write the entries (goals by the fp64 arithmetic of candidate_goal)
-    const bool none_free = !(t_min < __builtin_huge_valf());
+    const bool none_free = !(t_min < INF);
     int mine = 0;
     for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
+        const int c = cb + ptid;
         if (c >= c1) continue;
-        const int st = c_st[c - c0];
+        const int st = c_st[c - c0] & 0x7f;
         const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
         mine += (need | (none_free & (c == c0))) ? 1 : 0;
     }
@@ -1481,12 +1697,11 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         mx.ego_base[e] = (int)base; mx.ego_n[e] = n;
     }
     // (one candidate per thread, the usual case: the entry's fp64 goal is formed while thread 0's queue-reserving atomic is on its way)
-    const bool one_pass = c0 + (int)blockDim.x >= c1;            // workgroup-uniform
     double g1x = 0.0, g1y = 0.0, g1th = 0.0;
     int ok1 = 0;
     bool need1 = false;
-    if (one_pass && c0 + tid < c1) {
-        const int c = c0 + tid, st = c_st[c - c0];
+    if (one_pass && c0 + ptid < c1) {
+        const int c = c0 + ptid, st = c_st[c - c0] & 0x7f;
         need1 = (((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min)) | (none_free & (c == c0));
         if (need1) {
             const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
@@ -1498,16 +1713,16 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     if (one_pass) {
         if (need1) {
             RefEntry r;
-            r.e = e; r.c = c0 + tid; r.gx = g1x; r.gy = g1y; r.gth = g1th;
+            r.e = e; r.c = c0 + ptid; r.gx = g1x; r.gy = g1y; r.gth = g1th;
             // ok: 0 = no goal (infeasible), -1 = evaluate, -2 = evaluate, certainly collision-free (the occupancy test is skipped)
             r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = ok1; r.pad = 0;
             mx.q[base + pos] = r;
         }
     } else
     for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
+        const int c = cb + ptid;
         if (c >= c1) continue;
-        const int st = c_st[c - c0];
+        const int st = c_st[c - c0] & 0x7f;
         const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
         if (need | (none_free & (c == c0))) {
             double gx = 0.0, gy = 0.0, gth = 0.0;
@@ -1519,6 +1734,14 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
             ++pos;
         }
     }
+#ifdef F1P_F3_PHASES
+    F1P_FPH();
+    if (mx.dbg_cost32 && !mx.dbg_state && lane == 0) {           // per wave: stamps relative to the first, slot 16 w ..
+        float* d = mx.dbg_cost32 + (size_t)e * C + 16 * wave;
+        for (int k = 1; k < nfp; ++k) d[k] = (float)(fph[k] - fph[0]);
+        d[0] = (float)nfp; d[15] = (float)(fph[0] & 0xffffff);
+    }
+#endif
 #if F1P_MIX_F3_EGOS_PER_WG > 1
     __syncthreads();                                             // the LDS blocks are reused by the workgroup's next ego
 #endif
@@ -2111,10 +2334,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             const bool prof = ctx->lattice_profile && ctx->ev_prof[0];
             const dim3 fb(F1P_MIX_FILTER_BLOCK);
             // round 3: the rebuilt filter for the headline configuration (device-sampled goals, clearance mode, point footprint) ...
-            const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
             // ... as two kernels (prologue: one wave per ego; filter3: candidates only)
             const size_t rec_stride = ego_rec_stride(cfg->n_lookahead);
-            size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 4 + sizeof(int) * 4 + (size_t)n_cand * 5 + 16;
+            const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
+            size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + 16;
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const bool v3 = F1P_MIX_FILTER_V3 && !a.goals && mx.n_disc == 0 && (mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
                             (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) : lds_fits(ctx, k_lattice_filter3<2>, lds_f3));
