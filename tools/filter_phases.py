@@ -32,19 +32,3 @@ with Context(0) as ctx:
         for j in range(d.shape[1]): print(f"   {labels[j] if j < len(labels) else j:50s} mean {d[:, j].mean():8.0f}  p90 {np.percentile(d[:, j], 90):8.0f}  max {d[:, j].max():8.0f}")
     t0 = raw[:, 0, 15]
     print("start-time spread (mod 2^24):", np.ptp(t0))
-    # timeline: start (24 low bits of the clock, unwrapped against the earliest) and end of every workgroup (wave 0's stamps)
-    k0 = raw[:, 0, 0].astype(int)
-    start = raw[:, 0, 15].astype(np.int64)
-    ref = np.median(start)
-    start = ((start - ref + (1 << 23)) % (1 << 24)) - (1 << 23)      # centred on the median
-    start -= start.min()
-    life = np.array([raw[i, 0, k0[i] - 1] for i in range(E)])
-    end = start + life
-    print(f"workgroup starts: p1 {np.percentile(start, 1):.0f}  p25 {np.percentile(start, 25):.0f}  p50 {np.percentile(start, 50):.0f}  p75 {np.percentile(start, 75):.0f}  p99 {np.percentile(start, 99):.0f}  max {start.max():.0f} cycles after the first")
-    print(f"workgroup ends:   p1 {np.percentile(end, 1):.0f}  p50 {np.percentile(end, 50):.0f}  p90 {np.percentile(end, 90):.0f}  p99 {np.percentile(end, 99):.0f}  max {end.max():.0f}")
-    order = np.argsort(start)
-    print("lifetime by start-time decile:", [int(life[order[i * E // 10:(i + 1) * E // 10]].mean()) for i in range(10)])
-    print("start of decile:", [int(start[order[i * E // 10]]) for i in range(10)])
-    edges = np.arange(0, end.max() + 5000, 5000)
-    running = [(int(t), int(((start <= t) & (end > t)).sum())) for t in edges]
-    print("workgroups in flight at t:", running)
