@@ -1636,7 +1636,9 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                 int ns = F1P_ST_PENDING;
                 [[maybe_unused]] float xe = 0.f, ye = 0.f;
 #ifndef F1P_MIX_DEBUG_END
-                if (F1P_MIX_MACRO && plan.nt <= 64 && __builtin_popcountll(selm) <= F1P_MIX_COOP_MAX) {
+                // (test hook: with every state wanted, odd egos take the cooperative pass for all their candidates, even egos the lane-per-candidate
+                // pass -- tests/test_gpu_lattice_mixed.py checks the claims of both)
+                if (F1P_MIX_MACRO && plan.nt <= 64 && (__builtin_popcountll(selm) <= F1P_MIX_COOP_MAX || (all_states && (e & 1)))) {
                     // a few selected candidates: the whole wave takes them one at a time (lane = test point)
                     for (unsigned long long m = selm; m; m &= m - 1) {
                         const int sl = __ffsll((long long)m) - 1;

@@ -138,6 +138,38 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
 
 
+def test_lazy_station_pass_agrees_with_the_eager_one(ctx, scene):
+    """round 4: the candidate kernel looks at positions only for the candidates whose bracket reaches below the best collision-free one,
+    and a wave takes them cooperatively (lane = test point).  (a) the refinement queue is the one the eager evaluation (every candidate,
+    debug hook) produces; (b) the cooperative and the lane-per-candidate pass -- the hook runs them on odd / even egos -- give the same
+    verdict for all but a vanishing share of the candidates (a station within a rounding of a cell edge band), and both kinds of claim
+    hold in fp64 (test_filter_bracket_and_states_hold_against_fp64)"""
+    rl, img, origin = scene
+    C, S = 256, 50
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    for sigma, seed in ((0.3, 21), (0.9, 22)):
+        E = 600
+        poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sigma)
+        poses[3, :2] += [1.4, 1.4]; poses[4, :2] += 300.0                                  # in the wall (every station tested) / off the map
+        d_c, d_s = ctx.alloc(4 * (E + 1) * C), ctx.alloc(4 * (E + 1) * C)
+        ctx.lattice_set_mode(2)
+        lazy = ctx.lattice_plan(poses, cfg); n_lazy = ctx.lattice_debug_queue(E)
+        ctx.lattice_set_mode(2, d_c, d_s)
+        eager = ctx.lattice_plan(poses, cfg); n_eager = ctx.lattice_debug_queue(E)
+        st_a = d_s.download(np.int32, (E + 1, C))[:E].copy()
+        np.testing.assert_array_equal(n_lazy, n_eager)
+        for k in lazy:
+            np.testing.assert_array_equal(lazy[k], eager[k], err_msg=k)
+        assert 1.0 <= n_lazy.mean() < 6.0 and (n_lazy >= 1).all()
+        shifted = np.concatenate([poses[:1], poses])                                    # every ego's index parity flips: the other pass
+        ctx.lattice_plan(shifted, cfg)
+        st_b = d_s.download(np.int32, (E + 1, C))[1:].copy()
+        ctx.lattice_set_mode(1)
+        assert (st_a != st_b).mean() < 2e-3, float((st_a != st_b).mean())
+        assert ((st_a == 0).mean() > 0.2) and ((st_b == 0).mean() > 0.2)
+        d_c.free(); d_s.free()
+
+
 def test_clearance_mode_is_exact_and_follows_the_bitmap(ctx, scene):
     """f1p_lattice_set_clearance: one station in 2 r + 1 looked up in the clearance map (r = 1 default, 2) against every station on
     the bitmap (r = 0) and the all-fp64 kernel: bit-identical outputs on centred, off-centre and wall-hugging egos; the filter's
