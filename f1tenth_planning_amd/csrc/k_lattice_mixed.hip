@@ -1239,6 +1239,16 @@ __device__ __forceinline__ float wave_scan_add(float v) {          // inclusive 
     return v;
 }
 
+__device__ __forceinline__ float wave_min_f32(float v) {          // minimum over the 64 lanes (all active), in every lane; NaN operands are dropped (fminf)
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x112, 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x114, 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x118, 0xf, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int R>
 __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
                                                  const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
@@ -1314,6 +1324,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     __shared__ int s_ok[4][F1P_MAX_LOOKAHEADS];
     __shared__ int s_first[4][F1P_MAX_LOOKAHEADS];               // one wave holds every look-ahead row of its ego
     __shared__ int s_pairs[4][64];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = a.e0 + blockIdx.x * 4 + wave;
     if (e >= a.E) return;                                        // wave-uniform
@@ -1476,6 +1487,7 @@ __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, i
 template <int CR>
 __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
     const int pitch = a.tile_words + 1;
     const unsigned tile_bytes = (unsigned)(a.tile_rows + 1) * (unsigned)pitch * 4u;
     uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);       // (clearance word, bitmap word) pairs: (tile_rows + 1) x pitch, the last row / column the guard
@@ -1595,8 +1607,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     }
     // workgroup minimum of two values (slot = which of the three reductions: no barrier between them)
     auto wg_min2 = [&](int slot, float& v0, float& v1) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { v0 = fminf(v0, __shfl_xor(v0, m, 64)); v1 = fminf(v1, __shfl_xor(v1, m, 64)); }
+        v0 = wave_min_f32(v0); v1 = wave_min_f32(v1);
         float* r = red_f + slot * 8;
         if (lane == 0) { r[wave] = v0; r[4 + wave] = v1; }
         __syncthreads();
@@ -1769,9 +1780,20 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 // GS = lanes per entry: 16 (four entries per wave: the scalar prologue / epilogue -- atan2, the model's Newton steps, interval_setup, the
 // sequential sums -- is a third of the work and is shared by four entries then) or 64 (one wave per entry: when four per-entry LDS
 // blocks per wave do not fit, i.e. very long station counts).  Lanes of a group hold identical per-entry values.
+// value of the lane below within a GS-lane group (16: a DPP row; 64: the wave), + 0.0 into the group's first lane
+template <int GS>
+__device__ __forceinline__ double group_shr1(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    constexpr int ctrl = GS == 16 ? 0x111 : 0x138;               // row_shr:1 / wave_shr:1
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false), shi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)shi << 32) | (long long)(unsigned int)slo);
+}
+
 template <int GS, bool FOOT = false>
 __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
     constexpr int GPW = 64 / GS;                                 // groups (entries) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
@@ -1791,8 +1813,8 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
     __syncthreads();
 #ifdef F1P_MIX_PHASES
-    long long rph[8]; int nrp = 0;
-#define F1P_RPH() do { rph[nrp++] = clock64(); } while (0)
+    long long rph[16]; int nrp = 0;
+#define F1P_RPH() do { if (nrp < 15) rph[nrp++] = clock64(); } while (0)
 #else
 #define F1P_RPH() do {} while (0)
 #endif
@@ -1804,17 +1826,23 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     const unsigned int ngroups_total = gridDim.x * (blockDim.x >> 6) * GPW;
     const unsigned int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * GPW + grp;
     const unsigned int sh = g0 % F1P_MIX_QSHARDS, lstride = ngroups_total / F1P_MIX_QSHARDS;
-    const unsigned int n = mx.qcount[sh * 32u];
+    // The group's first entry is requested TOGETHER with the shard's count, not after it (slots past the count hold stale entries of
+    // earlier plans -- readable memory, masked below).  Written as two loads and one use of both: with the entry's load behind the
+    // `any live` exit, which needs the count, the two round trips ran one after the other (4.4 k cycles per entry, tools/refine_phases.py).
+    RefEntry r_first;
+    r_first.ok = 0; r_first.e = 0; r_first.c = 0; r_first.gx = 0; r_first.gy = 0; r_first.gth = 0; r_first.cost = 0; r_first.k0 = 0; r_first.dk = 0; r_first.L = 0; r_first.pad = 0;
+    unsigned int n = mx.qcount[sh * 32u];
+    if (g0 / F1P_MIX_QSHARDS < mx.q_shard_cap) r_first = mx.q[sh * mx.q_shard_cap + g0 / F1P_MIX_QSHARDS];
+    asm volatile("" : "+v"(n), "+v"(r_first.ok));
     for (unsigned int ib = 0, li = g0 / F1P_MIX_QSHARDS; ; ib += ngroups_total, li += lstride) {
         const unsigned int i = sh * mx.q_shard_cap + li;
         const bool live = li < n;
-        (void)ib;
         if (!__any(live)) break;                                     // wave-uniform exit; groups past the end idle through the barriers
-        RefEntry r;
-        r.ok = 0; r.e = 0; r.c = 0; r.gx = 0; r.gy = 0; r.gth = 0; r.cost = 0; r.k0 = 0; r.dk = 0; r.L = 0; r.pad = 0;
-        // (the entry is requested together with the shard's count, not after it: slots past the count hold stale entries of earlier
-        // plans -- readable memory, masked below)
-        if (li < mx.q_shard_cap) r = mx.q[i];
+        RefEntry r = r_first;
+        if (ib != 0) {
+            r.ok = 0; r.e = 0; r.c = 0; r.gx = 0; r.gy = 0; r.gth = 0; r.cost = 0; r.k0 = 0; r.dk = 0; r.L = 0; r.pad = 0;
+            if (li < mx.q_shard_cap) r = mx.q[i];
+        }
         if (!live) { r.ok = 0; r.e = a.e0; r.c = 0; }
         F1P_RPH();
         const bool work = live && r.ok != 0;                         // ok == 0: no goal -- the filter wrote cost = +inf, zero clothoid
@@ -1835,6 +1863,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         G1State g;
         g.r = 0; g.phi0 = 0; g.delta = 0; g.A = 0;
         bool fitting = work && g1_begin(r.gx, r.gy, r.gth, g);
+        F1P_RPH();
         double c0 = 0.0;
         bool ok = false;
         for (int it = 0; it < 20 && __any(fitting); ++it) {          // g1_fit's own iteration (one pass in all but pathological goals)
@@ -1866,6 +1895,9 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
+#ifdef F1P_MIX_PHASES
+                if (it == 0) F1P_RPH();
+#endif
                 if (gl < 12) {
                     const double* v = gl < 6 ? ncs : nsn;
                     if (rule16) {                                    // the same sixteen fma in the same order, operands read ahead
@@ -1927,6 +1959,9 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
             FitMoments m;
 #pragma unroll
             for (int q = 0; q < 6; ++q) { m.c[q] = shfl_d(acc, gbase + q); m.s[q] = shfl_d(acc, gbase + 6 + q); }
+#ifdef F1P_MIX_PHASES
+            if (it == 0) F1P_RPH();
+#endif
             if (fitting) {
                 const int st = g1_step(m, g, c0);
                 if (st != 0) { fitting = false; ok = st > 0; }
@@ -1946,6 +1981,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         // an entry the filter proved collision-free computes them only for that hand-over, beside the other groups' occupancy passes
         const bool store_inc = run && mx.inc != nullptr && li < mx.inc_cap;
         const bool inc_pass = occ_pass || store_inc;
+        double rix[4] = {0.0, 0.0, 0.0, 0.0}, riy[4] = {0.0, 0.0, 0.0, 0.0};   // this lane's interval increments (up to four intervals per lane)
         if (__any(inc_pass)) {
             if (inc_pass) {
                 const IntervalCoef ic = interval_setup(k0, dk, L, ds);
@@ -1953,7 +1989,17 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
                 // evaluation loop runs, re-anchoring inside interval_increment), so one piece_state_at per lane instead of one per
                 // interval -- three anchors (six fp64 sincos) and their advances fewer in the usual 49 intervals over 16 lanes
                 const int per = (S - 1 + GS - 1) / GS, q0 = gl * per, q1 = q0 + per < S - 1 ? q0 + per : S - 1;
-                if (q0 < q1) {
+                if (!FOOT && per <= 4) {                          // (group-uniform; the usual case) a lane's increments stay in registers (the footprint instantiations have none to spare)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { rix[k] = 0.0; riy[k] = 0.0; }
+                    if (q0 < q1) {
+                        PieceState st = piece_state_at(k0, dk, ds, q0, ic);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (q0 + k < q1) interval_increment(k0, dk, (double)(q0 + k) * ds, (q0 + k) * ic.nsub, ic, st, rix[k], riy[k]);
+                        }
+                    }
+                } else if (q0 < q1) {
                     PieceState st = piece_state_at(k0, dk, ds, q0, ic);
                     for (int q = q0; q < q1; ++q) {
                         double dx, dy;
@@ -1974,25 +2020,55 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
                 // left in LDS.  Eight increments are read ahead of their eight additions: read-then-add per element was one LDS round trip
                 // per station (~100 cycles x 49: a quarter of an entry's lifetime).  Past the last interval the sums take + 0.0, an
                 // identity (they start at + 0.0 and can never be - 0.0), so the loop has no per-element branch.
-                double x = 0.0, y = 0.0;
+                // (round 4: whole blocks of eight without a per-element select -- `x += in ? dx : 0.0` compiled to four v_cndmask on VCC, 16
+                // cycles each: 175 cycles per station, 8.6 k per entry, tools/refine_phases.py -- and the remainder one by one)
+                const int per = (S - 1 + GS - 1) / GS;
                 if (gl == 0) { pos_x[0] = 0.0; pos_y[0] = 0.0; }
-                for (int j0 = 0; j0 < S - 1; j0 += 8) {
-                    double dx[8], dy[8];
+                if (!FOOT && per <= 4) {
+                    // Round 4: the running sums as a systolic chain over the group's lanes.  Lane l holds the increments of intervals l per ..
+                    // l per + per - 1; with x_in(l) = x_out(l - 1) (a DPP shift, 0 into lane 0) and x_out = (((x_in + i0) + i1) + i2) + i3, lane l
+                    // is right after l + 1 rounds and stays right (its input no longer changes): ceil((S - 1) / per) rounds of eight additions in
+                    // registers give every lane the sum entering its intervals -- the additions of the evaluation loop, in its order (a lane's
+                    // unused slots add + 0.0, an identity: the sums start at + 0.0 and never become - 0.0).  The block-of-eight loop below read every
+                    // increment back from LDS in every lane and wrote every position from lane 0: 4.7 k cycles per entry against ~1.5 k.
+                    const int nrounds = (S - 1 + per - 1) / per;
+                    double xin = 0.0, yin = 0.0, xo = 0.0, yo = 0.0;
+                    for (int t = 0; t < nrounds; ++t) {
+                        xin = group_shr1<GS>(xo); yin = group_shr1<GS>(yo);
+                        xo = xin; yo = yin;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u < S - 1 ? j0 + u : S - 2;
-                        dx[u] = inc_x[j]; dy[u] = inc_y[j];
+                        for (int k = 0; k < 4; ++k) { xo += rix[k]; yo += riy[k]; }
                     }
+                    double x = xin, y = yin;
+                    const int q0 = gl * per;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool in = j0 + u < S - 1;
-                        x += in ? dx[u] : 0.0; y += in ? dy[u] : 0.0;
-                        if (in && gl == 0) { pos_x[j0 + u + 1] = x; pos_y[j0 + u + 1] = y; }
+                    for (int k = 0; k < 4; ++k) {
+                        x += rix[k]; y += riy[k];
+                        if (k < per && q0 + k < S - 1) { pos_x[q0 + k + 1] = x; pos_y[q0 + k + 1] = y; }
                     }
+                } else {
+                double x = 0.0, y = 0.0;
+                int j0 = 0;
+                for (; j0 + 8 <= S - 1; j0 += 8) {
+                    double dx[8], dy[8], xs[8], ys[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { dx[u] = inc_x[j0 + u]; dy[u] = inc_y[j0 + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { x += dx[u]; y += dy[u]; xs[u] = x; ys[u] = y; }
+                    if (gl == 0) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { pos_x[j0 + u + 1] = xs[u]; pos_y[j0 + u + 1] = ys[u]; }
+                    }
+                }
+                for (; j0 < S - 1; ++j0) {
+                    x += inc_x[j0]; y += inc_y[j0];
+                    if (gl == 0) { pos_x[j0 + 1] = x; pos_y[j0 + 1] = y; }
+                }
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
+            F1P_RPH();
             if (inc_pass) {
                 // the cell words of a lane's stations (gl, gl + GS, ...) are requested together: one global round trip per entry
                 constexpr int NSL = 4;                               // stations per lane handled in registers; a longer horizon loops
@@ -2066,12 +2142,35 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        F1P_RPH();
         const unsigned long long hm = __ballot(hit);
         const bool any_hit = ((hm >> gbase) & (GS == 64 ? ~0ull : (1ull << (GS & 63)) - 1ull)) != 0ull;
         if (run) {
             double sumk = 0.0, sim = 0.0;
-            for (int q = 0; q < S; ++q) sumk += akv[q];               // station order, like `sumk += ak` of the loop
-            if (prev) for (int q = 0; q < sim_m; ++q) sim += simv[q];  // ... and `sim += d * d`
+            // station order, like `sumk += ak` and `sim += d * d` of the loop; eight operands read ahead of their eight additions (one LDS
+            // round trip per station otherwise: 3.4 k cycles per entry)
+            {
+                int q = 0;
+                for (; q + 8 <= S; q += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = akv[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sumk += v[u];
+                }
+                for (; q < S; ++q) sumk += akv[q];
+            }
+            if (prev) {
+                int q = 0;
+                for (; q + 8 <= sim_m; q += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = simv[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sim += v[u];
+                }
+                for (; q < sim_m; ++q) sim += simv[q];
+            }
             const double maxk = __builtin_fmax(fabs(k0 + dk * (0.0 * ds)), fabs(k0 + dk * ((double)(S - 1) * ds)));
             cost = 0.0;                               // eval(): cost = 0.; cost += w_i * f_i
             cost += cfg.w_length * (1.0 / L);
@@ -2088,9 +2187,9 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
         }
 #ifdef F1P_MIX_PHASES
         F1P_RPH();
-        if (ib == 0 && live && gl == 0 && mx.dbg_state && (size_t)i * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width) {
-            for (int k = 0; k + 1 < nrp; ++k) mx.dbg_state[(size_t)i * 8 + k] = (int)(rph[k + 1] - rph[k]);
-            mx.dbg_state[(size_t)i * 8 + 7] = nrp;
+        if (ib == 0 && live && gl == 0 && mx.dbg_state && (size_t)i * 16 + 16 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width) {
+            for (int k = 0; k + 1 < nrp; ++k) mx.dbg_state[(size_t)i * 16 + k] = (int)(rph[k + 1] - rph[k]);
+            mx.dbg_state[(size_t)i * 16 + 15] = nrp;
         }
 #endif
     }
@@ -2099,6 +2198,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
 // wave per ego: select() over the refined candidates, winner re-emission, tracking (the tail of k_lattice_eval)
 __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = a.e0 + blockIdx.x * 4 + wave;
     if (blockIdx.x == 0 && tid < F1P_MIX_QSHARDS) mx.qcount[tid * 32u] = 0u;   // the refinement kernel is done with them: ready for the next plan

@@ -9,7 +9,7 @@ E, C, S = 4096, 256, 50
 rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
 poses = synth.make_egos(rl, E, seed=1)
 cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
-names = ["queue count + entry load", "fp64 fit", "xform + interval increments", "prefix sums + occupancy reads", "cost terms + reduce + store/publish + ticket", "selection: argmin / winner data", "selection: emit + track"]
+names = ["queue count + entry load", "fit: g1_begin (atan2, guess)", "fit: node sincos -> LDS", "fit: moment chains + gather", "fit: model steps (+ further passes) + finish", "interval setup + increments", "prefix sums (positions)", "position hand-over + occupancy words", "per-station cost terms -> LDS", "sequential sums, cost, store"]
 with Context(0) as ctx:
     ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
     d_poses = ctx.to_device(poses)
@@ -17,9 +17,9 @@ with Context(0) as ctx:
     d_c, d_s = ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
     ctx.lattice_set_mode(2, d_c, d_s)
     for _ in range(5): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
-    st = d_s.download(np.int32, (E * C // 8, 8))
-    ok = st[:, 7] >= 6
-    npz = int(st[ok][:, 7].max()) - 1
+    st = d_s.download(np.int32, (E * C // 16, 16))
+    ok = st[:, 15] == 11
+    npz = 10
     ph = st[ok][:, :npz].astype(np.float64)
     print("entries stamped:", int(ok.sum()))
     tot = ph.sum(1).mean()
