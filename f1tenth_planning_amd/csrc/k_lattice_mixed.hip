@@ -161,25 +161,26 @@ struct Fit32 { float k0, dk, L; bool ok; int why; float ek0, edk, eLrel; };
 // Clothoid.G1Hermite(0,0,0,x,y,theta) in f32: the structure of g1_fit (published guess, one quadrature pass, degree-5 Taylor
 // model) with 16 nodes and the hardware sin / cos (v_sin_f32 / v_cos_f32 take revolutions).  ok = false: do not trust it.
 __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
+    // Round 4: ONE straight line of arithmetic, the tests collected as flags.  A wave runs every step anyway as soon as one of its 64
+    // candidates passes a test, so the early returns saved nothing -- but each of them made the compiler materialise the default of every
+    // result on its path (~120 v_mov_b32 and ~25 exec-mask branches per candidate, a tenth of the candidate kernel's issue time).  A
+    // candidate that fails a test computes garbage behind it (NaN / inf are harmless: nothing traps) and reports ok = false.
     Fit32 f;
-    f.k0 = 0.f; f.dk = 0.f; f.L = 0.f; f.ok = false; f.why = 40; f.ek0 = 0.f; f.edk = 0.f; f.eLrel = 0.f;
     const float r = __builtin_sqrtf(x1 * x1 + y1 * y1);
-    if (!(r > 1e-6f) || !(r < 1e6f)) return f;
+    const bool c40 = (r > 1e-6f) & (r < 1e6f);
     const float phi = atan2f(y1, x1);
     const float PI_F = 3.14159265358979f;
     const float phi0 = -phi;                                                  // |phi| <= pi already
     float phi1 = th1 - phi;
     phi1 = phi1 - 2.0f * PI_F * __builtin_rintf(phi1 * F1P_INV_2PI_F);
     // near the +-pi seam of either angle the fp64 normalisation may land on the other side: a different curve altogether
-    f.why = 41;
-    if (!(fabsf(phi0) < PI_F - 2e-3f) || !(fabsf(phi1) < PI_F - 2e-3f)) return f;
+    const bool c41 = (fabsf(phi0) < PI_F - 2e-3f) & (fabsf(phi1) < PI_F - 2e-3f);
     const float delta = phi1 - phi0;
     const float X = phi0 * (1.0f / PI_F), Y = phi1 * (1.0f / PI_F);
     const float xy = X * Y, X2 = X * X, Y2 = Y * Y;
     const float A0 = (phi0 + phi1) * (2.989696028701907f + xy * (0.716228953608281f + xy * -0.458969738821509f) +
                                       (-0.502821153340377f + xy * 0.261062141752652f) * (X2 + Y2) + -0.045854475238709f * (X2 * X2 + Y2 * Y2));
-    f.why = 42;
-    if (!(fabsf(A0) + fabsf(delta - A0) <= F1P_MIX_EXC_MAX)) return f;       // beyond what 16 nodes integrate to f32 accuracy (also NaN)
+    const bool c42 = fabsf(A0) + fabsf(delta - A0) <= F1P_MIX_EXC_MAX;       // beyond what 16 nodes integrate to f32 accuracy (also NaN)
     const float ar = A0 * F1P_INV_2PI_F, br = (delta - A0) * F1P_INV_2PI_F, cr = phi0 * F1P_INV_2PI_F;   // phase in revolutions
     float mc[6], ms[6];
 #pragma unroll
@@ -187,8 +188,11 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     // The rule is symmetric about 1/2: nodes j and 15 - j share u = tau^2 - tau and the weight, i.e. the whole row w u^k -- so the
     // two nodes' cosines (sines) are added first and ONE row of six fma serves both: 8 x 12 fma instead of 16 x 12 (round 4).  Each
     // node's phase is still formed from the tabulated node itself, so the a-priori bound below holds with room (fewer roundings).
+#ifndef F1P_EXP_FIT_PAIRS
+#define F1P_EXP_FIT_PAIRS 8          // (timing experiments only: fewer pairs give WRONG moments)
+#endif
 #pragma unroll F1P_MIX_FIT_UNROLL
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < F1P_EXP_FIT_PAIRS; ++j) {
         const float tau = c_gl16_xf[j], tau2 = c_gl16_xf[15 - j];
         const float ph = __builtin_fmaf(__builtin_fmaf(ar, tau, br), tau, cr);
         const float ph2 = __builtin_fmaf(__builtin_fmaf(ar, tau2, br), tau2, cr);
@@ -200,8 +204,7 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
         }
     }
     const float g0 = ms[0], g1 = mc[1], g2 = -0.5f * ms[2], g3 = mc[3] * (-1.0f / 6.0f), g4 = ms[4] * (1.0f / 24.0f), g5 = mc[5] * (1.0f / 120.0f);
-    f.why = 43;
-    if (!(fabsf(g1) > 1e-4f)) return f;
+    const bool c43 = fabsf(g1) > 1e-4f;
     float d = -g0 * __builtin_amdgcn_rcpf(g1);                                  // 1-ulp reciprocals: the filter's error budget is the margin
     float dv_last = g1;
 #pragma unroll
@@ -211,15 +214,15 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
         d -= pv * __builtin_amdgcn_rcpf(dv);
         dv_last = dv;
     }
-    f.why = 44;
-    if (!(fabsf(d) <= 0.3f)) return f;                                         // the degree-5 model's remainder is < 1e-10 there: |g^(6)| / 6! <= 1.2e-7
+    const bool c44 = fabsf(d) <= 0.3f;                                         // the degree-5 model's remainder is < 1e-10 there: |g^(6)| / 6! <= 1.2e-7
     const float A = A0 + d;
     const float q5 = ms[5] * (-1.0f / 120.0f), q4 = mc[4] * (1.0f / 24.0f), q3 = ms[3] * (1.0f / 6.0f), q2 = -0.5f * mc[2], q1 = -ms[1];
     const float c0 = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, q5, q4), q3), q2), q1), mc[0]);
-    f.why = 45;
-    if (!(c0 > 0.05f)) return f;                                               // L = r / c0 ill-conditioned or negative: fp64 decides
+    const bool c45 = c0 > 0.05f;                                               // L = r / c0 ill-conditioned or negative: fp64 decides
     const float L = r * __builtin_amdgcn_rcpf(c0), iL = c0 * __builtin_amdgcn_rcpf(r);
-    f.L = L; f.k0 = (delta - A) * iL; f.dk = 2.0f * A * (iL * iL); f.ok = true;
+    f.L = L; f.k0 = (delta - A) * iL; f.dk = 2.0f * A * (iL * iL);
+    f.ok = c40 & c41 & c42 & c43 & c44 & c45;
+    f.why = !c40 ? 40 : (!c41 ? 41 : (!c42 ? 42 : (!c43 ? 43 : (!c44 ? 44 : 45))));   // the first test that failed (debug hook)
     // ---- a-priori error of THIS fit against the fp64 fit of the same goal (u = 2^-24 = 6e-8) ----------------------------
     //   node phase [rev]: coefficient and fma roundings <= 4 u P / 2 pi with P = |A0| + |delta - A0| + |phi0| [rad]; v_sin / v_cos: 2.1 u
     //   absolute (EXHAUSTIVE over |x| <= 8 rev, profiles/r03_hw_f32_primitive_errors.txt)  =>  each node value within (2.1 + 4 P) u;
@@ -486,6 +489,16 @@ __device__ __forceinline__ Filt32 station_loop_f32_clear(const Fit32& f, const F
     return o;
 }
 
+__device__ __forceinline__ int wave_scan_add_i32(int v) {          // inclusive sum over the 64 lanes (all active)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // intersect_point's scan (utils/utils.py:84-149, wave_intersect) with whole 64-segment chunks skipped when the circle cannot reach them:
 // `box` is nearest_scan_boxed's table (bounding box of the waypoints of rows 64c .. 64c + 64).  A segment can only be hit if the
 // point is within `radius` of it; a chunk whose box is farther than radius + 1e-4 m (orders above the rounding of the reference's
@@ -567,9 +580,11 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
                                                        const double* __restrict__ wy, const double* __restrict__ wpsi, int n, double tstart,
                                                        int wave, int nwaves, double* cen_x, double* cen_y, double* cen_psi, int* cen_ok,
                                                        int* lds_first, int* lds_pairs, double near_d = 0.0, int* stat = nullptr,
-                                                       const double* __restrict__ wbox = nullptr, int first_cap = 16) {
+                                                       const double* __restrict__ wbox = nullptr, int first_cap = 16, long long* tst = nullptr) {
+#define F1P_LAT(k) do { if (tst) { __builtin_amdgcn_s_waitcnt(0); tst[k] = clock64(); } } while (0)
     const int lane = threadIdx.x & 63;
     const int nl = cfg.n_lookahead;
+    F1P_LAT(0);
     const int start_i = (int)tstart;
     const double start_t = tstart - __builtin_trunc(tstart);
     // Round 3: the 64 segments are the first 64 of the reference's SCAN ORDER -- start_i .. n-2, then the wrap loop's -1, 0, 1, ...
@@ -597,6 +612,7 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         seg_sx = sx; seg_sy = sy; seg_ex = ex; seg_ey = ey;
         const float ax = (float)(sx - px), ay = (float)(sy - py), bx = (float)(ex - px), by = (float)(ey - py);
         const float vx = (float)(ex - sx), vy = (float)(ey - sy);
+        F1P_LAT(1);                                                 // the segment rows arrived
         const float dS = __builtin_sqrtf(ax * ax + ay * ay), dE = __builtin_sqrtf(bx * bx + by * by);
         const float len2 = vx * vx + vy * vy;
         const float u = -(ax * vx + ay * vy);                       // projection parameter times len2
@@ -605,19 +621,29 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         const float hi = fmaxf(dS, dE);
         const float slack = 1e-4f + 4e-6f * hi;                     // + the f32 rounding of the bracket itself
         if (lane < first_cap) lds_first[lane] = 0x7fffffff;
+        // Round 4: every lane first collects the radii its segment may meet as a bit mask (the radius of slot s comes by v_readlane: s is
+        // wave-uniform), then the pairs are numbered by ONE scan of the per-lane counts and written.  The loop used to take a ds_bpermute,
+        // a ballot and a divergent LDS write per radius: 390 cycles each, 6.2 k of the prologue's 21 k (tools/prologue_phases.py).  The pairs
+        // come out lane-major instead of radius-major; the exact tests below take them in any order (atomicMin per radius).
+        unsigned long long mine = 0ull;
+        const float lo_s = lo - slack, hi_s = hi + slack;
+        const bool nan_seg = !(dS == dS) | !(dE == dE);           // NaN anywhere: flagged (fminf / fmaxf drop a NaN operand)
         int slot = 0;
         for (int l = wave; l < nl; l += nwaves, ++slot) {
-            const float r = __shfl(my_r32, slot, 64);
-            const bool flag = (!(r < lo - slack) & !(r > hi + slack)) | !(dS == dS) | !(dE == dE);   // NaN anywhere: flagged (fminf / fmaxf drop a NaN operand)
-            const unsigned long long m = __ballot(flag);
-            if (flag) {
-                const int idx = total + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (idx < 64) lds_pairs[idx] = (lane << 8) | slot;
-            }
-            total += __builtin_popcountll(m);
+            const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r32), slot));
+            const bool flag = (!(r < lo_s) & !(r > hi_s)) | nan_seg;
+            mine |= flag ? (1ull << slot) : 0ull;
         }
+        const int my_n = __builtin_popcountll(mine);
+        const int incl = wave_scan_add_i32(my_n);
+        total = __builtin_amdgcn_readlane(incl, 63);
         if (total > 64) fast = false;
+        else {
+            int idx = incl - my_n;
+            for (unsigned long long m = mine; m; m &= m - 1) lds_pairs[idx++] = (lane << 8) | (__ffsll((long long)m) - 1);
+        }
     }
+    F1P_LAT(2);                                                     // brackets + pair compaction
     if (fast) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -625,13 +651,15 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         const int off = code >> 8, slot = code & 0xff;
         // the pair's segment is virtual segment `off`, whose rows lane `off` loaded for the bracket: the same fp64 values by shuffle
         const double hx0 = shfl_d(seg_sx, off), hy0 = shfl_d(seg_sy, off), hx1 = shfl_d(seg_ex, off), hy1 = shfl_d(seg_ey, off);
+        const double pair_r = shfl_d(my_r, slot);                   // the radius lane `slot` holds: cfg.lookahead[wave + slot nwaves], the same fp64 value
         if (lane < total) {
-            const SegHit h = seg_hit(px, py, cfg.lookahead[wave + slot * nwaves], hx0, hy0, hx1, hy1, off == 0, start_t);
+            const SegHit h = seg_hit(px, py, pair_r, hx0, hy0, hx1, hy1, off == 0, start_t);
             if (h.hit) atomicMin(&lds_first[slot], off);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+    F1P_LAT(3);                                                     // exact tests
     // lane s finishes this wave's s-th radius: one round trip for all the centres instead of one per radius
     const int my_first = (fast && lane < nslots) ? lds_first[lane] : 0x7fffffff;
     bool my_found = my_first != 0x7fffffff;
@@ -673,6 +701,8 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         }
         if (my_found) { cen_x[l] = c_x; cen_y[l] = c_y; cen_psi[l] = c_psi; }
     }
+    F1P_LAT(4);
+#undef F1P_LAT
 }
 
 // CR = MixArgs::clear_r (0: every station against the bitmap; 1, 2: clearance mode): one instantiation per station loop, so each keeps the 64-VGPR budget
@@ -1398,8 +1428,10 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     F1P_PPH();
 #ifdef F1P_PRO_PHASES
     int lstat[4] = {0, 0, 0, 0};
-    wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, lstat, a.wbox, F1P_MAX_LOOKAHEADS);
+    long long lat[5] = {0, 0, 0, 0, 0};
+    wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, lstat, a.wbox, F1P_MAX_LOOKAHEADS, lat);
     if (lane == 0 && mx.dbg_cost32) for (int k = 0; k < 4; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 40 + k] = (float)lstat[k];
+    if (lane == 0 && mx.dbg_cost32) for (int k = 0; k < 4; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 48 + k] = (float)(lat[k + 1] - lat[k]);
 #else
     wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, nullptr, a.wbox, F1P_MAX_LOOKAHEADS);
 #endif
@@ -1546,25 +1578,25 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     // ---- phase 1, every candidate in f32: goal -> G1 fit -> cost and bracket [lo, hi]; nothing looks at positions -------------------
     float kf_k0 = 0.f, kf_dk = 0.f, kf_L = 0.f, kf_edge = 0.f;    // the one-pass thread's fit for the station pass
     auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& edge, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
+        // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
         const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
         const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
-        int st = F1P_ST_BAD;
-        lo = INF; hi = INF; k0 = 0.f; dk = 0.f; L = 0.f; edge = 0.f; gx = 0.f; gy = 0.f; dbg_code = -1;
-        o.cost = INF; o.ebound = 0.f; o.never_free = true;
-        if (gf->ok) {
-            const double w = ((const F1P_LDS(double)*)wtab)[k];
-            gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
-            const float r2 = gx * gx + gy * gy;
-            st = F1P_ST_UNSURE; lo = -INF;                                     // until a trusted bracket says otherwise: the fp64 tests decide
-            if (r2 > 1e-8f && r2 < 1e20f) {                                    // (tiny, huge or NaN in f32: g1_fit rejects r <= 1e-12 itself)
-                const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
-                if (f.ok) {
-                    o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
-                    st = o.state | (o.never_free ? 0x80 : 0);
-                    lo = o.lo; hi = o.hi; k0 = f.k0; dk = f.dk; L = f.L; edge = o.edge;
-                } else dbg_code = f.why;
-            }
-        }
+        const bool gok = gf->ok != 0;
+        const double w = ((const F1P_LDS(double)*)wtab)[k];
+        gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+        const float r2 = gx * gx + gy * gy;
+        const bool r_ok = (r2 > 1e-8f) & (r2 < 1e20f);                          // (tiny, huge or NaN in f32: the fp64 tests decide; g1_fit rejects r <= 1e-12 itself)
+        const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
+        o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
+        const bool trusted = r_ok & f.ok;
+        k0 = f.k0; dk = f.dk; L = f.L; edge = o.edge;
+        // no goal: BAD (infeasible in fp64 too);  no trusted bracket: UNSURE with lo = -inf (the fp64 tests decide);  else what bracket_f2 says
+        int st = trusted ? (o.state | (o.never_free ? 0x80 : 0)) : F1P_ST_UNSURE;
+        st = gok ? st : F1P_ST_BAD;
+        lo = gok ? (trusted ? o.lo : -INF) : INF;
+        hi = (gok & trusted) ? o.hi : INF;
+        dbg_code = (gok & r_ok & !f.ok) ? f.why : -1;
+        if (mx.dbg_cost32 || mx.dbg_bound) { if (!(gok & trusted)) { o.cost = INF; o.ebound = 0.f; } }   // (test hooks: what the nested version reported)
         return st;
     };
     float my_hi_p = INF;                                          // min hi over this thread's PENDING candidates

@@ -25,6 +25,8 @@ with Context(0) as ctx:
     st = d_c.download(np.float32, (E, C))[:, 40:44]
     print(f"look-ahead: general scans per ego mean {st[:, 0].mean():.3f} max {st[:, 0].max():.0f} (egos with any: {(st[:, 0] > 0).mean() * 100:.1f} %), fast path {st[:, 1].mean() * 100:.1f} %, "
           f"pairs mean {st[:, 2].mean():.1f} max {st[:, 2].max():.0f}, surely-none radii mean {st[:, 3].mean():.2f}")
+    la = d_c.download(np.float32, (E, C))[:, 48:52]
+    for k, nm in enumerate(["look-ahead: rows arrive", "look-ahead: brackets + pair compaction", "look-ahead: exact tests", "look-ahead: centres"]): print(f"   {nm:40s} {la[:, k].mean():8.0f} (max {la[:, k].max():.0f})")
     slow = ph[:, 3] > 2 * np.median(ph[:, 3])
     print(f"slow look-ahead waves: {slow.mean() * 100:.1f} %; of those: general scans mean {st[slow, 0].mean():.2f}, fast {st[slow, 1].mean() * 100:.0f} %")
     print(f"wave lifetime {tot:.0f} ticks mean, {ph.sum(1).max():.0f} max; start-time spread {np.ptp(t0):.0f} ticks (mod 2^24)")
