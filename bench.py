@@ -562,28 +562,25 @@ def leg_kmpc_c4(rk, args, steps):
 
 
 def filter_shape(S, r):
-    """What k_lattice_filter3 does per candidate in the clearance mode r (station_loop_f2, csrc/k_lattice.hip -- this mirrors its loop
-    structure): G = 2 r + 1; r single intervals up to the first tested station, then ONE integrated piece of G intervals between
-    consecutive tested stations, single intervals through the tail; one look-up per tested station.  r = 0: every interval a piece of
-    its own, every station looked up."""
+    """What k_lattice_filter3 does (csrc/k_lattice_mixed.hip): EVERY candidate gets the f32 fit and the four cost terms with their bracket
+    (bracket_f2: nothing there looks at positions); the station pass -- positions and occupancy look-ups -- runs only for the candidates whose
+    bracket reaches below the best collision-free one (station_pass_wave; pass_plan is mirrored here): in the clearance mode r the tested
+    stations are r, r + G, r + 2 G, ... (G = 2 r + 1) and the last station when the tested ones do not cover it, each reached by ONE
+    integrated piece.  r = 0 (every_station, k_lattice_filter): every interval a piece of its own, every station looked up, every candidate."""
     if r <= 0:
-        return {"pieces_integrated_per_candidate": S - 1, "stations_looked_up_per_candidate": S, "clearance_r": 0}
+        return {"pieces_integrated_per_candidate": S - 1, "stations_looked_up_per_candidate": S, "clearance_r": 0,
+                "station_pass": "every candidate"}
     G = 2 * r + 1
-    pieces = tests = 0
-    pos = 0
-    if G < S:                                   # r single intervals to the first tested station, then one piece per tested station
-        pieces += r; pos = r; tests += 1
-        base = G
-        while base + r <= S - 1:
-            pieces += 1; pos += G; tests += 1
-            base += G
-        tail_test = S - 1 > pos + r             # what lies beyond pos + r is proved by the last station
+    if G < S:
+        nm = (S - 1 - r) // G
+        pos = r + nm * G
+        tests = 1 + nm + (1 if S - 1 > pos + r else 0)
     else:
-        tail_test = True
-    pieces += (S - 1) - pos                     # single intervals through the tail
-    tests += 1 if tail_test else 0
-    return {"pieces_integrated_per_candidate": pieces, "stations_looked_up_per_candidate": tests, "clearance_r": r,
-            "intervals_per_candidate": S - 1, "stations_per_candidate": S}
+        tests = 1
+    return {"pieces_integrated_per_candidate": tests, "stations_looked_up_per_candidate": tests, "clearance_r": r,
+            "intervals_per_candidate": S - 1, "stations_per_candidate": S,
+            "station_pass": "lazy: only the candidates whose cost bracket reaches below the best collision-free candidate's (see "
+                            "station_pass_candidates_per_ego); the fit and the cost bracket are computed for every candidate"}
 
 
 def algorithmic_ops(poses, rl, cfg, grid, prev_in, n_egos=3, stride=8):
@@ -786,6 +783,13 @@ def main_lattice(args):
         ctx.lattice_profile(False)
         acc /= max(10, min(args.steps, 50))
         mixed_ms = {"k_lattice_prologue": float(acc[0]), "k_lattice_filter3": float(acc[1]), "k_lattice_refine": float(acc[2]), "k_lattice_select": float(acc[3])}
+        # entries per ego the filter of that last plan handed to the fp64 refinement = the candidates whose collision state mattered (minus
+        # certain hits, which are dropped): what the lazy station pass looked at
+        try:
+            nq = ctx.lattice_debug_queue(E)
+            pass_stat = {"mean": float(nq.mean()), "p99": float(np.percentile(nq, 99)), "max": int(nq.max()), "of": C}
+        except Exception as exc:   # noqa: BLE001 -- a statistic, not a gate
+            pass_stat = {"error": str(exc)}
 
     # runtime audit of the mixed schedule (f1p_lattice_set_audit): the timed plan again, every plan followed by the all-fp64 exhaustive
     # kernel on a moving window of 256 egos and a bit-for-bit comparison of every output; outside the timed region
@@ -872,6 +876,8 @@ def main_lattice(args):
         pcie_value = (float(E) * C * S / (lat["p50_ms"] * 1e-3)) if lat else None
         default_sched = not (args.all_fp64 or args.prune or materialised or args.generator != "clothoid")
         shape = filter_shape(S, 2) if default_sched else None
+        if shape is not None and mixed_ms:
+            shape["station_pass_candidates_per_ego"] = pass_stat
         # SURVEY 8d's op count, from the instrumented restatement (rank 0, a few seconds of pure Python)
         algo = None
         if default_sched and not cand_sharded and not args.no_cpu_baseline:
@@ -883,8 +889,8 @@ def main_lattice(args):
                 algo["achieved_over_peak"] = ops_s / 1e12 / (2.0 * VALU_PEAK_F32_GUIDE)
                 algo["note"] = ("algorithmic ops of the CPU restatement per candidate x candidates / the candidate kernel's duration, against 157.3 T flop/s "
                                 "(guide: f32 FMA = 2 flop per lane-instruction).  NOT an efficiency: k_lattice_filter3 reaches the same decisions with "
-                                "far fewer operations (f32 fit on ONE 16-node pass, closed-form cost terms, one integrated piece per five intervals, one "
-                                "look-up per five stations: see filter_shape and valu.valu_instr_per_candidate), so this ratio measures how much work "
+                                "far fewer operations (f32 fit on ONE 16-node pass, closed-form cost terms, positions and look-ups only for the ~1.5 candidates "
+                                "per ego whose collision state can matter: see filter_shape and valu.valu_instr_per_candidate), so this ratio measures how much work "
                                 "the algorithm removed as much as how fast the rest runs -- the issue-slot figure is roofline.frac")
         hbm = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                "algorithmic_bytes_per_launch": abytes, "bytes_per_candidate_step": abytes / (E * C * S),
@@ -938,9 +944,10 @@ def main_lattice(args):
             "plan_latency_host_boundary": lat,
             "schedule": ("all fp64" + (" + branch and bound" if args.prune else "")) if not default_sched else
                         ("k_lattice_prologue (fp64, wave per ego: nearest segment, look-ahead centres, goal frames, moments of the previous path) -> "
-                         "k_lattice_filter3 (f32, thread per candidate: G1 fit on one 16-node pass, integrated pieces + clearance look-ups per filter_shape, "
-                         "closed-form curvature and similarity terms, cost bracket + collision state) -> k_lattice_refine (fp64, the reference's arithmetic "
-                         "on the ~2 candidates per ego the brackets cannot rank) -> k_lattice_select (fp64 argmin, winner's rows, tracker); "
+                         "k_lattice_filter3 (f32, thread per candidate: G1 fit on one 16-node pass, closed-form curvature and similarity terms, cost "
+                         "bracket; then the station pass -- integrated pieces + clearance look-ups per filter_shape, a wave per selected candidate -- "
+                         "for the few candidates whose bracket reaches below the best collision-free one) -> k_lattice_refine (fp64, the reference's "
+                         "arithmetic on the ~1.5 candidates per ego the brackets cannot rank) -> k_lattice_select (fp64 argmin, winner's rows, tracker); "
                          "outputs bit-identical to the all-fp64 kernel"),
             "filter_shape": shape,
             "algorithmic_ops_per_candidate": algo,

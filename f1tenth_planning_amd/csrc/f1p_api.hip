@@ -149,6 +149,16 @@ struct Stage {
 // hipHostRegister), else null.  A kernel that stores through it writes straight into the caller's array; a range that is only partly
 // registered would fault, so both ends must be known to HIP as host memory with ONE linear device mapping between them (the
 // first byte alone had been checked, and the host address used instead of attr.devicePointer).
+static void* pinned_device_ptr(const void* p, size_t bytes);
+// ... with the context's own page-locked blocks answered from its table (no runtime call)
+static void* pinned_device_ptr(const f1p_ctx* ctx, const void* p, size_t bytes) {
+    if (!p || bytes == 0) return nullptr;
+    const char* c = (const char*)p;
+    if (ctx->h_step && ctx->h_step_dev && c >= ctx->h_step && c + bytes <= ctx->h_step + ctx->step_host_bytes) return ctx->h_step_dev + (c - ctx->h_step);
+    for (const auto& b : ctx->host_blocks)
+        if (c >= b.base && c + bytes <= b.base + b.bytes) return b.dev + (c - b.base);
+    return pinned_device_ptr(p, bytes);
+}
 static void* pinned_device_ptr(const void* p, size_t bytes) {
     if (!p || bytes == 0) return nullptr;
     hipPointerAttribute_t a, b;
@@ -346,11 +356,19 @@ int f1p_host_alloc(f1p_ctx* ctx, void** hptr, size_t bytes) {
     if (!hptr) return set_error(ctx, F1P_EINVAL, "hptr is NULL");
     *hptr = nullptr;
     F1P_HIP(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, *hptr, 0) == hipSuccess && dev) ctx->host_blocks.push_back({(char*)*hptr, bytes ? bytes : 1, (char*)dev});
+    else (void)hipGetLastError();                                // (not in the table: the per-call checks decide)
     return F1P_OK;
 }
 int f1p_host_free(f1p_ctx* ctx, void* hptr) {
     F1P_ENTER(ctx);
-    if (hptr) F1P_HIP(ctx, hipHostFree(hptr));
+    if (hptr) {
+        for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
+            if (ctx->host_blocks[i].base == (char*)hptr) { ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i); break; }
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));             // a kernel may still be writing into it (zero-copy outputs)
+        F1P_HIP(ctx, hipHostFree(hptr));
+    }
     return F1P_OK;
 }
 int f1p_h2d(f1p_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
@@ -786,7 +804,7 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
     const size_t C = (size_t)cfg->n_lookahead * cfg->n_width, S = cfg->n_stations, e = E;
     // (page-locked best_traj: see below -- decided here so that the arena does not reserve bytes nobody uses)
     TRAJ* bt_dev = (best_traj && !all_cost && !all_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS)
-                       ? (TRAJ*)pinned_device_ptr(best_traj, sizeof(TRAJ) * e * S * 4) : nullptr;
+                       ? (TRAJ*)pinned_device_ptr(ctx, best_traj, sizeof(TRAJ) * e * S * 4) : nullptr;
     const bool pinned = bt_dev != nullptr;
     const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
     Stage s(ctx);
@@ -868,9 +886,12 @@ static int ensure_step(f1p_ctx* ctx, int E, int S, bool keep_traj) {
     if (hb > ctx->step_host_bytes) {
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->h_step) (void)hipHostFree(ctx->h_step);
-        ctx->h_step = nullptr; ctx->step_host_bytes = 0;
+        ctx->h_step = nullptr; ctx->step_host_bytes = 0; ctx->h_step_dev = nullptr;
         F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_step, hb, hipHostMallocDefault));
         ctx->step_host_bytes = hb;
+        void* dev = nullptr;
+        ctx->h_step_dev = (hipHostGetDevicePointer(&dev, ctx->h_step, 0) == hipSuccess) ? (char*)dev : nullptr;
+        if (!ctx->h_step_dev) (void)hipGetLastError();
     }
     const size_t db = al256(32 * (size_t)E) + 2 * al256(4 * (size_t)E) + (keep_traj ? al256(32 * (size_t)E * S) : 0);
     if (db > ctx->step_dev_bytes) {
@@ -900,14 +921,14 @@ int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f
     double* d_pose_copy = (double*)db; int32_t* d_idx = (int32_t*)(db + al256(32 * e)); int32_t* d_near = (int32_t*)((char*)d_idx + al256(4 * e));
     double* d_traj = keep_traj ? (double*)((char*)d_near + al256(4 * e)) : nullptr;
     // the caller's arrays when page-locked, the context's block otherwise
-    const double* k_poses = (const double*)pinned_device_ptr(poses, 32 * e);
-    if (!k_poses) { memcpy(h_poses, poses, 32 * e); k_poses = (const double*)pinned_device_ptr(h_poses, 32 * e); }
-    double* k_steer = (double*)pinned_device_ptr(steer, 8 * e); double* k_speed = (double*)pinned_device_ptr(speed, 8 * e);
-    int32_t* k_status = status ? (int32_t*)pinned_device_ptr(status, 4 * e) : nullptr;
+    const double* k_poses = (const double*)pinned_device_ptr(ctx, poses, 32 * e);
+    if (!k_poses) { memcpy(h_poses, poses, 32 * e); k_poses = (const double*)pinned_device_ptr(ctx, h_poses, 32 * e); }
+    double* k_steer = (double*)pinned_device_ptr(ctx, steer, 8 * e); double* k_speed = (double*)pinned_device_ptr(ctx, speed, 8 * e);
+    int32_t* k_status = status ? (int32_t*)pinned_device_ptr(ctx, status, 4 * e) : nullptr;
     const bool own_steer = !k_steer, own_speed = !k_speed, own_status = status && !k_status;
-    if (own_steer) k_steer = (double*)pinned_device_ptr(h_steer, 8 * e);
-    if (own_speed) k_speed = (double*)pinned_device_ptr(h_speed, 8 * e);
-    if (own_status) k_status = (int32_t*)pinned_device_ptr(h_status, 4 * e);
+    if (own_steer) k_steer = (double*)pinned_device_ptr(ctx, h_steer, 8 * e);
+    if (own_speed) k_speed = (double*)pinned_device_ptr(ctx, h_speed, 8 * e);
+    if (own_status) k_status = (int32_t*)pinned_device_ptr(ctx, h_status, 4 * e);
     if (!k_poses || !k_steer || !k_speed || (status && !k_status)) return set_error(ctx, F1P_ESTATE, "page-locked step block is not device-visible");
     if (!ctx->lattice_closed_loop) { ctx->lattice_closed_loop = true; ctx->cl_valid = false; }   // a step IS a link of a closed loop
     ClosedLoop cl;

@@ -1,5 +1,6 @@
 // f1p_internal.h -- host-side context and launch declarations shared by the translation units of libf1p.so
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -110,7 +111,12 @@ struct f1p_ctx {
     // f1p_lattice_step_batch: page-locked block (poses | steer | speed | status) the kernels read / write directly, and the device side
     // (pose copy | best_idx | near_idx | kept trajectories)
     char* h_step = nullptr; size_t step_host_bytes = 0;
+    char* h_step_dev = nullptr;             // its device-side address (hipHostGetDevicePointer, once)
     char* d_step = nullptr; size_t step_dev_bytes = 0;
+    // page-locked blocks this context handed out itself (f1p_host_alloc): a pointer inside one of them is device-visible by construction,
+    // so the per-call checks of a caller's array (three runtime calls per array, ~2 us each) are not needed for it
+    struct HostBlock { char* base; size_t bytes; char* dev; };
+    std::vector<HostBlock> host_blocks;
     int step_traj_E = 0, step_traj_S = 0;   // shape of the trajectories kept by the last step (0 = none)
 
     // candidate slices of one ego over several workgroups (few egos, many candidates): partial winners + tickets
