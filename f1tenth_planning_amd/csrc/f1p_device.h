@@ -54,6 +54,32 @@ __device__ __forceinline__ void wave_argmin(double& d, int& i) {
     }
 }
 
+// The same result over the 64 lanes of a FULLY ACTIVE wave by DPP row shifts / row broadcasts and one v_readlane instead of six
+// ds_bpermute round trips per operand (~1.2 k cycles of a one-wave-per-SIMD kernel's chain against ~0.3 k).  argmin_better is a total
+// order on (value, index), so the shape of the reduction tree does not matter.
+__device__ __forceinline__ void wave_argmin_dpp(double& d, int& i) {
+#define F1P_ARGMIN_DPP_STEP(CTRL, ROWS)                                                                                         \
+    {                                                                                                                           \
+        const long long b = __double_as_longlong(d);                                                                            \
+        const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);                                                            \
+        const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false), ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false); \
+        const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROWS, 0xf, false);                                               \
+        const double od = __longlong_as_double(((long long)ohi << 32) | (long long)(unsigned int)olo);                          \
+        if (argmin_better(od, oi, d, i)) { d = od; i = oi; }                                                                    \
+    }
+    F1P_ARGMIN_DPP_STEP(0x111, 0xf)    // row_shr:1  (a lane without a source keeps its own pair: not better than itself)
+    F1P_ARGMIN_DPP_STEP(0x112, 0xf)    // row_shr:2
+    F1P_ARGMIN_DPP_STEP(0x114, 0xf)    // row_shr:4
+    F1P_ARGMIN_DPP_STEP(0x118, 0xf)    // row_shr:8: lane 15 of every row holds its row's winner
+    F1P_ARGMIN_DPP_STEP(0x142, 0xa)    // row_bcast:15 into rows 1, 3
+    F1P_ARGMIN_DPP_STEP(0x143, 0xc)    // row_bcast:31 into rows 2, 3: lane 63 holds the wave's winner
+#undef F1P_ARGMIN_DPP_STEP
+    const long long b = __double_as_longlong(d);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    d = __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+
 // block-wide argmin; `sd`/`si` are LDS scratch of >= blockDim.x/64 entries.  All threads get the result.
 __device__ __forceinline__ void block_argmin(double& d, int& i, double* sd, int* si) {
     wave_argmin(d, i);
