@@ -170,6 +170,20 @@ def test_lazy_station_pass_agrees_with_the_eager_one(ctx, scene):
         d_c.free(); d_s.free()
 
 
+def test_long_horizons_take_the_general_paths(ctx, scene):
+    """station counts beyond the fast paths: more than four intervals per refinement lane (the running sums fall back to the LDS blocks),
+    more than 64 test points per station pass (lane per candidate from the tile), and the one-entry-per-wave refinement whose LDS blocks
+    no longer fit four to a wave (S = 600: the systolic sums shift across the whole wave); an ego in the wall tests every station"""
+    rl, img, origin = scene
+    for S, n_cand, E in ((70, 64, 330), (200, 64, 330), (600, 32, 330)):
+        cfg = synth.bench_lattice_cfg(n_cand=n_cand, n_stations=S)
+        poses = synth.make_egos(rl, E, seed=S, pos_sigma=0.5)
+        poses[2, :2] += [1.4, 1.4]
+        a = _both(ctx, poses, cfg)
+        assert (a["status"] == 0).mean() > 0.3
+        _both(ctx, poses, cfg, prev_theta=a["best_traj"][:, :, 2] + 0.01)
+
+
 def test_clearance_mode_is_exact_and_follows_the_bitmap(ctx, scene):
     """f1p_lattice_set_clearance: one station in 2 r + 1 looked up in the clearance map (r = 1 default, 2) against every station on
     the bitmap (r = 0) and the all-fp64 kernel: bit-identical outputs on centred, off-centre and wall-hugging egos; the filter's
