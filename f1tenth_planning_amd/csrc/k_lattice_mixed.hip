@@ -1269,14 +1269,19 @@ __device__ __forceinline__ float wave_scan_add(float v) {          // inclusive 
     return v;
 }
 
-__device__ __forceinline__ float wave_min_f32(float v) {          // minimum over the 64 lanes (all active), in every lane; NaN operands are dropped (fminf)
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x112, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x114, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x118, 0xf, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false)));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// Minimum of non-NaN floats over the 64 lanes (all active) on order-preserving integer keys: fminf compiles to a canonicalising v_max
+// in front of every v_min (four instructions per DPP step); v_min_i32 folds the DPP operand and needs none.  key(x) is monotone in x
+// over all finite values and +-inf (-0.0 < +0.0 as keys: a minimum of brackets does not care).
+__device__ __forceinline__ int f32_order_key(float x) { const int b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float f32_from_order_key(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ int wave_min_key(int v) {                // result in every lane (a wave-uniform value)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 template <int R>
@@ -1532,7 +1537,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     double* wtab = reinterpret_cast<double*>(rec + rec_bytes);   // [64] lateral offsets (LDS copy: indexed per lane)
     float* red_f = reinterpret_cast<float*>(wtab + F1P_MAX_WIDTHS);   // [3 reductions][2 values][4 waves]
     int* cnt = reinterpret_cast<int*>(red_f + 24);               // [4]: refine count, queue base
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = nl * cfg.n_width;
     const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
     const int nc = c1 - c0;
@@ -1638,13 +1643,25 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         }
     }
     // workgroup minimum of two values (slot = which of the three reductions: no barrier between them)
-    auto wg_min2 = [&](int slot, float& v0, float& v1) {
-        v0 = wave_min_f32(v0); v1 = wave_min_f32(v1);
-        float* r = red_f + slot * 8;
-        if (lane == 0) { r[wave] = v0; r[4 + wave] = v1; }
+    // (none of the reduced values is ever NaN: a bracket without a finite cost is (-inf, +inf).  Four waves: F1P_MIX_FILTER_BLOCK = 256)
+    static_assert(F1P_MIX_FILTER_BLOCK == 256, "the workgroup reductions read four wave slots");
+    int* red_i = reinterpret_cast<int*>(red_f);
+    auto wg_min1 = [&](int slot, float& v0) {
+        const int k0 = wave_min_key(f32_order_key(v0));
+        int* r = red_i + slot * 8;
+        if (lane == 0) r[wave] = k0;
         __syncthreads();
-        v0 = r[0]; v1 = r[4];
-        for (int w = 1; w < nwaves; ++w) { v0 = fminf(v0, r[w]); v1 = fminf(v1, r[4 + w]); }
+        const int4 q = *reinterpret_cast<const int4*>(r);
+        v0 = f32_from_order_key(min(min(q.x, q.y), min(q.z, q.w)));
+    };
+    auto wg_min2 = [&](int slot, float& v0, float& v1) {
+        const int k0 = wave_min_key(f32_order_key(v0)), k1 = wave_min_key(f32_order_key(v1));
+        int* r = red_i + slot * 8;
+        if (lane == 0) { r[wave] = k0; r[4 + wave] = k1; }
+        __syncthreads();
+        const int4 q0 = *reinterpret_cast<const int4*>(r), q1 = *reinterpret_cast<const int4*>(r + 4);
+        v0 = f32_from_order_key(min(min(q0.x, q0.y), min(q0.z, q0.w)));
+        v1 = f32_from_order_key(min(min(q1.x, q1.y), min(q1.z, q1.w)));
     };
 
     // ---- phase 2, the station pass in rounds.  Needed: T = min hi over the FREE candidates, and the state of every candidate with
@@ -1654,9 +1671,9 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     const bool exact_all_wg = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
     const PassPlan plan = pass_plan<CR>(__builtin_amdgcn_readfirstlane(ep->S), exact_all_wg);
     float t_free = INF;                                           // min hi over this thread's FREE candidates
-    float thr = my_hi_p, unused = INF;
+    float thr = my_hi_p;
     F1P_FPH();
-    wg_min2(0, thr, unused);
+    wg_min1(0, thr);
     F1P_FPH();
     for (int round = 0; round < 2; ++round) {
         float my_lo_p = INF;                                      // min lo over this thread's candidates still PENDING after the round
