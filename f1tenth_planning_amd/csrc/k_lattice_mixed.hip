@@ -1521,7 +1521,10 @@ __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, i
     return true;
 }
 
-template <int CR>
+// DBG: the instantiation with the test hooks (MixArgs::dbg_*; the phase-stamp builds).  The production instantiation has none of their
+// code and none of their pointers to keep in scalar registers (the kernel spills SGPRs into VGPR lanes: every one less is two 4-cycle
+// instructions less per use).
+template <int CR, bool DBG = false>
 __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
@@ -1576,7 +1579,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     // workgroup -- and wave w of every resident workgroup shares SIMD w, so one SIMD per CU ran every pass while three idled (measured:
     // filter 53 us against 41 before the lazy pass).
     const int ptid = blockDim.x == 256 ? (tid + (int)((((unsigned)e * 0x9E3779B1u) >> 30) << 6)) & 255 : tid;
-    const bool all_states = mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
+    const bool all_states = DBG && mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
     const float inv_nw = 1.0f / (float)cfg.n_width;
     const float INF = __builtin_huge_valf();
 
@@ -1601,7 +1604,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         lo = gok ? (trusted ? o.lo : -INF) : INF;
         hi = (gok & trusted) ? o.hi : INF;
         dbg_code = (gok & r_ok & !f.ok) ? f.why : -1;
-        if (mx.dbg_cost32 || mx.dbg_bound) { if (!(gok & trusted)) { o.cost = INF; o.ebound = 0.f; } }   // (test hooks: what the nested version reported)
+        if (DBG && (mx.dbg_cost32 || mx.dbg_bound)) { if (!(gok & trusted)) { o.cost = INF; o.ebound = 0.f; } }   // (test hooks: what the nested version reported)
         return st;
     };
     float my_hi_p = INF;                                          // min hi over this thread's PENDING candidates
@@ -1614,13 +1617,13 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         c_st[c - c0] = (unsigned char)st;
         if ((st & 0x7f) == F1P_ST_PENDING) my_hi_p = fminf(my_hi_p, hi);
 #if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES)
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
-        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+        if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
+        if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
 #elif defined(F1P_MIX_DEBUG_END)
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = 0.0f;
-        if (mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
+        if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = 0.0f;
+        if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
 #endif
-        if (mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
+        if (DBG && mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
     }
     // ---- the tiles for the station pass: requested now, behind the candidates' arithmetic; the first reduction's barrier publishes them
     {
@@ -1714,9 +1717,9 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                 if (sel) {
                     c_st[c - c0] = (unsigned char)ns;
                     if (ns == F1P_ST_FREE) t_free = fminf(t_free, c_hi[c - c0]);
-                    if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = ns;
+                    if (DBG && mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = ns;
 #ifdef F1P_MIX_DEBUG_END
-                    if (mx.dbg_cost32) {
+                    if (DBG && mx.dbg_cost32) {
                         const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;
                         const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
                         const double w = ((const F1P_LDS(double)*)wtab)[k];
@@ -1798,7 +1801,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     }
 #ifdef F1P_F3_PHASES
     F1P_FPH();
-    if (mx.dbg_cost32 && !mx.dbg_state && lane == 0) {           // per wave: stamps relative to the first, slot 16 w ..
+    if (DBG && mx.dbg_cost32 && !mx.dbg_state && lane == 0) {           // per wave: stamps relative to the first, slot 16 w ..
         float* d = mx.dbg_cost32 + (size_t)e * C + 16 * wave;
         for (int k = 1; k < nfp; ++k) d[k] = (float)(fph[k] - fph[0]);
         d[0] = (float)nfp; d[15] = (float)(fph[0] & 0xffffff);
@@ -2491,7 +2494,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + 16;
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const bool v3 = F1P_MIX_FILTER_V3 && !a.goals && mx.n_disc == 0 && (mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
-                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) : lds_fits(ctx, k_lattice_filter3<2>, lds_f3));
+                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3)
+                                              : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3));
             // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the
             // first (it waits for the first prologue): one chunk's latency-bound kernels (prologue, refinement, selection: a few waves
             // per SIMD) run beside the other's VALU-bound candidate kernel instead of after it.  Every chunk has its own queue region
@@ -2576,8 +2580,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         F1P_HIP(ctx, hipStreamWaitEvent(ctx->pipe_stream[0], ctx->ev_pipe[0], 0));
                     }
                     const unsigned f3_grid = (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
-                    if (mk.clear_r == 1) hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
-                    else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                    const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound;      // (test hooks: their own instantiation)
+                    if (mk.clear_r == 1) {
+                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                        else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                    } else {
+                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                        else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                    }
                 }
                 else if (mk.n_disc > 0 && mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter<1, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
                 else if (mk.n_disc > 0 && mk.clear_r == 2) hipLaunchKernelGGL((k_lattice_filter<2, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
