@@ -1861,9 +1861,6 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     // a dependent global round trip (16 x ~500 cycles: most of the fit's time, tools/refine_phases.py)
     __shared__ double s_gl_wu[16][6];
     __shared__ double s_gl_x[16];
-    if (tid < 96) s_gl_wu[tid / 6][tid % 6] = c_gl_wu[tid / 6][tid % 6];
-    else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
-    __syncthreads();
 #ifdef F1P_MIX_PHASES
     long long rph[16]; int nrp = 0;
 #define F1P_RPH() do { if (nrp < 15) rph[nrp++] = clock64(); } while (0)
@@ -1885,6 +1882,10 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     r_first.ok = 0; r_first.e = 0; r_first.c = 0; r_first.gx = 0; r_first.gy = 0; r_first.gth = 0; r_first.cost = 0; r_first.k0 = 0; r_first.dk = 0; r_first.L = 0; r_first.pad = 0;
     unsigned int n = mx.qcount[sh * 32u];
     if (g0 / F1P_MIX_QSHARDS < mx.q_shard_cap) r_first = mx.q[sh * mx.q_shard_cap + g0 / F1P_MIX_QSHARDS];
+    // ... and the tables go to LDS while both are on their way (they used to be staged, and waited for, before the count was even asked for)
+    if (tid < 96) s_gl_wu[tid / 6][tid % 6] = c_gl_wu[tid / 6][tid % 6];
+    else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
+    __syncthreads();
     asm volatile("" : "+v"(n), "+v"(r_first.ok));
     for (unsigned int ib = 0, li = g0 / F1P_MIX_QSHARDS; ; ib += ngroups_total, li += lstride) {
         const unsigned int i = sh * mx.q_shard_cap + li;
