@@ -1874,20 +1874,24 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     // group g works on shard g % shards, entries g / shards, + groups / shards, ... (the launcher makes the group count a multiple of the shard count)
     const unsigned int ngroups_total = gridDim.x * (blockDim.x >> 6) * GPW;
     const unsigned int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * GPW + grp;
-    const unsigned int sh = g0 % F1P_MIX_QSHARDS, lstride = ngroups_total / F1P_MIX_QSHARDS;
+    // A wave's groups take CONSECUTIVE entries of one shard -- an ego's own entries, or neighbouring egos': alike goals, alike phase lengths.
+    // The groups of a wave run in lockstep, so every phase costs the maximum over its four entries; with the groups of a wave spread
+    // over the shards (entries of unrelated egos) the refinement took 20.5 us against 19.3 (round 4).
+    const unsigned int sh = (g0 / GPW) % F1P_MIX_QSHARDS, lstride = ngroups_total / F1P_MIX_QSHARDS;
+    const unsigned int li_first = (g0 / (GPW * F1P_MIX_QSHARDS)) * GPW + g0 % GPW;
     // The group's first entry is requested TOGETHER with the shard's count, not after it (slots past the count hold stale entries of
     // earlier plans -- readable memory, masked below).  Written as two loads and one use of both: with the entry's load behind the
     // `any live` exit, which needs the count, the two round trips ran one after the other (4.4 k cycles per entry, tools/refine_phases.py).
     RefEntry r_first;
     r_first.ok = 0; r_first.e = 0; r_first.c = 0; r_first.gx = 0; r_first.gy = 0; r_first.gth = 0; r_first.cost = 0; r_first.k0 = 0; r_first.dk = 0; r_first.L = 0; r_first.pad = 0;
     unsigned int n = mx.qcount[sh * 32u];
-    if (g0 / F1P_MIX_QSHARDS < mx.q_shard_cap) r_first = mx.q[sh * mx.q_shard_cap + g0 / F1P_MIX_QSHARDS];
+    if (li_first < mx.q_shard_cap) r_first = mx.q[sh * mx.q_shard_cap + li_first];
     // ... and the tables go to LDS while both are on their way (they used to be staged, and waited for, before the count was even asked for)
     if (tid < 96) s_gl_wu[tid / 6][tid % 6] = c_gl_wu[tid / 6][tid % 6];
     else if (tid < 112) s_gl_x[tid - 96] = c_gl_x[tid - 96];
     __syncthreads();
     asm volatile("" : "+v"(n), "+v"(r_first.ok));
-    for (unsigned int ib = 0, li = g0 / F1P_MIX_QSHARDS; ; ib += ngroups_total, li += lstride) {
+    for (unsigned int ib = 0, li = li_first; ; ib += ngroups_total, li += lstride) {
         const unsigned int i = sh * mx.q_shard_cap + li;
         const bool live = li < n;
         if (!__any(live)) break;                                     // wave-uniform exit; groups past the end idle through the barriers
