@@ -2269,6 +2269,7 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     long long sph[8]; sph[0] = clock64();
 #endif
     const int base = mx.ego_base[e], n = mx.ego_n[e], ni = mx.ego_ni[e];
+    const double v_near = a.wv[ni];                              // the tracker's speed command: requested with the entries, consumed at the end
     const int c0 = cfg.cand_begin;
     // Round 4: ONE round trip for everything the usual ego needs.  Lane j takes the WHOLE record of entry j (cost, index, clothoid) -- the
     // winner's clothoid then comes by shuffle, not by a second dependent load -- and, alongside, every lane requests its station of the
@@ -2344,14 +2345,14 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     }
 #ifdef F1P_MIX_PHASES
     sph[2] = clock64();
-    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3);
-    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3);
+    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3, &v_near);
+    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, sph + 3, &v_near);
     sph[5] = clock64();
     if (lane == 0 && mx.dbg_cost32 && (size_t)e * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width)
         for (int k = 0; k < 5; ++k) mx.dbg_cost32[(size_t)a.E * cfg.n_lookahead * cfg.n_width / 2 + (size_t)e * 8 + k] = (float)(sph[k + 1] - sph[k]);
 #else
-    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
-    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y);
+    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);
+    else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);
 #endif
 }
 
