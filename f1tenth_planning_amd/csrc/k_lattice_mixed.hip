@@ -1849,13 +1849,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     constexpr int GPW = 64 / GS;                                 // groups (entries) per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
-    const int S = cfg.n_stations;
-    double* ncs = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * (64 + 4 * (size_t)S);   // [32] cos at the nodes
-    double* nsn = ncs + 32;                                                                    // [32] sin at the nodes
-    double* inc_x = nsn + 32;                                                                  // [S]
-    double* inc_y = inc_x + S;                                                                 // [S]
-    double* akv = inc_y + S;                                                                   // [S] |kappa| per station (station positions x before the cost phase)
-    double* simv = akv + S;                                                                    // [S] similarity term per station (station positions y before the cost phase)
+    const int S_arg = cfg.n_stations;
     // the 16-node rule's nodes and weight table (the rule of all but pathological goals) in LDS, once per workgroup: a lane's
     // sixteen-step moment chain then reads its operands from LDS with all reads in flight together -- from constant memory every step was
     // a dependent global round trip (16 x ~500 cycles: most of the fit's time, tools/refine_phases.py)
@@ -1868,9 +1862,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
 #define F1P_RPH() do {} while (0)
 #endif
     F1P_RPH();
-    const int den = S - 1 > 1 ? S - 1 : 1;
     const bool collide_on = cfg.check_collision && a.has_grid;
-    const int sim_m = S - cfg.n_shift - cfg.n_cull;
     // group g works on shard g % shards, entries g / shards, + groups / shards, ... (the launcher makes the group count a multiple of the shard count)
     const unsigned int ngroups_total = gridDim.x * (blockDim.x >> 6) * GPW;
     const unsigned int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * GPW + grp;
@@ -1892,6 +1884,23 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     __syncthreads();
     asm volatile("" : "+v"(n), "+v"(r_first.ok));
     for (unsigned int ib = 0, li = li_first; ; ib += ngroups_total, li += lstride) {
+#ifdef F1P_MIX_REFINE_LICM
+        const int S = S_arg;
+#else
+        // The loop almost always runs ONCE (a group has one entry), but everything that depends only on the station count is "loop-invariant":
+        // the compiler hoists ~80 such scalars in front of the loop and, with 100 SGPRs, spills them into VGPR lanes (162 v_writelane before
+        // the first entry, a v_readlane at every use).  An opaque copy of S per iteration keeps them where they are used.
+        int S = S_arg;
+        asm volatile("" : "+s"(S));
+#endif
+        const int den = S - 1 > 1 ? S - 1 : 1;
+        const int sim_m = S - cfg.n_shift - cfg.n_cull;
+        double* ncs = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * (64 + 4 * (size_t)S);   // [32] cos at the nodes
+        double* nsn = ncs + 32;                                                                    // [32] sin at the nodes
+        double* inc_x = nsn + 32;                                                                  // [S]
+        double* inc_y = inc_x + S;                                                                 // [S]
+        double* akv = inc_y + S;                                                                   // [S] |kappa| per station (station positions x before the cost phase)
+        double* simv = akv + S;                                                                    // [S] similarity term per station (station positions y before the cost phase)
         const unsigned int i = sh * mx.q_shard_cap + li;
         const bool live = li < n;
         if (!__any(live)) break;                                     // wave-uniform exit; groups past the end idle through the barriers
