@@ -54,6 +54,21 @@ __device__ __forceinline__ void wave_argmin(double& d, int& i) {
     }
 }
 
+// Minimum of non-NaN floats over the 64 lanes (all active) on order-preserving integer keys: fminf compiles to a canonicalising v_max
+// in front of every v_min (four instructions per DPP step); v_min_i32 folds the DPP operand and needs none.  key(x) is monotone in x
+// over all finite values and +-inf (-0.0 < +0.0 as keys: a minimum of brackets does not care).
+__device__ __forceinline__ int f32_order_key(float x) { const int b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float f32_from_order_key(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ int wave_min_key(int v) {                // result in every lane (a wave-uniform value)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));   // (a lane without a source takes the identity)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // The same result over the 64 lanes of a FULLY ACTIVE wave by DPP row shifts / row broadcasts and one v_readlane instead of six
 // ds_bpermute round trips per operand (~1.2 k cycles of a one-wave-per-SIMD kernel's chain against ~0.3 k).  argmin_better is a total
 // order on (value, index), so the shape of the reduction tree does not matter.
@@ -194,9 +209,25 @@ __device__ __forceinline__ void nearest_scan(double px, double py, const double*
 // wave must call this (ballot inside).
 // best_t (optional): the projection parameter of the lane's best segment, so that a caller that needs nearest_point's `t` after the
 // cross-lane argmin can take it from the owning lane by shuffle instead of loading the segment again and projecting a second time.
+__device__ __forceinline__ void nearest_scan_preload(const double* __restrict__ wx, const double* __restrict__ wy, const double* __restrict__ box, int n,
+                                                     int tid, double* pre) {
+    const int lane = tid & 63;
+    const int nchunk = (n - 1 + 63) >> 6;
+    const int stride = (n + 63) >> 6;
+    int j = lane * stride;
+    if (j > n - 1) j = n - 1;
+    pre[0] = 0.0; pre[1] = 0.0; pre[2] = 0.0; pre[3] = 0.0;
+    if (box && lane < nchunk) { pre[0] = box[4 * lane]; pre[1] = box[4 * lane + 1]; pre[2] = box[4 * lane + 2]; pre[3] = box[4 * lane + 3]; }
+    pre[4] = wx[j]; pre[5] = wy[j];
+}
+
 __device__ __forceinline__ void nearest_scan_boxed(double px, double py, const double* __restrict__ wx,
                                                    const double* __restrict__ wy, const double* __restrict__ box, int n,
-                                                   int tid, int nthreads, double& best_d, int& best_i, double* best_t = nullptr) {
+                                                   int tid, int nthreads, double& best_d, int& best_i, double* best_t = nullptr,
+                                                   const double* pre = nullptr) {
+    // pre (optional, 6 doubles per lane): this lane's first chunk box (xmin, xmax, ymin, ymax) and its sample waypoint, loaded by the caller
+    // BEFORE the query point was known (neither depends on it) -- nearest_scan_preload -- so that the scan does not start with a round
+    // trip of its own behind the pose's
 #if !F1P_NEAREST_PRUNE
     nearest_scan(px, py, wx, wy, n, tid, nthreads, best_d, best_i);
     if (best_t) *best_t = best_i != 0x7fffffff ? seg_project(px, py, wx[best_i], wy[best_i], wx[best_i + 1], wy[best_i + 1]).t : 0.0;
@@ -212,12 +243,18 @@ __device__ __forceinline__ void nearest_scan_boxed(double px, double py, const d
     int j = lane * stride;
     if (j > n - 1) j = n - 1;
     // the first 64 chunk boxes are requested together with the samples (they do not depend on the bound): one round trip, not two
-    double b0x = 0.0, b0X = 0.0, b0y = 0.0, b0Y = 0.0;
-    if (lane < nchunk) { b0x = box[4 * lane]; b0X = box[4 * lane + 1]; b0y = box[4 * lane + 2]; b0Y = box[4 * lane + 3]; }
-    const double ex = px - wx[j], ey = py - wy[j];
-    double ub2 = ex * ex + ey * ey;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) ub2 = __builtin_fmin(ub2, shfl_xor_d(ub2, m));   // fmin drops NaN samples
+    double b0x = 0.0, b0X = 0.0, b0y = 0.0, b0Y = 0.0, sx_ = 0.0, sy_ = 0.0;
+    if (pre) { b0x = pre[0]; b0X = pre[1]; b0y = pre[2]; b0Y = pre[3]; sx_ = pre[4]; sy_ = pre[5]; }
+    else {
+        if (lane < nchunk) { b0x = box[4 * lane]; b0X = box[4 * lane + 1]; b0y = box[4 * lane + 2]; b0Y = box[4 * lane + 3]; }
+        sx_ = wx[j]; sy_ = wy[j];
+    }
+    const double ex = px - sx_, ey = py - sy_;
+    // The bound only prunes, so the wave minimum is taken on f32 values rounded UP (six v_min_i32_dpp on order keys instead of twelve
+    // ds_bpermute + fmin on doubles); a NaN sample has the largest key and drops out unless every sample is NaN (then nothing is pruned).
+    const double ub2_own = ex * ex + ey * ey;
+    const float ub2_up = (float)ub2_own * (1.0f + 2.4e-7f);
+    const double ub2 = (double)f32_from_order_key(wave_min_key(f32_order_key(ub2_up == ub2_up ? ub2_up : __builtin_nanf(""))));
     const double thr = ub2 * (1.0 + 1e-6) + 1e-9;
     int turn = 0;
     for (int cb = 0; cb < nchunk; cb += 64) {

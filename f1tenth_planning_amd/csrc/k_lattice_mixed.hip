@@ -992,7 +992,42 @@ struct EgoParamsF2 {
 // rounds on the few candidates that can still matter (k_lattice_filter3).  The states and brackets of the candidates that reach the
 // refinement queue are the ones the every-candidate loop produced, so the queue -- and every output -- is unchanged.
 #define F1P_ST_PENDING 4           // bracket known, collision state not looked at (yet)
-struct Brk32 { float cost, lo, hi, edge, ebound; int state; bool never_free; };
+struct Brk32 { float cost, lo, hi, ebound; int state; bool never_free; };
+
+// The band around a cell edge inside which a look-up of THIS candidate decides nothing: farther than the f32 POSITION error -- the
+// calibrated band (edge0 + edge1 L: 5-10x the measured end-point error, tools/mixed_endpoint_error.py) or, when larger, the candidate's
+// a-priori bound:
+//   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
+//   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
+//   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
+// In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station is
+// within the ONE cell of slack the clearance map was built with: a candidate whose band reaches 0.8 cells decides nothing
+// by its positions (the caller's never_free; ADVICE r3 -- never observed: the bound is three orders inside it for every trusted candidate).
+// Only the candidates that take the station pass need it (round 4: it used to be formed for all 256).
+template <int R>
+__device__ __forceinline__ float edge_f2(float k0, float dk, float L, float ek0, float edk, float eLrel, const F1P_LDS(EgoParamsF2)* ep, bool exact_all,
+                                         float* e_pos_out = nullptr) {
+    constexpr int G = 2 * R + 1;
+    const bool macro = F1P_MIX_MACRO && !exact_all && G > 1;
+    const float gm = macro ? (float)G : 1.0f;
+    const float ds = L * ep->inv_den, h = 0.5f * ds;
+    const float b = 0.5f * dk * h * h;
+    const float kmax = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, L, k0)));
+    const float hp = gm * h, bp = (gm * gm) * b;
+    const float U = 6.0e-8f;
+    const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+    const float e_th = L * ek0 + 0.5f * L * L * edk + 2.0f * TH * eLrel;
+    const float zm = (kmax * hp) * (kmax * hp);                           // of the piece actually integrated (hp = G h in the macro mode)
+    // the one-piece series keeps P = 2 - z/3 + z^2/60 - b^2/5 and Q = 2 b (1/3 - z/10) of int_{-1}^{1} exp(j (a t + b t^2)) dt; the first
+    // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
+    const float abp = fabsf(bp);
+    const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
+    const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
+    if (e_pos_out) *e_pos_out = e_pos;
+    float edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
+    if (!(edge == edge)) edge = 2.0f;                                      // NaN: nothing is "away from an edge"
+    return edge;
+}
 
 template <int R>
 __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, double sim_s2, double sim_s3, double sim_s4) {
@@ -1015,32 +1050,11 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     const float hp = gm * h, bp = (gm * gm) * b;                             // the piece's half-length and quadratic phase coefficient
     const bool untrusted = !(kmax * hp <= 0.4f) || !(fabsf(bp) <= 0.05f);    // outside the one-piece series' range the positions decide nothing
     bool unsure = untrusted || !(ds <= ep->clear_ds_cap);                    // ... nor beyond the spacing the clearance map was built for (NaN: unsure)
-    // "away from every cell edge" = farther than the f32 POSITION error: the calibrated band (edge0 + edge1 L: 5-10x the measured
-    // end-point error, tools/mixed_endpoint_error.py) or, when larger, this candidate's a-priori bound:
-    //   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
-    //   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
-    //   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
-    float edge;
-    {
-        const float U = 6.0e-8f;
-        const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
-        const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel;
-        const float zm = (kmax * hp) * (kmax * hp);                           // of the piece actually integrated (hp = G h in the macro mode)
-        // the one-piece series keeps P = 2 - z/3 + z^2/60 - b^2/5 and Q = 2 b (1/3 - z/10) of int_{-1}^{1} exp(j (a t + b t^2)) dt; the first
-        // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
-        const float abp = fabsf(bp);
-        const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
-        const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
-        o.ebound = e_pos;                                                  // (F1P_MIX_DEBUG_END: the end-point tool compares the measured miss with this bound [m])
-        edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
-        if (!(edge == edge)) edge = 2.0f;                                  // NaN: nothing is "away from an edge"
-        // In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station
-        // is within the ONE cell of slack the clearance map was built with: the a-priori position bound is three orders
-        // inside it for every trusted candidate, but nothing compared the two -- a candidate whose bound reaches 0.8 cells decides nothing
-        // by its positions (never observed: the fuzz runs and the audit are green without it)
-        unsure |= !(edge < 0.8f);
-    }
-    o.edge = edge;
+    // (the cell-edge band of the look-ups -- and with it the a-priori POSITION bound -- is formed by edge_f2 for the candidates that take the
+    // station pass: nothing in the bracket needs it)
+#ifdef F1P_MIX_DEBUG_END
+    { float e_pos_dbg; (void)edge_f2<R>(k0, dk, L, f.ek0, f.edk, f.eLrel, ep, exact_all, &e_pos_dbg); o.ebound = e_pos_dbg; }   // the end-point tool compares the measured miss with this bound [m]
+#endif
     float sim = 0.f;
     const double* prev = ep->prev;
     if (prev) {
@@ -1269,21 +1283,6 @@ __device__ __forceinline__ float wave_scan_add(float v) {          // inclusive 
     return v;
 }
 
-// Minimum of non-NaN floats over the 64 lanes (all active) on order-preserving integer keys: fminf compiles to a canonicalising v_max
-// in front of every v_min (four instructions per DPP step); v_min_i32 folds the DPP operand and needs none.  key(x) is monotone in x
-// over all finite values and +-inf (-0.0 < +0.0 as keys: a minimum of brackets does not care).
-__device__ __forceinline__ int f32_order_key(float x) { const int b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float f32_from_order_key(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
-__device__ __forceinline__ int wave_min_key(int v) {                // result in every lane (a wave-uniform value)
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));   // (a lane without a source takes the identity)
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));   // (a lane without a source takes the identity)
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));   // (a lane without a source takes the identity)
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));   // (a lane without a source takes the identity)
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
 template <int R>
 __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
                                                  const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
@@ -1373,6 +1372,9 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
 #define F1P_PPH() do {} while (0)
 #endif
     F1P_PPH();
+    // what the nearest-segment scan reads first (chunk boxes, sample waypoints) does not depend on the pose: requested together with it
+    double scan_pre[6];
+    nearest_scan_preload(a.wx, a.wy, a.wbox, a.n, lane, scan_pre);
     const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
     if (a.pose_copy && lane < 4) a.pose_copy[4 * e + lane] = a.poses[4 * e + lane];   // the poses came from host memory: HBM copy for the kernels behind this one
     // moments of the previous path's headings for the filter's closed-form similarity term (EgoParamsF2::M0..M2): the loads are
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     // ---- nearest segment and look-ahead centres: the arithmetic of k_lattice (fp64: these decide indices), one wave ---------------
     double nd; int ni;
     double my_t = 0.0;
-    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, lane, 64, nd, ni, &my_t);
+    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, lane, 64, nd, ni, &my_t, a.wbox ? scan_pre : nullptr);
     F1P_PPH();
     // nearest_point's t of the winning segment: the lane that projected it still holds it (the same seg_project call, the same bits) --
     // round 3 loaded the segment again and projected a second time, a dependent round trip + ~60 fp64 instructions per ego
@@ -1446,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     sn_t = shfl_d(sn_t, 0); cs_t = shfl_d(cs_t, 0);
     if (a.prev_theta) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { pm0 += shfl_xor_d(pm0, m); pm1 += shfl_xor_d(pm1, m); pm2 += shfl_xor_d(pm2, m); }
+        for (int m = 32; m >= 1; m >>= 1) { pm0 += shfl_xor_d(pm0, m); pm1 += shfl_xor_d(pm1, m); pm2 += shfl_xor_d(pm2, m); }   // (requested early, consumed here: off the chain)
     }
     unsigned char* rec = recs + (size_t)e * ego_rec_stride(nl);
     double* r_cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
@@ -1584,8 +1586,8 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     const float INF = __builtin_huge_valf();
 
     // ---- phase 1, every candidate in f32: goal -> G1 fit -> cost and bracket [lo, hi]; nothing looks at positions -------------------
-    float kf_k0 = 0.f, kf_dk = 0.f, kf_L = 0.f, kf_edge = 0.f;    // the one-pass thread's fit for the station pass
-    auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& edge, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
+    float kf_k0 = 0.f, kf_dk = 0.f, kf_L = 0.f, kf_ek0 = 0.f, kf_edk = 0.f, kf_eL = 0.f;    // the one-pass thread's fit (and its error bounds) for the station pass
+    auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& ek0, float& edk, float& eL, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
         // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
         const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
         const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
         o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
         const bool trusted = r_ok & f.ok;
-        k0 = f.k0; dk = f.dk; L = f.L; edge = o.edge;
+        k0 = f.k0; dk = f.dk; L = f.L; ek0 = f.ek0; edk = f.edk; eL = f.eLrel;
         // no goal: BAD (infeasible in fp64 too);  no trusted bracket: UNSURE with lo = -inf (the fp64 tests decide);  else what bracket_f2 says
         int st = trusted ? (o.state | (o.never_free ? 0x80 : 0)) : F1P_ST_UNSURE;
         st = gok ? st : F1P_ST_BAD;
@@ -1612,7 +1614,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         const int c = cb + ptid;
         if (c >= c1) continue;
         float lo, hi, gx, gy; Brk32 o; int dbg_code;
-        const int st = bracket_of(c, kf_k0, kf_dk, kf_L, kf_edge, lo, hi, gx, gy, o, dbg_code);
+        const int st = bracket_of(c, kf_k0, kf_dk, kf_L, kf_ek0, kf_edk, kf_eL, lo, hi, gx, gy, o, dbg_code);
         c_lo[c - c0] = lo; c_hi[c - c0] = hi;
         c_st[c - c0] = (unsigned char)st;
         if ((st & 0x7f) == F1P_ST_PENDING) my_hi_p = fminf(my_hi_p, hi);
@@ -1691,11 +1693,15 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 #endif
             const unsigned long long selm = __ballot(sel);
             if (selm) {                                           // wave-uniform
-                float k0 = kf_k0, dk = kf_dk, L = kf_L, edge = kf_edge;
+                float k0 = kf_k0, dk = kf_dk, L = kf_L, ek0 = kf_ek0, edk = kf_edk, eL = kf_eL;
                 if (!one_pass && sel) {                           // several candidates per thread: the selected one is fitted again
                     float lo2, hi2, gx, gy; Brk32 o; int dbg_code;
-                    (void)bracket_of(c, k0, dk, L, edge, lo2, hi2, gx, gy, o, dbg_code);
+                    (void)bracket_of(c, k0, dk, L, ek0, edk, eL, lo2, hi2, gx, gy, o, dbg_code);
                 }
+                // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
+                float edge = 2.0f;
+                bool nfree = (st & 0x80) != 0;
+                if (sel) { edge = edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, exact_all_wg); nfree |= !(edge < 0.8f); }
                 int ns = F1P_ST_PENDING;
                 [[maybe_unused]] float xe = 0.f, ye = 0.f;
 #ifndef F1P_MIX_DEBUG_END
@@ -1707,13 +1713,13 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                         const int sl = __ffsll((long long)m) - 1;
                         const float uk0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k0), sl)), udk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), sl));
                         const float uL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L), sl)), uedge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edge), sl));
-                        const bool unf = (__builtin_amdgcn_readlane(st, sl) & 0x80) != 0;
+                        const bool unf = __builtin_amdgcn_readlane(nfree ? 1 : 0, sl) != 0;
                         const int r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, lane, plan, exact_all_wg);
                         if (lane == sl) ns = r;
                     }
                 } else
 #endif
-                if (sel) ns = station_pass_f2<CR>(k0, dk, L, edge, (st & 0x80) != 0, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, xe, ye);
+                if (sel) ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, xe, ye);
                 if (sel) {
                     c_st[c - c0] = (unsigned char)ns;
                     if (ns == F1P_ST_FREE) t_free = fminf(t_free, c_hi[c - c0]);
@@ -1766,9 +1772,10 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     int ok1 = 0;
     bool need1 = false;
     if (one_pass && c0 + ptid < c1) {
-        const int c = c0 + ptid, st = c_st[c - c0] & 0x7f;
-        need1 = (((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min)) | (none_free & (c == c0));
+        const int c = c0 + ptid;
+        need1 = mine != 0;                                           // (one candidate per thread: what the count above found)
         if (need1) {
+            const int st = c_st[c - c0] & 0x7f;
             const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
             ok1 = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0;
         }
@@ -1948,8 +1955,10 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
             double acc = 0.0;                                        // group lanes 0..5: m.c[gl], 6..11: m.s[gl - 6]
             const int k = gl < 6 ? gl : gl - 6;
             int max_panels = panels;
+            if (__any(panels > 1)) {                             // (one ballot in the usual case: the butterfly was six ds_bpermute round trips per fit pass)
 #pragma unroll
-            for (int m_ = 32; m_ >= 1; m_ >>= 1) { const int o = __shfl_xor(max_panels, m_, 64); max_panels = o > max_panels ? o : max_panels; }
+                for (int m_ = 32; m_ >= 1; m_ >>= 1) { const int o = __shfl_xor(max_panels, m_, 64); max_panels = o > max_panels ? o : max_panels; }
+            }
             if (max_panels == 1) {
                 const bool rule16 = cnt == 16;                       // off == 0: the tables in LDS
                 for (int j = gl; j < cnt; j += GS) {
