@@ -182,14 +182,14 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
                                       (-0.502821153340377f + xy * 0.261062141752652f) * (X2 + Y2) + -0.045854475238709f * (X2 * X2 + Y2 * Y2));
     const bool c42 = fabsf(A0) + fabsf(delta - A0) <= F1P_MIX_EXC_MAX;       // beyond what 16 nodes integrate to f32 accuracy (also NaN)
     const float ar = A0 * F1P_INV_2PI_F, br = (delta - A0) * F1P_INV_2PI_F, cr = phi0 * F1P_INV_2PI_F;   // phase in revolutions
+    // (this translation unit is compiled without the SLP vectoriser: its v_pk_* cost more in the moves that assemble their operand pairs than
+    // they save -- filter3 33.4 -> 32.3 us.  The accumulation below written with explicit two-element vectors, 12 v_pk_fma_f32 per two node
+    // pairs instead of 24 v_fma_f32, measured 32.55 us: scalar it stays.)
     float mc[6], ms[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
-    // The rule is symmetric about 1/2: nodes j and 15 - j share u = tau^2 - tau and the weight, i.e. the whole row w u^k -- so the
-    // two nodes' cosines (sines) are added first and ONE row of six fma serves both: 8 x 12 fma instead of 16 x 12 (round 4).  Each
-    // node's phase is still formed from the tabulated node itself, so the a-priori bound below holds with room (fewer roundings).
 #ifndef F1P_EXP_FIT_PAIRS
-#define F1P_EXP_FIT_PAIRS 8          // (timing experiments only: fewer pairs give WRONG moments)
+#define F1P_EXP_FIT_PAIRS 8
 #endif
 #pragma unroll F1P_MIX_FIT_UNROLL
     for (int j = 0; j < F1P_EXP_FIT_PAIRS; ++j) {
