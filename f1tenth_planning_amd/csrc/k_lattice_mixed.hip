@@ -188,11 +188,8 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     float mc[6], ms[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
-#ifndef F1P_EXP_FIT_PAIRS
-#define F1P_EXP_FIT_PAIRS 8
-#endif
 #pragma unroll F1P_MIX_FIT_UNROLL
-    for (int j = 0; j < F1P_EXP_FIT_PAIRS; ++j) {
+    for (int j = 0; j < 8; ++j) {
         const float tau = c_gl16_xf[j], tau2 = c_gl16_xf[15 - j];
         const float ph = __builtin_fmaf(__builtin_fmaf(ar, tau, br), tau, cr);
         const float ph2 = __builtin_fmaf(__builtin_fmaf(ar, tau2, br), tau2, cr);
@@ -1686,11 +1683,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
             const int c = cb + ptid;
             const int st = c < c1 ? (int)c_st[c - c0] : F1P_ST_BAD;
             const float lo = c < c1 ? c_lo[c - c0] : INF;
-#ifdef F1P_F3_NO_PASS
-            const bool sel = false && (st & 0x7f) == F1P_ST_PENDING && (all_states || !(lo > thr));   // timing experiment only: WRONG results
-#else
             const bool sel = (st & 0x7f) == F1P_ST_PENDING && (all_states || !(lo > thr));
-#endif
             const unsigned long long selm = __ballot(sel);
             if (selm) {                                           // wave-uniform
                 float k0 = kf_k0, dk = kf_dk, L = kf_L, ek0 = kf_ek0, edk = kf_edk, eL = kf_eL;
