@@ -1,4 +1,4 @@
-// k_lattice_mixed.hip -- the mixed-precision schedule of the lattice planner (default from 320 egos): an f32 filter that knows its own
+// k_lattice_mixed.hip -- the mixed-precision schedule of the lattice planner (the default: F1P_MIX_MIN_EGOS_V3 / F1P_MIX_MIN_EGOS): an f32 filter that knows its own
 // error decides what CANNOT win, the unchanged fp64 arithmetic decides among the rest; every output is bit-identical to k_lattice
 // (k_lattice.hip).  Kernels: k_lattice_prologue (fp64, wave per ego) -> k_lattice_filter3 (f32, thread per candidate) -> k_lattice_refine
 // (fp64, 16 lanes per queue entry) -> k_lattice_select (fp64, wave per ego); k_lattice_filter is the one-kernel fallback filter for host
@@ -9,7 +9,7 @@
 namespace f1p {
 
 // ===================================================================================================================
-// Mixed-precision schedule (f1p_lattice_set_mode(ctx, 1), the default from F1P_MIX_MIN_EGOS egos): an f32 FILTER over every
+// Mixed-precision schedule (f1p_lattice_set_mode(ctx, 1), the default from F1P_MIX_MIN_EGOS_V3 / F1P_MIX_MIN_EGOS egos): an f32 FILTER over every
 // candidate-trajectory-step, the DECISION in fp64 -- the pattern of k_kmpc_shoot_mixed applied to the lattice planner.
 //
 //   k_lattice_filter  (workgroup per ego)   nearest segment, look-ahead centres, occupancy tile and goals exactly as k_lattice
@@ -37,8 +37,13 @@ namespace f1p {
 // added so that "everything blocked" returns the exhaustive loop's answer (first candidate, +inf).  Outputs are bit-identical to
 // k_lattice (tests: all fuzz seeds, the 4096-ego bench batch, collisions, similarity term, NaN inputs, host goals, shards).
 // ===================================================================================================================
+#ifndef F1P_MIX_MIN_EGOS_V3
+#define F1P_MIX_MIN_EGOS_V3 1  // ... and for the plans that take k_lattice_prologue + k_lattice_filter3 (device-sampled goals, clearance mode, point footprint): measured,
+                               // round 4 (the lazy station pass; tools/time_modes_vs_egos.py, all fp64 / mixed): 1 ego 0.0399 / 0.0279 ms, 8: 0.041 / 0.032, 64: 0.048 / 0.040,
+                               // 256: 0.050 / 0.037, 512: 0.063 / 0.041, 2048: 0.132 / 0.052 -- the mixed schedule wins at every batch size
+#endif
 #ifndef F1P_MIX_MIN_EGOS
-#define F1P_MIX_MIN_EGOS 320   // measured crossover (tools/time_modes_vs_egos.py, round 3): 1 ego 0.0397 (all fp64) / 0.0398 (mixed), 64: 0.048 / 0.054, 256: 0.0502 / 0.0507, 512: 0.064 / 0.053, 1024: 0.077 / 0.060, 2048: 0.132 / 0.073 ms (round 2: 512)
+#define F1P_MIX_MIN_EGOS 320   // (the one-kernel fallback filter: host goals, r = 0, oriented footprint) measured crossover (tools/time_modes_vs_egos.py, round 3): 1 ego 0.0397 (all fp64) / 0.0398 (mixed), 64: 0.048 / 0.054, 256: 0.0502 / 0.0507, 512: 0.064 / 0.053, 1024: 0.077 / 0.060, 2048: 0.132 / 0.073 ms (round 2: 512)
 #endif
 // filter tolerances (calibrated by tests/test_gpu_lattice_mixed.py through the debug hook):
 #ifndef F1P_MIX_MARGIN_REL
@@ -2470,8 +2475,11 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             if (clear_ok) break;
         }
     }
+    // (the plans that will take the prologue + candidate-kernel pair -- decided for good below -- switch to the mixed schedule from one ego)
+    const bool v3_likely = F1P_MIX_FILTER_V3 && !a.goals && !foot && clear_ok && (clear_r_eff == 1 || clear_r_eff == 2) && a.tile_words + 1 <= 16;
+    const int min_egos = v3_likely ? F1P_MIX_MIN_EGOS_V3 : F1P_MIX_MIN_EGOS;
     if (ctx->lattice_mixed && (!foot || clear_ok) && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
-        (E >= F1P_MIX_MIN_EGOS || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
+        (E >= min_egos || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t tile_bytes = sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
         size_t lds_f = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS) + sizeof(EgoParams) + sizeof(EgoParams32) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
                        sizeof(float) * 4 + sizeof(int) * (2 + 64 + 256) + (size_t)n_cand * 5 + 16 + 2 * tile_bytes;

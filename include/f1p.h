@@ -207,7 +207,7 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius);
  * configured with f1p_inflate_grid (one exact dilation by the sum of the two radii) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
  * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the grid with the caller's inflation alone.  Needs the grid;
- * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 320 egos with device-sampled goals --
+ * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 320 egos, with device-sampled goals --
  * the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0); outputs are bit-identical either way. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
 
@@ -315,7 +315,8 @@ int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f
 int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S);
 
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
- *   mixed = 1 (default): batches of >= 320 egos run an f32 filter over EVERY candidate-trajectory-step (fit, stations, occupancy,
+ *   mixed = 1 (default): plans with device-sampled goals and a point footprint in the clearance mode (the usual case) at every batch
+ *   size, other plans from 320 egos, run an f32 filter over the candidates (fit, cost bracket; stations, occupancy,
  *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
  *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
  *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;

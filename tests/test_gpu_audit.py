@@ -37,10 +37,16 @@ def test_audit_counts_and_stays_at_zero(scene):
         ctx.lattice_set_audit(0)
         ctx.lattice_plan(poses, cfg)
         assert ctx.lattice_audit_read()["plans"] == 0
-        # below the mixed schedule's batch size the plan IS the fp64 kernel: nothing to audit
+        # small batches take the mixed schedule too (round 4: it wins from one ego) and are audited like any other ...
         ctx.lattice_set_audit(1, 32)
         ctx.lattice_plan(poses[:100], cfg)
+        a = ctx.lattice_audit_read(reset=True)
+        assert a["plans"] == 1 and a["egos"] == 32 and a["mismatching_egos"] == 0, a
+        # ... while a plan of the all-fp64 kernel IS the truth: nothing to audit
+        ctx.lattice_set_mode(0)
+        ctx.lattice_plan(poses[:100], cfg)
         assert ctx.lattice_audit_read()["plans"] == 0
+        ctx.lattice_set_mode(1)
 
 
 def test_audit_fires_when_the_filter_is_broken(scene):

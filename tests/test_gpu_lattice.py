@@ -227,7 +227,7 @@ def test_branch_and_bound_is_bit_identical_to_the_exhaustive_loop(ctx, scene):
     """cfg.prune = 1 skips the station loop of candidates whose cost lower bound exceeds the best cost so far; index, cost,
     status, steering, speed and trajectory must not change in any bit -- with collisions, with the similarity term, with more
     than 256 candidates, on a candidate shard, with blocked egos, host goals, NaN goals and a NaN previous trajectory.
-    (mode 0 = all fp64: from 320 egos the default schedule is the mixed-precision one, tests/test_gpu_lattice_mixed.py)"""
+    (mode 0 = all fp64: the default schedule is the mixed-precision one, tests/test_gpu_lattice_mixed.py)"""
     ctx.lattice_set_mode(0)
     rl, img, origin = scene
     import copy
