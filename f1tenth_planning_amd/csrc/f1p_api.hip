@@ -829,6 +829,8 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
     // From 8192 egos the batch is planned in slices of >= 4096 egos whose results travel on a second stream while the next slice
     // is planned (only into page-locked memory: copies into pageable memory block the calling thread and would serialise the slices).
     TRAJ* d_bt = zero_copy_traj ? bt_dev : s.out(best_traj, e * S * 4);
+    struct HostDst { f1p_ctx* c; ~HostDst() { c->traj_dst_host = false; } } host_dst{ctx};   // (reset on every way out)
+    ctx->traj_dst_host = zero_copy_traj;
     double* d_ac = s.out(all_cost, e * C); double* d_at = s.out(all_traj, e * C * S * 4);
     auto plan = [&](size_t e0, size_t n) {
         double* bt64 = nullptr; float* bt32 = nullptr;

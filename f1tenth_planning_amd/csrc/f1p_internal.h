@@ -110,6 +110,7 @@ struct f1p_ctx {
 
     // f1p_lattice_step_batch: page-locked block (poses | steer | speed | status) the kernels read / write directly, and the device side
     // (pose copy | best_idx | near_idx | kept trajectories)
+    bool traj_dst_host = false;        // the plan being launched writes best_traj straight into page-locked host memory (zero-copy rows)
     char* h_step = nullptr; size_t step_host_bytes = 0;
     char* h_step_dev = nullptr;             // its device-side address (hipHostGetDevicePointer, once)
     char* d_step = nullptr; size_t step_dev_bytes = 0;

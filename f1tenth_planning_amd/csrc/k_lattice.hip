@@ -502,7 +502,7 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
                    double* d_pose_copy) {
     if (E <= 0) return F1P_OK;
     LatticeArgs a;
-    a.theta_out = d_theta_out; a.pose_copy = nullptr;
+    a.theta_out = d_theta_out; a.pose_copy = nullptr; a.traj_in_hbm = ctx->traj_dst_host ? 0 : 1;
     a.poses = d_poses; a.goals = d_goals; a.prev_theta = d_prev_theta;
     a.E = E; a.mode = mode; a.e0 = 0;
     a.wx = ctx->d_wx; a.wy = ctx->d_wy; a.wv = ctx->d_wv; a.wpsi = ctx->d_wpsi; a.wbox = ctx->d_wbox; a.n = ctx->n_wp;
