@@ -1569,9 +1569,9 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 #endif
     // ---- the ego's record: one coalesced copy into LDS ----------------------------------------------------------------------------
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(recs + (size_t)e * rec_bytes);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(rec);
-        for (int q = tid; q < (int)(rec_bytes >> 2); q += blockDim.x) dst[q] = src[q];
+        const uint4* src = reinterpret_cast<const uint4*>(recs + (size_t)e * rec_bytes);   // (the stride and the LDS block are 16-byte aligned)
+        uint4* dst = reinterpret_cast<uint4*>(rec);
+        for (int q = tid; q < (int)(rec_bytes >> 4); q += blockDim.x) dst[q] = src[q];
     }
     if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
     if (tid == 0) cnt[0] = 0;
