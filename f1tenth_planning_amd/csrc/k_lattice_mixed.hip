@@ -1477,9 +1477,12 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         __builtin_nontemporal_store(cxv, r_cen + l); __builtin_nontemporal_store(cyv, r_cen + nl + l); __builtin_nontemporal_store(sp, r_cen + 2 * nl + l);
         __builtin_nontemporal_store(cp, r_cen + 3 * nl + l); __builtin_nontemporal_store(gth64, r_cen + 4 * nl + l);
         {
+            typedef double f1p_d2 __attribute__((ext_vector_type(2)));
+            typedef int f1p_i2 __attribute__((ext_vector_type(2)));
             double* gd = reinterpret_cast<double*>(r_gf + l);
-            __builtin_nontemporal_store(g.cx, gd); __builtin_nontemporal_store(g.cy, gd + 1); __builtin_nontemporal_store(g.nx, gd + 2); __builtin_nontemporal_store(g.ny, gd + 3);
-            __builtin_nontemporal_store(g.gth, reinterpret_cast<float*>(gd + 4)); __builtin_nontemporal_store(g.ok, reinterpret_cast<int*>(gd + 4) + 1);
+            __builtin_nontemporal_store((f1p_d2){g.cx, g.cy}, reinterpret_cast<f1p_d2*>(gd));
+            __builtin_nontemporal_store((f1p_d2){g.nx, g.ny}, reinterpret_cast<f1p_d2*>(gd + 2));
+            __builtin_nontemporal_store((f1p_i2){__float_as_int(g.gth), g.ok}, reinterpret_cast<f1p_i2*>(gd + 4));
         }
     }
     F1P_PPH();
