@@ -2317,10 +2317,21 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
         if (n >= 1 && li0 < mx.inc_cap) { const double* gp = mx.inc + ((size_t)sh0 * mx.inc_cap + li0) * 2 * (size_t)S; sx0 = gp[lane]; sy0 = gp[S + lane]; }
         if (n >= 2 && li0 + 1 < mx.inc_cap) { const double* gp = mx.inc + ((size_t)sh0 * mx.inc_cap + li0 + 1) * 2 * (size_t)S; sx1 = gp[lane]; sy1 = gp[S + lane]; }
     }
-    for (int j = lane + 64; j < n; j += 64) {
-        const double cost = mx.q[base + j].cost;
-        const int c = mx.q[base + j].c;
-        if (argmin_better(cost, c, bc, bi)) { bc = cost; bi = c; bslot = base + j; }
+    // (a blocked ego's further entries, four rounds of loads in flight at a time: one round trip per 256 entries instead of one per 64 --
+    // the wave with the most entries is the one the kernel waits for)
+    for (int j0 = lane + 64; j0 < n; j0 += 256) {
+        double cost[4]; int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            cost[u] = __builtin_huge_val(); cc[u] = 0x7fffffff;
+            if (j < n) { cost[u] = mx.q[base + j].cost; cc[u] = mx.q[base + j].c; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < n && argmin_better(cost[u], cc[u], bc, bi)) { bc = cost[u]; bi = cc[u]; bslot = base + j; }
+        }
     }
     int src = 0;
     {   // wave argmin carrying the slot (candidate indices are unique per ego)

@@ -20,4 +20,9 @@ with Context(0) as ctx:
     ph = d_c.download(np.float32, (E * C,))[E * C // 2:E * C // 2 + E * 8].reshape(E, 8)[:, :5].astype(np.float64)
     tot = ph.sum(1).mean()
     for k in range(5): print(f"{names[k]:38s} {ph[:, k].mean():10.0f} ticks  {100 * ph[:, k].mean() / tot:5.1f} %")
-    print(f"wave lifetime {tot:.0f} ticks")
+    life = ph.sum(1)
+    print(f"wave lifetime {tot:.0f} ticks mean, p90 {np.percentile(life, 90):.0f}, p99 {np.percentile(life, 99):.0f}, max {life.max():.0f}")
+    n = ctx.lattice_debug_queue(E)
+    for lo, hi in ((1, 1), (2, 4), (5, 64), (65, 100000)):
+        m = (n >= lo) & (n <= hi)
+        if m.any(): print(f"   egos with {lo}..{hi} entries: {m.sum():5d}  lifetime mean {life[m].mean():8.0f}  max {life[m].max():8.0f}   first phase mean {ph[m, 0].mean():8.0f}")
