@@ -29,4 +29,8 @@ with Context(0) as ctx:
     for k, nm in enumerate(["look-ahead: rows arrive", "look-ahead: brackets + pair compaction", "look-ahead: exact tests", "look-ahead: centres"]): print(f"   {nm:40s} {la[:, k].mean():8.0f} (max {la[:, k].max():.0f})")
     slow = ph[:, 3] > 2 * np.median(ph[:, 3])
     print(f"slow look-ahead waves: {slow.mean() * 100:.1f} %; of those: general scans mean {st[slow, 0].mean():.2f}, fast {st[slow, 1].mean() * 100:.0f} %")
-    print(f"wave lifetime {tot:.0f} ticks mean, {ph.sum(1).max():.0f} max; start-time spread {np.ptp(t0):.0f} ticks (mod 2^24)")
+    life = ph.sum(1)
+    print(f"wave lifetime {tot:.0f} ticks mean, p90 {np.percentile(life, 90):.0f}, p99 {np.percentile(life, 99):.0f}, {life.max():.0f} max")
+    worst = np.argsort(life)[-8:]
+    print("the eight slowest waves, per phase:")
+    for w in worst: print("   ", [int(v) for v in ph[w]], int(life[w]))
