@@ -71,14 +71,16 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 struct SrcStream {
     const float* __restrict__ ce;
     int R;
+    static constexpr bool whole_chunks = false;   // the filter keeps its step-by-step blocks: 24 loads of a chunk in flight leave no registers for a six-step block (66 VGPR spills, 0.039 -> 0.045 ms)
     __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
         a = ce[((size_t)t * 2 + 0) * R + r];
         d = ce[((size_t)t * 2 + 1) * R + r];
     }
-    // steps te and te + 1 (te even); the tail re-reads the last step (unused)
+    // steps te and te + 1 (te even); the tail re-reads the last step (unused).  FULL: the caller guarantees te + 1 < T
+    template <bool FULL = false>
     __device__ __forceinline__ void get2(int te, int T, int r, float& a0, float& d0, float& a1, float& d1) const {
-        get(te < T ? te : T - 1, r, a0, d0);
-        get(te + 1 < T ? te + 1 : T - 1, r, a1, d1);
+        get(FULL || te < T ? te : T - 1, r, a0, d0);
+        get(FULL || te + 1 < T ? te + 1 : T - 1, r, a1, d1);
     }
 };
 
@@ -99,14 +101,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-struct SrcGen {
+// WARM_SET: `warm` is never null (k_kmpc_plan_gen's LDS copy, zero-filled without a warm start) -- no null test, hence no branch
+// around each of the filter's warm-start reads (each one used to end a basic block, and with it the scheduler's view)
+template <bool WARM_SET>
+struct SrcGenT {
     uint32_t k0, k1, call, ego;
     float sig_a, sig_d;
     const float* warm;          // [T][2] (accel, steer) of this ego, LDS or global; nullptr = no warm start (zeros)
+    static constexpr bool whole_chunks = true;
     __device__ __forceinline__ void one(int t, int r, uint32_t xa, uint32_t xd, float& a, float& d) const {
         const float za = ((float)(int)__builtin_amdgcn_sad_u8(xa, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;   // sum of the word's 4 bytes
         const float zd = ((float)(int)__builtin_amdgcn_sad_u8(xd, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;
-        const float wa = warm ? warm[2 * t] : 0.0f, wd = warm ? warm[2 * t + 1] : 0.0f;
+        const float wa = WARM_SET || warm ? warm[2 * t] : 0.0f, wd = WARM_SET || warm ? warm[2 * t + 1] : 0.0f;
         // rollout 0 = the warm start itself, rollout 1 = all zero, as per-lane FACTORS instead of two compares + two selects per
         // control (r is fixed per lane for the whole rollout, so the factors fold into loop-invariant registers): sigma -> 0 for
         // r < 2, warm -> 0 for r = 1.  fma(0, z, w) = w and fma(0, z, w * 0) = +-0 exactly: the same controls, bit for bit in value.
@@ -119,15 +125,17 @@ struct SrcGen {
         philox4x32_10((uint32_t)(t >> 1), (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
         one(t, r, (t & 1) ? x2 : x0, (t & 1) ? x3 : x1, a, d);
     }
-    // steps te and te + 1 (te even) from ONE Philox call; steps >= T are generated like any other (and unused)
+    // steps te and te + 1 (te even) from ONE Philox call; steps >= T are generated like any other (and unused).  FULL: te + 1 < T
+    template <bool FULL = false>
     __device__ __forceinline__ void get2(int te, int T, int r, float& a0, float& d0, float& a1, float& d1) const {
         uint32_t x0, x1, x2, x3;
         philox4x32_10((uint32_t)(te >> 1), (uint32_t)r, ego, call, k0, k1, x0, x1, x2, x3);
-        const int tb = te + 1 < T ? te + 1 : te;                      // warm[] has T rows
-        one(te < T ? te : T - 1, r, x0, x1, a0, d0);
-        one(tb < T ? tb : T - 1, r, x2, x3, a1, d1);
+        const int tb = FULL || te + 1 < T ? te + 1 : te;              // warm[] has T rows
+        one(FULL || te < T ? te : T - 1, r, x0, x1, a0, d0);
+        one(FULL || tb < T ? tb : T - 1, r, x2, x3, a1, d1);
     }
 };
+typedef SrcGenT<false> SrcGen;
 
 // fp64 cost of ONE rollout r: running sum in the reference's accumulation order
 template <bool FAST, typename Src>
@@ -201,31 +209,35 @@ __device__ __forceinline__ f1p_f2 med3x2(f1p_f2 x, float lo, float hi) {
 }
 struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd; };
 
-template <typename Src>
+template <bool FULL, typename Src>
 __device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, int r1, int t0,
                                                  f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
     static_assert(F1P_K4_CHUNK2 % 2 == 0, "the chunk is loaded in pairs of steps");
 #pragma unroll
     for (int j = 0; j < F1P_K4_CHUNK2; j += 2) {
         float a00, d00, a01, d01, a10, d10, a11, d11;
-        src.get2(t0 + j, T, r0, a00, d00, a01, d01);                   // t0 is a multiple of the (even) chunk size
-        src.get2(t0 + j, T, r1, a10, d10, a11, d11);
+        src.template get2<FULL>(t0 + j, T, r0, a00, d00, a01, d01);    // t0 is a multiple of the (even) chunk size
+        src.template get2<FULL>(t0 + j, T, r1, a10, d10, a11, d11);
         av[j].x = a00; av[j].y = a10; dv[j].x = d00; dv[j].y = d10;
         av[j + 1].x = a01; av[j + 1].y = a11; dv[j + 1].x = d01; dv[j + 1].y = d11;
     }
 }
 
-template <bool POLY>
+// FULL: the whole chunk lies inside the horizon (no per-step `t < T` branch: the chunk is ONE basic block, so the compiler schedules
+// the six steps, their LDS reads and the chunk's Philox calls against each other instead of step by step); FIRST: t0 == 0 (the only
+// chunk with a step that has no predecessor)
+template <bool POLY, bool FULL, bool FIRST>
 __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, const KmpcF32& k, int T, int t0,
                                             const f1p_f2 (&av)[F1P_K4_CHUNK2], const f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
 #pragma clang fp contract(fast)
 #pragma unroll
     for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
-        const int t = t0 + j;
-        if (t < T) {
+        const int t = FIRST ? j : t0 + j;
+        const bool has_prev = FIRST ? j > 0 : (FULL ? true : t > 0);       // (FULL, !FIRST: t0 >= one chunk)
+        if (FULL || t < T) {
             const f1p_f2 a = med3x2(av[j], -k.max_accel, k.max_accel);
             f1p_f2 d = med3x2(dv[j], -k.max_steer, k.max_steer);
-            if (t > 0) {
+            if (has_prev) {
                 const f1p_f2 lo = s.pd - k.dmax, hi = s.pd + k.dmax;
                 d.x = __builtin_amdgcn_fmed3f(d.x, lo.x, hi.x);
                 d.y = __builtin_amdgcn_fmed3f(d.y, lo.y, hi.y);
@@ -233,7 +245,7 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + t], e1 = s.y - sref32[1 * (T + 1) + t];
             const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + t], e3 = s.yaw - sref32[3 * (T + 1) + t];
             s.cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
-            if (t > 0) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
+            if (has_prev) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
             f1p_f2 cy, sy;                                             // cos / sin of the absolute heading
             {   // hardware sin / cos of the relative heading (the transcendental unit runs beside the packed FMAs: a polynomial
                 // phasor recurrence measured 4 % slower), rotated by the start heading
@@ -271,10 +283,28 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const 
                                                          int r0, int r1) {
     KmpcState2 s;
     s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f;
-    for (int t0 = 0; t0 < T; t0 += F1P_K4_CHUNK2) {
+    int t0 = 0;
+    if (Src::whole_chunks && T >= F1P_K4_CHUNK2) {                     // the first chunk, whole
         f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
-        kmpc_load_chunk2(src, T, r0, r1, t0, a0, d0);
-        kmpc_steps2<POLY>(s, sref32, k, T, t0, a0, d0);
+        kmpc_load_chunk2<true>(src, T, r0, r1, 0, a0, d0);
+        kmpc_steps2<POLY, true, true>(s, sref32, k, T, 0, a0, d0);
+        t0 = F1P_K4_CHUNK2;
+        for (; t0 + F1P_K4_CHUNK2 <= T; t0 += F1P_K4_CHUNK2) {         // whole chunks
+            kmpc_load_chunk2<true>(src, T, r0, r1, t0, a0, d0);
+            kmpc_steps2<POLY, true, false>(s, sref32, k, T, t0, a0, d0);
+        }
+    }
+    if (!Src::whole_chunks) {
+        for (; t0 < T; t0 += F1P_K4_CHUNK2) {
+            f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
+            kmpc_load_chunk2<false>(src, T, r0, r1, t0, a0, d0);
+            kmpc_steps2<POLY, false, false>(s, sref32, k, T, t0, a0, d0);
+        }
+    } else if (t0 < T) {                                               // the remainder (or a horizon shorter than one chunk), step by step
+        f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
+        kmpc_load_chunk2<false>(src, T, r0, r1, t0, a0, d0);
+        if (t0 == 0) kmpc_steps2<POLY, false, true>(s, sref32, k, T, 0, a0, d0);
+        else kmpc_steps2<POLY, false, false>(s, sref32, k, T, t0, a0, d0);
     }
     const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + T], e1 = s.y - sref32[1 * (T + 1) + T];
     const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + T], e3 = s.yaw - sref32[3 * (T + 1) + T];
@@ -634,9 +664,18 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     float* c32 = reinterpret_cast<float*>(sref + 4 * (T + 1) + 4 + 2);   // [R] filter costs (G == 1: LDS only)
     const int e = blockIdx.x / ga.G, g = blockIdx.x - e * ga.G;
     if (e >= E) return;
+#ifdef F1P_K4_PHASES     // shader-clock stamps at the phase boundaries -> n_refined-shaped debug rows in ga.cost32 (tools/kmpc_phases.py)
+    long long tph[8]; int nph = 0;
+#define F1P_KPH() do { tph[nph++] = clock64(); } while (0)
+#define F1P_KPH_OUT() do { F1P_KPH(); if (tid == 0 && ga.cost32 && ga.G == 1) { for (int k_ = 0; k_ + 1 < nph; ++k_) ga.cost32[(size_t)e * R + k_] = (float)(tph[k_ + 1] - tph[k_]); ga.cost32[(size_t)e * R + 7] = (float)(tph[0] & 0xffffff); ga.cost32[(size_t)e * R + 8] = (float)(tph[nph - 1] & 0xffffff); } if (lane == 0 && ga.cost32 && ga.G == 1) { ga.cost32[(size_t)e * R + 10 + wave] = (float)(__builtin_amdgcn_s_getreg(63492) & 0xffff); ga.cost32[(size_t)e * R + 14 + wave] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf); ga.cost32[(size_t)e * R + 18 + wave] = (float)(clock64() - tph[0]); } } while (0)
+#else
+#define F1P_KPH() do {} while (0)
+#define F1P_KPH_OUT() do {} while (0)
+#endif
+    F1P_KPH();
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
     for (int q = tid; q < 2 * T; q += blockDim.x) warm_s[q] = ga.warm_in ? ga.warm_in[(size_t)e * 2 * T + q] : 0.0f;
-    SrcGen src;
+    SrcGenT<true> src;
     src.k0 = ga.k0; src.k1 = ga.k1; src.call = ga.call; src.ego = (uint32_t)e; src.sig_a = ga.sig_a; src.sig_d = ga.sig_d;
     src.warm = warm_s;
     float* warm_out = ga.warm_out ? ga.warm_out + (size_t)e * 2 * T : nullptr;
@@ -655,6 +694,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
     k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
 
+    F1P_KPH();
     // ---- pass A: f32 filter over this workgroup's slice ---------------------------------------------------------------
     const int r_lo = g * ga.Rs, r_hi = min(R, r_lo + ga.Rs);
     float* cost_out = ga.G > 1 ? ga.cost32 + (size_t)e * R : c32;
@@ -666,9 +706,12 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
             const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(src, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(src, sref32, k, T, r, r1);
             cost_out[r] = c.x;
             if (r1 != r) cost_out[r1] = c.y;
+#ifndef F1P_K4_PHASES
             if (ga.G == 1 && ga.cost32) { ga.cost32[(size_t)e * R + r] = c.x; if (r1 != r) ga.cost32[(size_t)e * R + r1] = c.y; }
+#endif
         }
     }
+    F1P_KPH();
     if (ga.G > 1) {
         __threadfence();                                              // this workgroup's costs are visible device-wide ...
         __syncthreads();
@@ -684,6 +727,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
         __syncthreads();
     }
 
+    F1P_KPH();
     // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
     if (!in_range) {
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
@@ -714,6 +758,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     }
     __syncthreads();
     const int n = cnt[0];
+    F1P_KPH();
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
     } else if (n == 1 && !best_cost) {
@@ -724,6 +769,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
         // the survivors in ascending rollout order: the atomic list is in arrival order, the decision (first minimum) is by index
         kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
     }
+    F1P_KPH_OUT();
 }
 
 // materialise SrcGen's controls as the [E][T][2][R] f32 buffer of the streamed entry points (tests: generated == streamed)
