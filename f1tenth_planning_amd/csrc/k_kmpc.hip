@@ -110,8 +110,10 @@ struct SrcGenT {
     const float* warm;          // [T][2] (accel, steer) of this ego, LDS or global; nullptr = no warm start (zeros)
     static constexpr bool whole_chunks = true;
     __device__ __forceinline__ void one(int t, int r, uint32_t xa, uint32_t xd, float& a, float& d) const {
-        const float za = ((float)(int)__builtin_amdgcn_sad_u8(xa, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;   // sum of the word's 4 bytes
-        const float zd = ((float)(int)__builtin_amdgcn_sad_u8(xd, 0u, 0u) - F1P_IH_MEAN) * F1P_IH_INV_STD;
+        // sum of the word's 4 bytes minus 510, the mean folded into v_sad_u8's accumulator: integers of magnitude <= 510, exact in
+        // f32 either way, so (float)(sum - 510) is the same value as (float)sum - 510.0f without the v_add_f32
+        const float za = (float)(int)__builtin_amdgcn_sad_u8(xa, 0u, (uint32_t)-(int)F1P_IH_MEAN) * F1P_IH_INV_STD;
+        const float zd = (float)(int)__builtin_amdgcn_sad_u8(xd, 0u, (uint32_t)-(int)F1P_IH_MEAN) * F1P_IH_INV_STD;
         const float wa = WARM_SET || warm ? warm[2 * t] : 0.0f, wd = WARM_SET || warm ? warm[2 * t + 1] : 0.0f;
         // rollout 0 = the warm start itself, rollout 1 = all zero, as per-lane FACTORS instead of two compares + two selects per
         // control (r is fixed per lane for the whole rollout, so the factors fold into loop-invariant registers): sigma -> 0 for
@@ -388,10 +390,16 @@ __device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const doubl
     const double dc = clampd((double)df, -cfg.max_steer, cfg.max_steer);   // |delta| <= MAX_STEER  :401
     d = dc;
     if (!COST) {
-        for (int s = 1; s < T; ++s) {                                  // |d delta| <= MAX_DSTEER*DTK :391-394
+        // |d delta| <= MAX_DSTEER*DTK :391-394.  The sweeps stop at the first one that changes no lane: every lane then satisfies
+        // d_j = clamp(dc_j, d_{j-1} -+ dmax) at once, which is the sequential result (a rate-limited run is a few steps long, so
+        // this is a handful of sweeps instead of T - 1 at the tail of every workgroup).  One whole wave calls this (kmpc_emit_wave).
+        for (int s = 1; s < T; ++s) {
             const double pd = lane_up1(d);
             const double dn = clampd(dc, pd - dmax, pd + dmax);
-            d = first ? dc : dn;
+            const double d1 = first ? dc : dn;
+            const bool moved = j < T && d1 != d;
+            d = d1;
+            if (!__any(moved)) break;
         }
         return 0.0;
     }
@@ -502,12 +510,14 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
                                                   double sx, double sy, double sv, double syaw, int e, int n, const int* list, double* sref,
                                                   double* __restrict__ steer, double* __restrict__ speed, int32_t* __restrict__ best_idx,
                                                   double* __restrict__ best_cost, double* __restrict__ best_seq, int32_t* __restrict__ n_refined,
-                                                  float* __restrict__ warm_out = nullptr) {
+                                                  float* __restrict__ warm_out = nullptr, bool sref_ready = false) {
     const int T = cfg.horizon, tid = threadIdx.x;
     double* red_d = sref + 4 * (T + 1);
     int* red_i = reinterpret_cast<int*>(red_d + 4);
-    for (int q = tid; q < 4 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 4 * (T + 1) + q];
-    __syncthreads();
+    if (!sref_ready) {                                                 // (k_kmpc_plan_gen fills sref with the rest of its setup)
+        for (int q = tid; q < 4 * (T + 1); q += blockDim.x) sref[q] = ref[(size_t)e * 4 * (T + 1) + q];
+        __syncthreads();
+    }
     const double dmax = cfg.max_dsteer * cfg.dt;
     double bc = __builtin_huge_val(); int bi = 0x7fffffff;
     const int GL = kmpc_lane_group(T);
@@ -568,6 +578,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     }
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
+        sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
         const int row = q / (T + 1);
         sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, then rounded
     }
@@ -614,13 +625,13 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     __syncthreads();
     const int n = *cnt;
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
-        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
+        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, nullptr, true);
     } else if (n == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
         kmpc_emit_wave(ce, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, nullptr);
         if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
-        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
+        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, nullptr, true);
     }
 }
 
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4;     // workgroup-uniform: the fast paths' ranges
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
+        sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
         const int row = q / (T + 1);
         sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));
     }
@@ -698,6 +710,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     // ---- pass A: f32 filter over this workgroup's slice ---------------------------------------------------------------
     const int r_lo = g * ga.Rs, r_hi = min(R, r_lo + ga.Rs);
     float* cost_out = ga.G > 1 ? ga.cost32 + (size_t)e * R : c32;
+    float fmin_ = __builtin_huge_valf();                              // G == 1: this thread's minimum, straight from the filter's registers
     if (in_range) {
         const bool poly = k.max_steer <= 0.45f;
         const int half = (r_hi - r_lo + 1) >> 1;                      // rollouts r and r + half share the packed lanes
@@ -706,6 +719,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
             const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(src, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(src, sref32, k, T, r, r1);
             cost_out[r] = c.x;
             if (r1 != r) cost_out[r1] = c.y;
+            fmin_ = fminf(fmin_, fminf(c.x, c.y));                     // NaN costs are ignored here and caught below (r1 == r: c.y repeats c.x)
 #ifndef F1P_K4_PHASES
             if (ga.G == 1 && ga.cost32) { ga.cost32[(size_t)e * R + r] = c.x; if (r1 != r) ga.cost32[(size_t)e * R + r1] = c.y; }
 #endif
@@ -730,15 +744,13 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     F1P_KPH();
     // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
     if (!in_range) {
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
         return;
     }
-    float fmin_ = __builtin_huge_valf();
-    for (int r = tid; r < R; r += blockDim.x) {
-        float c;
-        if (ga.G > 1) c = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        else c = cost_out[r];
-        fmin_ = fminf(fmin_, c);                                      // NaN costs are ignored here and caught below
+    if (ga.G > 1) {
+        fmin_ = __builtin_huge_valf();
+        for (int r = tid; r < R; r += blockDim.x)
+            fmin_ = fminf(fmin_, __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
@@ -760,14 +772,14 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     const int n = cnt[0];
     F1P_KPH();
     if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
     } else if (n == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
         kmpc_emit_wave(src, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
         if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
         // the survivors in ascending rollout order: the atomic list is in arrival order, the decision (first minimum) is by index
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out);
+        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
     }
     F1P_KPH_OUT();
 }
