@@ -370,6 +370,12 @@ __device__ __forceinline__ void kmpc_emit(const Src& src, const f1p_kmpc_cfg& cf
 // outputs are bit-identical; ~1 700 wave instructions instead of ~10 500 for T = 30 (the single-lane tail was half of the
 // generated-controls kernel: 91 -> 52 us at 1024 egos).
 // ---------------------------------------------------------------------------------------------------
+#ifdef F1P_K4_PHASES
+__shared__ long long f1p_kst[16];
+#define F1P_KST(i) do { if (threadIdx.x == 0) f1p_kst[i] = clock64(); } while (0)
+#else
+#define F1P_KST(i) do {} while (0)
+#endif
 __device__ __forceinline__ double lane_up1(double v) {                // lane i <- lane i - 1 of the wave; lane 0 keeps its own
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -403,18 +409,22 @@ __device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const doubl
         }
         return 0.0;
     }
+    F1P_KST(1);
     // ---- chains 1: steering rate limit, speed ------------------------------------------------------------------------------
     const double vinc = lane_up1(a * cfg.dt);                          // lane j: a_{j-1} DTK
     double v = sv;
+    // A group's first lane keeps (dc, sv) through PER-LANE BOUNDS instead of a select behind every sweep's result (two v_cndmask on each
+    // chain's critical path): its rate limit is infinite -- dc > +inf and dc < -inf are false (as are comparisons with the NaN of
+    // inf - inf), so clampd returns dc -- and its speed bounds are both sv, so whatever finite sum reaches it comes out as sv.
+    const double dm = first ? __builtin_huge_val() : dmax;
+    const double v_lo = first ? sv : cfg.min_speed, v_hi = first ? sv : cfg.max_speed;
     for (int s = 1; s <= T; ++s) {
         const double pd = lane_up1(d), pv = lane_up1(v);
-        const double dn = clampd(dc, pd - dmax, pd + dmax);
-        double vn = pv + vinc;                                         // :236
-        if (vn > cfg.max_speed) vn = cfg.max_speed;                    // :238-241
-        else if (vn < cfg.min_speed) vn = cfg.min_speed;
-        d = first ? dc : dn;
-        v = first ? sv : vn;
+        d = clampd(dc, pd - dm, pd + dm);
+        const double vn = pv + vinc;                                   // :236
+        v = vn > v_hi ? v_hi : (vn < v_lo ? v_lo : vn);                // :238-241
     }
+    F1P_KST(2);
     // ---- chain 2: heading --------------------------------------------------------------------------------------------------
     double dl = d;
     if (dl >= cfg.max_steer) dl = cfg.max_steer;                       // :226-229
@@ -423,23 +433,27 @@ __device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const doubl
     sincos_core(dl, &sd, &cd);
     const double tn = sd / cd;
     const double yinc = lane_up1((v / cfg.wheelbase) * tn * cfg.dt);   // :233-235
+    F1P_KST(3);
     double yaw = syaw;
     for (int s = 1; s <= T; ++s) {
         const double py = lane_up1(yaw);
         const double yn = py + yinc;
         yaw = first ? syaw : yn;
     }
+    F1P_KST(4);
     // ---- chains 3: position ------------------------------------------------------------------------------------------------
     double sn, cs;
     sincos_core(yaw, &sn, &cs);
     const double xinc = lane_up1(v * cs * cfg.dt), yyinc = lane_up1(v * sn * cfg.dt);   // :231-232
     double x = sx, y = sy;
+    F1P_KST(5);
     for (int s = 1; s <= T; ++s) {
         const double px = lane_up1(x), py = lane_up1(y);
         const double xn = px + xinc, yn = py + yyinc;
         x = first ? sx : xn;
         y = first ? sy : yn;
     }
+    F1P_KST(6);
     // ---- stage terms (all lanes), then the cost in the reference's accumulation order -----------------------------------------
     const int jj = j < T ? j : T;
     const bool last = j >= T;
@@ -452,14 +466,18 @@ __device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const doubl
     const double Cc = cfg.rd[0] * da * da + cfg.rd[1] * dd * dd;                         // :334
     const bool mid = !first && !last;
     double cost = 0.0;
+    F1P_KST(7);
+    // The terms a lane does not have enter as +0.0 instead of being selected around: c + 0.0 == c bit for bit unless c is -0.0, and
+    // the running sum never is (it starts from +0.0, and +0.0 + x is -0.0 for no x); a NaN stays that NaN.  The first lane's
+    // predecessor is masked to +0.0 by two v_and (the reference's `0.0 + A`).
+    const double Bz = last ? 0.0 : B, Cz = mid ? Cc : 0.0;
+    const int keep = first ? 0 : -1;
     for (int s = 0; s <= T; ++s) {
         const double pc = lane_up1(cost);
-        const double c1 = (first ? 0.0 : pc) + A;
-        const double c2 = c1 + B;
-        const double c2s = last ? c1 : c2;
-        const double c3 = c2s + Cc;
-        cost = mid ? c3 : c2s;
+        const double pc0 = __hiloint2double(__double2hiint(pc) & keep, __double2loint(pc) & keep);
+        cost = ((pc0 + A) + Bz) + Cz;
     }
+    F1P_KST(8);
     return cost;
 }
 
@@ -526,13 +544,20 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
         const int gid = tid / GL, j = tid - gid * GL;
         double a = 0.0, d = 0.0;
         int mine = -1;
+        F1P_KST(0);
+        const bool one_wave = n * GL <= 64;                           // every survivor's group sits in the first wave: the others have
+        if (one_wave && tid >= 64) return;                            // nothing to add, and the argmin needs no barrier (no LDS round trip)
         if (gid < n) {
             mine = list[gid];
             const double c = kmpc_rollout_lanes<true>(ce, sref, cfg, sx, sy, sv, syaw, dmax, mine, j, a, d);
             if (j == T) { bc = c; bi = mine; }
         }
-        block_argmin(bc, bi, red_d, red_i);
+        F1P_KST(9);
+        if (one_wave) wave_argmin_dpp(bc, bi);
+        else block_argmin(bc, bi, red_d, red_i);
+        F1P_KST(10);
         if (mine == bi) kmpc_emit_lanes(cfg, sv, e, j, a, d, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
+        F1P_KST(11);
         if (tid == 0 && n_refined) n_refined[e] = n;
         return;
     }
@@ -678,7 +703,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
 #ifdef F1P_K4_PHASES     // shader-clock stamps at the phase boundaries -> n_refined-shaped debug rows in ga.cost32 (tools/kmpc_phases.py)
     long long tph[8]; int nph = 0;
 #define F1P_KPH() do { tph[nph++] = clock64(); } while (0)
-#define F1P_KPH_OUT() do { F1P_KPH(); if (tid == 0 && ga.cost32 && ga.G == 1) { for (int k_ = 0; k_ + 1 < nph; ++k_) ga.cost32[(size_t)e * R + k_] = (float)(tph[k_ + 1] - tph[k_]); ga.cost32[(size_t)e * R + 7] = (float)(tph[0] & 0xffffff); ga.cost32[(size_t)e * R + 8] = (float)(tph[nph - 1] & 0xffffff); } if (lane == 0 && ga.cost32 && ga.G == 1) { ga.cost32[(size_t)e * R + 10 + wave] = (float)(__builtin_amdgcn_s_getreg(63492) & 0xffff); ga.cost32[(size_t)e * R + 14 + wave] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf); ga.cost32[(size_t)e * R + 18 + wave] = (float)(clock64() - tph[0]); } } while (0)
+#define F1P_KPH_OUT() do { F1P_KPH(); if (tid == 0 && ga.cost32 && ga.G == 1) { for (int k_ = 0; k_ + 1 < nph; ++k_) ga.cost32[(size_t)e * R + k_] = (float)(tph[k_ + 1] - tph[k_]); ga.cost32[(size_t)e * R + 7] = (float)(tph[0] & 0xffffff); ga.cost32[(size_t)e * R + 8] = (float)(tph[nph - 1] & 0xffffff); for (int k_ = 0; k_ < 11; ++k_) ga.cost32[(size_t)e * R + 24 + k_] = (float)(f1p_kst[k_ + 1] - f1p_kst[k_]); ga.cost32[(size_t)e * R + 35] = (float)(f1p_kst[0] - tph[nph - 2]); } if (lane == 0 && ga.cost32 && ga.G == 1) { ga.cost32[(size_t)e * R + 10 + wave] = (float)(__builtin_amdgcn_s_getreg(63492) & 0xffff); ga.cost32[(size_t)e * R + 14 + wave] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf); ga.cost32[(size_t)e * R + 18 + wave] = (float)(clock64() - tph[0]); } } while (0)
 #else
 #define F1P_KPH() do {} while (0)
 #define F1P_KPH_OUT() do {} while (0)

@@ -24,7 +24,7 @@ with Context(0) as ctx:
     ctx.kmpc_warm_reset()
     for call in range(12): ctx.kmpc_plan_dev(d_x0, d_ref, E, cfg, _abi.kmpc_sampler(seed=1, call=call, use_warm=True), *d)
     ctx.sync()
-    ph = d_c.download(np.float32, (E, R))[:, :24].astype(np.float64); nr = d_nr.download(np.int32, (E,))
+    ph = d_c.download(np.float32, (E, R))[:, :40].astype(np.float64); nr = d_nr.download(np.int32, (E,))
     life = ph[:, :5].sum(1); tot = life.mean()
     for j in range(5): print(f"{names[j]:52s} {ph[:, j].mean():9.0f} ticks  {100 * ph[:, j].mean() / tot:5.1f} %   max {ph[:, j].max():9.0f}")
     print(f"workgroup lifetime {tot:.0f} ticks mean, p90 {np.percentile(life, 90):.0f}, p99 {np.percentile(life, 99):.0f}, max {life.max():.0f}")
@@ -46,3 +46,9 @@ with Context(0) as ctx:
     wl_simd = np.array([load[(cuid[i, w], simd[i, w])] for i in range(E) for w in range(4)]); wlf = wl.reshape(-1)
     for n_ in np.unique(wl_simd): print(f"      waves on a SIMD with {n_} waves: {int((wl_simd == n_).sum()):5d}  wave lifetime mean {wlf[wl_simd == n_].mean():8.0f}  max {wlf[wl_simd == n_].max():8.0f}")
     print("   lifetime histogram (ticks/1000):", np.histogram(life / 1000, bins=[0, 40, 50, 60, 70, 80, 90, 100, 110, 120, 200])[0])
+    m = nr >= 2
+    if m.any():
+        rn = ["entry -> lanes path", "Philox + clamps", "sweeps: rate limit + speed", "tan (fp64 sincos)", "sweeps: heading", "sincos of the heading", "sweeps: position", "stage terms", "sweeps: cost", "(return)", "block argmin", "emit"]
+        print("   refining workgroups (thread 0's clock):")
+        print(f"      {rn[0]:30s} {ph[m, 35].mean():8.0f}")
+        for k_ in range(11): print(f"      {rn[k_ + 1]:30s} {ph[m, 24 + k_].mean():8.0f}")
