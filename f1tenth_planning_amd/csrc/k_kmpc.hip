@@ -71,7 +71,9 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 struct SrcStream {
     const float* __restrict__ ce;
     int R;
-    static constexpr bool whole_chunks = false;   // the filter keeps its step-by-step blocks: 24 loads of a chunk in flight leave no registers for a six-step block (66 VGPR spills, 0.039 -> 0.045 ms)
+    // steps per basic block of the f32 filter (even: loaded as pairs of steps).  Measured at 1024 egos: 0.0337 ms with 2 / 0.035 with 4 /
+    // 0.045 with 6 (24 loads in flight + a six-step block: 66 VGPR spills) / 0.036 with the step-by-step blocks of rounds 1-3
+    static constexpr int chunk = 2;
     __device__ __forceinline__ void get(int t, int r, float& a, float& d) const {
         a = ce[((size_t)t * 2 + 0) * R + r];
         d = ce[((size_t)t * 2 + 1) * R + r];
@@ -108,7 +110,7 @@ struct SrcGenT {
     uint32_t k0, k1, call, ego;
     float sig_a, sig_d;
     const float* warm;          // [T][2] (accel, steer) of this ego, LDS or global; nullptr = no warm start (zeros)
-    static constexpr bool whole_chunks = true;
+    static constexpr int chunk = 6;               // six steps (three Philox calls per rollout) per basic block: 0.0467 ms against 0.048 with 2 or 4
     __device__ __forceinline__ void one(int t, int r, uint32_t xa, uint32_t xd, float& a, float& d) const {
         // sum of the word's 4 bytes minus 510, the mean folded into v_sad_u8's accumulator: integers of magnitude <= 510, exact in
         // f32 either way, so (float)(sum - 510) is the same value as (float)sum - 510.0f without the v_add_f32
@@ -195,9 +197,6 @@ struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_a
 #ifndef F1P_K4_WAVES_FILTER
 #define F1P_K4_WAVES_FILTER 4
 #endif
-#ifndef F1P_K4_CHUNK2
-#define F1P_K4_CHUNK2 6   // time steps per register buffer of the packed filter (4 x CHUNK2 VGPRs); even: loaded as pairs of steps
-#endif
 
 // Two rollouts per thread in the lanes of packed-f32 instructions: plain f32 VALU ops issue 16 lanes per clock on CDNA4 and
 // only v_pk_{fma,mul,add}_f32 reach the 32-lane f32 rate, so the filter -- which is VALU-bound once the control stream is
@@ -213,10 +212,10 @@ struct KmpcState2 { f1p_f2 x, y, v, yaw, cost, pa, pd; };
 
 template <bool FULL, typename Src>
 __device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, int r1, int t0,
-                                                 f1p_f2 (&av)[F1P_K4_CHUNK2], f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
-    static_assert(F1P_K4_CHUNK2 % 2 == 0, "the chunk is loaded in pairs of steps");
+                                                 f1p_f2 (&av)[Src::chunk], f1p_f2 (&dv)[Src::chunk]) {
+    static_assert(Src::chunk % 2 == 0, "the chunk is loaded in pairs of steps");
 #pragma unroll
-    for (int j = 0; j < F1P_K4_CHUNK2; j += 2) {
+    for (int j = 0; j < Src::chunk; j += 2) {
         float a00, d00, a01, d01, a10, d10, a11, d11;
         src.template get2<FULL>(t0 + j, T, r0, a00, d00, a01, d01);    // t0 is a multiple of the (even) chunk size
         src.template get2<FULL>(t0 + j, T, r1, a10, d10, a11, d11);
@@ -228,12 +227,12 @@ __device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, 
 // FULL: the whole chunk lies inside the horizon (no per-step `t < T` branch: the chunk is ONE basic block, so the compiler schedules
 // the six steps, their LDS reads and the chunk's Philox calls against each other instead of step by step); FIRST: t0 == 0 (the only
 // chunk with a step that has no predecessor)
-template <bool POLY, bool FULL, bool FIRST>
+template <bool POLY, bool FULL, bool FIRST, int CH>
 __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, const KmpcF32& k, int T, int t0,
-                                            const f1p_f2 (&av)[F1P_K4_CHUNK2], const f1p_f2 (&dv)[F1P_K4_CHUNK2]) {
+                                            const f1p_f2 (&av)[CH], const f1p_f2 (&dv)[CH]) {
 #pragma clang fp contract(fast)
 #pragma unroll
-    for (int j = 0; j < F1P_K4_CHUNK2; ++j) {
+    for (int j = 0; j < CH; ++j) {
         const int t = FIRST ? j : t0 + j;
         const bool has_prev = FIRST ? j > 0 : (FULL ? true : t > 0);       // (FULL, !FIRST: t0 >= one chunk)
         if (FULL || t < T) {
@@ -279,34 +278,30 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
 // POLY: tan of the clamped steering angle by its Taylor polynomial (|d| <= 0.45, checked by the caller) instead of the
 // sin / cos / rcp sequence of __tanf.  Contraction is on in the step function: this is the filter, its error budget is the
 // refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
-// The controls of F1P_K4_CHUNK2 time steps are requested up front (4 x CHUNK2 independent 256-byte wave loads in flight).
+// The controls of Src::chunk time steps are requested up front (streamed: 4 x chunk independent 256-byte wave loads in flight) and the
+// chunk's steps form one basic block (kmpc_steps2<FULL>); a horizon that is no multiple of the chunk ends step by step.
 template <bool POLY, typename Src>
 __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const float* sref32, const KmpcF32& k, int T,
                                                          int r0, int r1) {
     KmpcState2 s;
     s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f;
+    constexpr int CH = Src::chunk;
     int t0 = 0;
-    if (Src::whole_chunks && T >= F1P_K4_CHUNK2) {                     // the first chunk, whole
-        f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
+    if (T >= CH) {                                                     // the first chunk, whole
+        f1p_f2 a0[CH], d0[CH];
         kmpc_load_chunk2<true>(src, T, r0, r1, 0, a0, d0);
-        kmpc_steps2<POLY, true, true>(s, sref32, k, T, 0, a0, d0);
-        t0 = F1P_K4_CHUNK2;
-        for (; t0 + F1P_K4_CHUNK2 <= T; t0 += F1P_K4_CHUNK2) {         // whole chunks
+        kmpc_steps2<POLY, true, true, CH>(s, sref32, k, T, 0, a0, d0);
+        t0 = CH;
+        for (; t0 + CH <= T; t0 += CH) {                               // whole chunks
             kmpc_load_chunk2<true>(src, T, r0, r1, t0, a0, d0);
-            kmpc_steps2<POLY, true, false>(s, sref32, k, T, t0, a0, d0);
+            kmpc_steps2<POLY, true, false, CH>(s, sref32, k, T, t0, a0, d0);
         }
     }
-    if (!Src::whole_chunks) {
-        for (; t0 < T; t0 += F1P_K4_CHUNK2) {
-            f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
-            kmpc_load_chunk2<false>(src, T, r0, r1, t0, a0, d0);
-            kmpc_steps2<POLY, false, false>(s, sref32, k, T, t0, a0, d0);
-        }
-    } else if (t0 < T) {                                               // the remainder (or a horizon shorter than one chunk), step by step
-        f1p_f2 a0[F1P_K4_CHUNK2], d0[F1P_K4_CHUNK2];
+    if (t0 < T) {                                               // the remainder (or a horizon shorter than one chunk), step by step
+        f1p_f2 a0[CH], d0[CH];
         kmpc_load_chunk2<false>(src, T, r0, r1, t0, a0, d0);
-        if (t0 == 0) kmpc_steps2<POLY, false, true>(s, sref32, k, T, 0, a0, d0);
-        else kmpc_steps2<POLY, false, false>(s, sref32, k, T, t0, a0, d0);
+        if (t0 == 0) kmpc_steps2<POLY, false, true, CH>(s, sref32, k, T, 0, a0, d0);
+        else kmpc_steps2<POLY, false, false, CH>(s, sref32, k, T, t0, a0, d0);
     }
     const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + T], e1 = s.y - sref32[1 * (T + 1) + T];
     const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + T], e3 = s.yaw - sref32[3 * (T + 1) + T];
