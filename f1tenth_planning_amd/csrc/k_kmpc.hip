@@ -192,7 +192,15 @@ __device__ __forceinline__ void kmpc_rollouts(const Src& src, const double* sref
 // half the margin (measured at T = 30: f32 error = 2.5 % of the margin of 1e-4 relative + 0.02 absolute; tests/test_gpu_kmpc.py
 // checks both the error against the margin and the bit-identity of the results with the plain fp64 kernel).
 // ---------------------------------------------------------------------------------------------------
-struct KmpcF32 { float q[4], qf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; };
+// sq / sqf: square roots of the stage / terminal state weights (f32).  The filter's reference rows hold -sq[i] * ref_i (the fp64 product of
+// the ROUNDED root and the relative reference, so both halves of the error carry the same scale), and a state term is
+// e = fma(sq[i], s_i, row_i[t]); cost = fma(e, e, cost): two packed instructions instead of subtract, multiply, fma.  w_ok: every
+// weight is >= 0 (a negative one has no root: such a configuration takes the all-fp64 path).
+struct KmpcF32 { float sq[4], sqf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; int w_ok; };
+// one entry of the filter's reference rows: row i of [4][T+1], column t (t == T: the terminal weights)
+__device__ __forceinline__ float kmpc_ref32(const KmpcF32& kf, int row, bool terminal, double rel) {
+    return (float)(-(double)(terminal ? kf.sqf[row] : kf.sq[row]) * rel);
+}
 
 #ifndef F1P_K4_WAVES_FILTER
 #define F1P_K4_WAVES_FILTER 4
@@ -243,9 +251,9 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
                 d.x = __builtin_amdgcn_fmed3f(d.x, lo.x, hi.x);
                 d.y = __builtin_amdgcn_fmed3f(d.y, lo.y, hi.y);
             }
-            const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + t], e1 = s.y - sref32[1 * (T + 1) + t];
-            const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + t], e3 = s.yaw - sref32[3 * (T + 1) + t];
-            s.cost += k.q[0] * e0 * e0 + k.q[1] * e1 * e1 + k.q[2] * e2 * e2 + k.q[3] * e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
+            const f1p_f2 e0 = k.sq[0] * s.x + sref32[0 * (T + 1) + t], e1 = k.sq[1] * s.y + sref32[1 * (T + 1) + t];   // sqrt(q_i) (s_i - ref_i)
+            const f1p_f2 e2 = k.sq[2] * s.v + sref32[2 * (T + 1) + t], e3 = k.sq[3] * s.yaw + sref32[3 * (T + 1) + t];
+            s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
             if (has_prev) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
             f1p_f2 cy, sy;                                             // cos / sin of the absolute heading
             {   // hardware sin / cos of the relative heading (the transcendental unit runs beside the packed FMAs: a polynomial
@@ -303,9 +311,9 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const 
         if (t0 == 0) kmpc_steps2<POLY, false, true, CH>(s, sref32, k, T, 0, a0, d0);
         else kmpc_steps2<POLY, false, false, CH>(s, sref32, k, T, t0, a0, d0);
     }
-    const f1p_f2 e0 = s.x - sref32[0 * (T + 1) + T], e1 = s.y - sref32[1 * (T + 1) + T];
-    const f1p_f2 e2 = s.v - sref32[2 * (T + 1) + T], e3 = s.yaw - sref32[3 * (T + 1) + T];
-    s.cost += k.qf[0] * e0 * e0 + k.qf[1] * e1 * e1 + k.qf[2] * e2 * e2 + k.qf[3] * e3 * e3;
+    const f1p_f2 e0 = k.sqf[0] * s.x + sref32[0 * (T + 1) + T], e1 = k.sqf[1] * s.y + sref32[1 * (T + 1) + T];
+    const f1p_f2 e2 = k.sqf[2] * s.v + sref32[2 * (T + 1) + T], e3 = k.sqf[3] * s.yaw + sref32[3 * (T + 1) + T];
+    s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
     return s.cost;
 }
 
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     if (e >= E) return;
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
     const SrcStream ce{controls + (size_t)e * T * 2 * R, R};
-    if (!(fabs(syaw) <= 1.0e4) || !(fabs(cfg.max_steer) <= 1.0e4)) {  // workgroup-uniform: outside the fast paths' ranges
+    if (!(fabs(syaw) <= 1.0e4) || !(fabs(cfg.max_steer) <= 1.0e4) || !kf.w_ok) {  // workgroup-uniform: outside the fast paths' ranges
         kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
         return;
     }
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
         sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
         const int row = q / (T + 1);
-        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, then rounded
+        sref32[q] = kmpc_ref32(kf, row, q - row * (T + 1) == T, row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, scaled, then rounded
     }
     if (tid == 0) *cnt = 0;
     __syncthreads();
@@ -710,12 +718,12 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     src.k0 = ga.k0; src.k1 = ga.k1; src.call = ga.call; src.ego = (uint32_t)e; src.sig_a = ga.sig_a; src.sig_d = ga.sig_d;
     src.warm = warm_s;
     float* warm_out = ga.warm_out ? ga.warm_out + (size_t)e * 2 * T : nullptr;
-    const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4;     // workgroup-uniform: the fast paths' ranges
+    const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4 && kf.w_ok;     // workgroup-uniform: the fast paths' ranges
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
         sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
         const int row = q / (T + 1);
-        sref32[q] = (float)(row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));
+        sref32[q] = kmpc_ref32(kf, row, q - row * (T + 1) == T, row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));
     }
     if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
     __syncthreads();
@@ -999,7 +1007,11 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
 
 static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg) {
     KmpcF32 kf;
-    for (int i = 0; i < 4; ++i) { kf.q[i] = (float)cfg->q[i]; kf.qf[i] = (float)cfg->qf[i]; }
+    kf.w_ok = 1;
+    for (int i = 0; i < 4; ++i) {
+        if (!(cfg->q[i] >= 0.0) || !(cfg->qf[i] >= 0.0)) kf.w_ok = 0;
+        kf.sq[i] = kf.w_ok ? (float)std::sqrt(cfg->q[i]) : 0.f; kf.sqf[i] = kf.w_ok ? (float)std::sqrt(cfg->qf[i]) : 0.f;
+    }
     for (int i = 0; i < 2; ++i) { kf.r[i] = (float)cfg->r[i]; kf.rd[i] = (float)cfg->rd[i]; }
     kf.dt = (float)cfg->dt; kf.inv_wb_dt = (float)(cfg->dt / cfg->wheelbase); kf.max_steer = (float)cfg->max_steer;
     kf.max_accel = (float)cfg->max_accel; kf.max_speed = (float)cfg->max_speed; kf.min_speed = (float)cfg->min_speed;
