@@ -197,6 +197,15 @@ __device__ __forceinline__ void kmpc_rollouts(const Src& src, const double* sref
 // e = fma(sq[i], s_i, row_i[t]); cost = fma(e, e, cost): two packed instructions instead of subtract, multiply, fma.  w_ok: every
 // weight is >= 0 (a negative one has no root: such a configuration takes the all-fp64 path).
 struct KmpcF32 { float sq[4], sqf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; int w_ok; };
+// the reference relative to the ego state: row 0 / 1 position, 2 speed (absolute), 3 heading.  iso: positions in the EGO frame (the x / y
+// difference rotated by -yaw0, the partner coordinate fetched here); `rv` = ref_e[row][col], already loaded by the caller
+__device__ __forceinline__ double kmpc_rel_ref(const double* __restrict__ ref_e, int T, int row, int col, double rv, double sx, double sy, double syaw,
+                                               bool iso, double c0, double s0) {
+    if (row >= 2) return row == 3 ? rv - syaw : rv;
+    if (!iso) return row == 0 ? rv - sx : rv - sy;
+    const double dx = (row == 0 ? rv : ref_e[col]) - sx, dy = (row == 1 ? rv : ref_e[(T + 1) + col]) - sy;
+    return row == 0 ? c0 * dx + s0 * dy : c0 * dy - s0 * dx;
+}
 // one entry of the filter's reference rows: row i of [4][T+1], column t (t == T: the terminal weights)
 __device__ __forceinline__ float kmpc_ref32(const KmpcF32& kf, int row, bool terminal, double rel) {
     return (float)(-(double)(terminal ? kf.sqf[row] : kf.sq[row]) * rel);
@@ -235,7 +244,10 @@ __device__ __forceinline__ void kmpc_load_chunk2(const Src& src, int T, int r0, 
 // FULL: the whole chunk lies inside the horizon (no per-step `t < T` branch: the chunk is ONE basic block, so the compiler schedules
 // the six steps, their LDS reads and the chunk's Philox calls against each other instead of step by step); FIRST: t0 == 0 (the only
 // chunk with a step that has no predecessor)
-template <bool POLY, bool FULL, bool FIRST, int CH>
+// ISO: the position weights are equal (q[0] == q[1], qf[0] == qf[1]: the reference's own Q), so the filter integrates positions in the
+// EGO frame -- the caller rotated the reference rows once -- and the heading's cos / sin are used as they come (no rotation by the start
+// heading: four packed instructions per step less)
+template <bool POLY, bool ISO, bool FULL, bool FIRST, int CH>
 __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, const KmpcF32& k, int T, int t0,
                                             const f1p_f2 (&av)[CH], const f1p_f2 (&dv)[CH]) {
 #pragma clang fp contract(fast)
@@ -263,7 +275,8 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
                 __sincosf(s.yaw.y, &sn1, &cs1);
                 f1p_f2 sn, cs;
                 sn.x = sn0; sn.y = sn1; cs.x = cs0; cs.y = cs1;
-                cy = k.c0 * cs - k.s0 * sn; sy = k.s0 * cs + k.c0 * sn;
+                if (ISO) { cy = cs; sy = sn; }
+                else { cy = k.c0 * cs - k.s0 * sn; sy = k.s0 * cs + k.c0 * sn; }
             }
             const f1p_f2 vdt = s.v * k.dt;
             s.x += vdt * cy;
@@ -288,7 +301,7 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
 // refinement margin, and a*b+c as one v_pk_fma_f32 halves the instruction count.
 // The controls of Src::chunk time steps are requested up front (streamed: 4 x chunk independent 256-byte wave loads in flight) and the
 // chunk's steps form one basic block (kmpc_steps2<FULL>); a horizon that is no multiple of the chunk ends step by step.
-template <bool POLY, typename Src>
+template <bool POLY, bool ISO, typename Src>
 __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const float* sref32, const KmpcF32& k, int T,
                                                          int r0, int r1) {
     KmpcState2 s;
@@ -298,18 +311,18 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const 
     if (T >= CH) {                                                     // the first chunk, whole
         f1p_f2 a0[CH], d0[CH];
         kmpc_load_chunk2<true>(src, T, r0, r1, 0, a0, d0);
-        kmpc_steps2<POLY, true, true, CH>(s, sref32, k, T, 0, a0, d0);
+        kmpc_steps2<POLY, ISO, true, true, CH>(s, sref32, k, T, 0, a0, d0);
         t0 = CH;
         for (; t0 + CH <= T; t0 += CH) {                               // whole chunks
             kmpc_load_chunk2<true>(src, T, r0, r1, t0, a0, d0);
-            kmpc_steps2<POLY, true, false, CH>(s, sref32, k, T, t0, a0, d0);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, t0, a0, d0);
         }
     }
     if (t0 < T) {                                               // the remainder (or a horizon shorter than one chunk), step by step
         f1p_f2 a0[CH], d0[CH];
         kmpc_load_chunk2<false>(src, T, r0, r1, t0, a0, d0);
-        if (t0 == 0) kmpc_steps2<POLY, false, true, CH>(s, sref32, k, T, 0, a0, d0);
-        else kmpc_steps2<POLY, false, false, CH>(s, sref32, k, T, t0, a0, d0);
+        if (t0 == 0) kmpc_steps2<POLY, ISO, false, true, CH>(s, sref32, k, T, 0, a0, d0);
+        else kmpc_steps2<POLY, ISO, false, false, CH>(s, sref32, k, T, t0, a0, d0);
     }
     const f1p_f2 e0 = k.sqf[0] * s.x + sref32[0 * (T + 1) + T], e1 = k.sqf[1] * s.y + sref32[1 * (T + 1) + T];
     const f1p_f2 e2 = k.sqf[2] * s.v + sref32[2 * (T + 1) + T], e3 = k.sqf[3] * s.yaw + sref32[3 * (T + 1) + T];
@@ -604,29 +617,31 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
         kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
         return;
     }
+    double s0d, c0d;
+    sincos_core(syaw, &s0d, &c0d);
+    const bool poly = kf.max_steer <= 0.45f;              // polynomial tan inside its accuracy range (the reference's MAX_STEER is 0.4189)
+    const bool iso = poly && kf.sq[0] == kf.sq[1] && kf.sqf[0] == kf.sqf[1];
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
         sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
-        const int row = q / (T + 1);
-        sref32[q] = kmpc_ref32(kf, row, q - row * (T + 1) == T, row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));   // exact difference in fp64, scaled, then rounded
+        const int row = q / (T + 1), col = q - row * (T + 1);
+        sref32[q] = kmpc_ref32(kf, row, col == T, kmpc_rel_ref(ref + (size_t)e * 4 * (T + 1), T, row, col, rv, sx, sy, syaw, iso, c0d, s0d));   // fp64 difference (rotation), scaled, then rounded
     }
     if (tid == 0) *cnt = 0;
     __syncthreads();
     // the constants arrive converted from the host (kernel argument -> SGPRs); the three per-ego values are made scalar too,
     // so the filter's VGPRs hold only the two rollouts' state and the control buffers
     KmpcF32 k = kf;
-    double s0d, c0d;
-    sincos_core(syaw, &s0d, &c0d);
     k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
     k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
     k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
 
     // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
     float fmin_ = __builtin_huge_valf();
-    const bool poly = k.max_steer <= 0.45f;               // polynomial tan inside its accuracy range (the reference's MAX_STEER is 0.4189)
     for (int r = tid; r < R; r += 2 * blockDim.x) {                    // rollouts r and r + 256 share the packed lanes
         const int r1 = r + (int)blockDim.x < R ? r + (int)blockDim.x : r;
-        const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(ce, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(ce, sref32, k, T, r, r1);
+        const f1p_f2 c = iso ? kmpc_rollout_cost_f32x2<true, true>(ce, sref32, k, T, r, r1)
+                             : (poly ? kmpc_rollout_cost_f32x2<true, false>(ce, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false, false>(ce, sref32, k, T, r, r1));
         c32[r] = c.x;
         if (cost32_out) cost32_out[(size_t)e * R + r] = c.x;
         fmin_ = fminf(fmin_, c.x);                                     // NaN costs are ignored here and caught below
@@ -719,17 +734,19 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     src.warm = warm_s;
     float* warm_out = ga.warm_out ? ga.warm_out + (size_t)e * 2 * T : nullptr;
     const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4 && kf.w_ok;     // workgroup-uniform: the fast paths' ranges
+    double s0d, c0d;
+    sincos_core(in_range ? syaw : 0.0, &s0d, &c0d);
+    const bool poly = kf.max_steer <= 0.45f;
+    const bool iso = poly && kf.sq[0] == kf.sq[1] && kf.sqf[0] == kf.sqf[1];
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
         const double rv = ref[(size_t)e * 4 * (T + 1) + q];
         sref[q] = rv;                                                 // the fp64 rows the refinement reads (no second trip to memory at the kernel's tail)
-        const int row = q / (T + 1);
-        sref32[q] = kmpc_ref32(kf, row, q - row * (T + 1) == T, row == 0 ? rv - sx : (row == 1 ? rv - sy : (row == 3 ? rv - syaw : rv)));
+        const int row = q / (T + 1), col = q - row * (T + 1);
+        sref32[q] = kmpc_ref32(kf, row, col == T, kmpc_rel_ref(ref + (size_t)e * 4 * (T + 1), T, row, col, rv, sx, sy, syaw, iso, c0d, s0d));
     }
     if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
     __syncthreads();
     KmpcF32 k = kf;
-    double s0d, c0d;
-    sincos_core(in_range ? syaw : 0.0, &s0d, &c0d);
     k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
     k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
     k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
@@ -740,11 +757,11 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
     float* cost_out = ga.G > 1 ? ga.cost32 + (size_t)e * R : c32;
     float fmin_ = __builtin_huge_valf();                              // G == 1: this thread's minimum, straight from the filter's registers
     if (in_range) {
-        const bool poly = k.max_steer <= 0.45f;
         const int half = (r_hi - r_lo + 1) >> 1;                      // rollouts r and r + half share the packed lanes
         for (int q = tid; q < half; q += blockDim.x) {
             const int r = r_lo + q, r1 = r + half < r_hi ? r + half : r;
-            const f1p_f2 c = poly ? kmpc_rollout_cost_f32x2<true>(src, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false>(src, sref32, k, T, r, r1);
+            const f1p_f2 c = iso ? kmpc_rollout_cost_f32x2<true, true>(src, sref32, k, T, r, r1)
+                                 : (poly ? kmpc_rollout_cost_f32x2<true, false>(src, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false, false>(src, sref32, k, T, r, r1));
             cost_out[r] = c.x;
             if (r1 != r) cost_out[r1] = c.y;
             fmin_ = fminf(fmin_, fminf(c.x, c.y));                     // NaN costs are ignored here and caught below (r1 == r: c.y repeats c.x)
