@@ -196,12 +196,18 @@ __device__ __forceinline__ void kmpc_rollouts(const Src& src, const double* sref
 // the ROUNDED root and the relative reference, so both halves of the error carry the same scale), and a state term is
 // e = fma(sq[i], s_i, row_i[t]); cost = fma(e, e, cost): two packed instructions instead of subtract, multiply, fma.  w_ok: every
 // weight is >= 0 (a negative one has no root: such a configuration takes the all-fp64 path).
-struct KmpcF32 { float sq[4], sqf[4], r[2], rd[2], dt, inv_wb_dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; int w_ok; };
+// The heading is kept in REVOLUTIONS (what v_sin / v_cos take: no multiply by 1 / 2 pi per step): sq[3] / sqf[3] carry the 2 pi, row 3 of the
+// reference is in revolutions, tc[] = the tan polynomial's coefficients times dt / (wheelbase 2 pi) so that yaw += v * (d * P(d^2)) is the whole
+// heading update (yaw_k: the same factor for the __tanf path).
+// The control terms  sum_t r u_t^2 + sum_{t>=1} rd (u_t - u_{t-1})^2  are accumulated as  sum_t ((r + 2 rd) u_t - 2 rd u_{t-1}) u_t  with
+// (r + rd) at the first step and - rd u_last^2 after the last (three packed instructions per control and step instead of five):
+// rw = r + 2 rd, rx = -2 rd, rf = r + rd.
+struct KmpcF32 { float sq[4], sqf[4], rw[2], rx[2], rf[2], rd[2], tc[6], yaw_k, dt, max_steer, max_accel, max_speed, min_speed, dmax, c0, s0, v0; int w_ok; };
 // the reference relative to the ego state: row 0 / 1 position, 2 speed (absolute), 3 heading.  iso: positions in the EGO frame (the x / y
 // difference rotated by -yaw0, the partner coordinate fetched here); `rv` = ref_e[row][col], already loaded by the caller
 __device__ __forceinline__ double kmpc_rel_ref(const double* __restrict__ ref_e, int T, int row, int col, double rv, double sx, double sy, double syaw,
                                                bool iso, double c0, double s0) {
-    if (row >= 2) return row == 3 ? rv - syaw : rv;
+    if (row >= 2) return row == 3 ? (rv - syaw) * 0.15915494309189535 : rv;     // heading in revolutions
     if (!iso) return row == 0 ? rv - sx : rv - sy;
     const double dx = (row == 0 ? rv : ref_e[col]) - sx, dy = (row == 1 ? rv : ref_e[(T + 1) + col]) - sy;
     return row == 0 ? c0 * dx + s0 * dy : c0 * dy - s0 * dx;
@@ -265,14 +271,14 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             }
             const f1p_f2 e0 = k.sq[0] * s.x + sref32[0 * (T + 1) + t], e1 = k.sq[1] * s.y + sref32[1 * (T + 1) + t];   // sqrt(q_i) (s_i - ref_i)
             const f1p_f2 e2 = k.sq[2] * s.v + sref32[2 * (T + 1) + t], e3 = k.sq[3] * s.yaw + sref32[3 * (T + 1) + t];
-            s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 + k.r[0] * a * a + k.r[1] * d * d;
-            if (has_prev) { const f1p_f2 da = a - s.pa, dd = d - s.pd; s.cost += k.rd[0] * da * da + k.rd[1] * dd * dd; }
+            s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            if (has_prev) s.cost += (k.rw[0] * a + k.rx[0] * s.pa) * a + (k.rw[1] * d + k.rx[1] * s.pd) * d;
+            else s.cost += k.rf[0] * a * a + k.rf[1] * d * d;
             f1p_f2 cy, sy;                                             // cos / sin of the absolute heading
             {   // hardware sin / cos of the relative heading (the transcendental unit runs beside the packed FMAs: a polynomial
                 // phasor recurrence measured 4 % slower), rotated by the start heading
-                float sn0, cs0, sn1, cs1;
-                __sincosf(s.yaw.x, &sn0, &cs0);
-                __sincosf(s.yaw.y, &sn1, &cs1);
+                const float sn0 = __builtin_amdgcn_sinf(s.yaw.x), cs0 = __builtin_amdgcn_cosf(s.yaw.x);   // (arguments in revolutions)
+                const float sn1 = __builtin_amdgcn_sinf(s.yaw.y), cs1 = __builtin_amdgcn_cosf(s.yaw.y);
                 f1p_f2 sn, cs;
                 sn.x = sn0; sn.y = sn1; cs.x = cs0; cs.y = cs1;
                 if (ISO) { cy = cs; sy = sn; }
@@ -281,15 +287,15 @@ __device__ __forceinline__ void kmpc_steps2(KmpcState2& s, const float* sref32, 
             const f1p_f2 vdt = s.v * k.dt;
             s.x += vdt * cy;
             s.y += vdt * sy;
-            f1p_f2 tn;
             if (POLY) {                                                // odd Taylor polynomial to d^11: next term 0.0036 d^12 < 2.5e-7 for |d| <= 0.45
                 const f1p_f2 d2 = d * d;
-                tn = d * (1.0f + d2 * (0.33333333f + d2 * (0.13333333f + d2 * (0.053968254f + d2 * (0.021869489f + d2 * 0.0088632355f)))));
+                const f1p_f2 tn = d * (k.tc[0] + d2 * (k.tc[1] + d2 * (k.tc[2] + d2 * (k.tc[3] + d2 * (k.tc[4] + d2 * k.tc[5])))));
+                s.yaw += s.v * tn;
             } else {
+                f1p_f2 tn;
                 tn.x = __tanf(d.x); tn.y = __tanf(d.y);
+                s.yaw += s.v * k.yaw_k * tn;
             }
-            const f1p_f2 dyaw = s.v * k.inv_wb_dt * tn;
-            s.yaw += dyaw;
             s.v = med3x2(s.v + a * k.dt, k.min_speed, k.max_speed);
             s.pa = a; s.pd = d;
         }
@@ -327,6 +333,7 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const 
     const f1p_f2 e0 = k.sqf[0] * s.x + sref32[0 * (T + 1) + T], e1 = k.sqf[1] * s.y + sref32[1 * (T + 1) + T];
     const f1p_f2 e2 = k.sqf[2] * s.v + sref32[2 * (T + 1) + T], e3 = k.sqf[3] * s.yaw + sref32[3 * (T + 1) + T];
     s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    s.cost -= k.rd[0] * s.pa * s.pa + k.rd[1] * s.pd * s.pd;           // the last step has no successor (see KmpcF32)
     return s.cost;
 }
 
@@ -1029,8 +1036,16 @@ static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg) {
         if (!(cfg->q[i] >= 0.0) || !(cfg->qf[i] >= 0.0)) kf.w_ok = 0;
         kf.sq[i] = kf.w_ok ? (float)std::sqrt(cfg->q[i]) : 0.f; kf.sqf[i] = kf.w_ok ? (float)std::sqrt(cfg->qf[i]) : 0.f;
     }
-    for (int i = 0; i < 2; ++i) { kf.r[i] = (float)cfg->r[i]; kf.rd[i] = (float)cfg->rd[i]; }
-    kf.dt = (float)cfg->dt; kf.inv_wb_dt = (float)(cfg->dt / cfg->wheelbase); kf.max_steer = (float)cfg->max_steer;
+    const double two_pi = 6.283185307179586, yk = cfg->dt / cfg->wheelbase / two_pi;
+    kf.sq[3] = (float)((double)kf.sq[3] * two_pi); kf.sqf[3] = (float)((double)kf.sqf[3] * two_pi);
+    for (int i = 0; i < 2; ++i) {
+        kf.rw[i] = (float)(cfg->r[i] + 2.0 * cfg->rd[i]); kf.rx[i] = (float)(-2.0 * cfg->rd[i]); kf.rf[i] = (float)(cfg->r[i] + cfg->rd[i]);
+        kf.rd[i] = (float)cfg->rd[i];
+    }
+    const double tan_c[6] = {1.0, 1.0 / 3.0, 2.0 / 15.0, 17.0 / 315.0, 62.0 / 2835.0, 1382.0 / 155925.0};
+    for (int i = 0; i < 6; ++i) kf.tc[i] = (float)(tan_c[i] * yk);
+    kf.yaw_k = (float)yk;
+    kf.dt = (float)cfg->dt; kf.max_steer = (float)cfg->max_steer;
     kf.max_accel = (float)cfg->max_accel; kf.max_speed = (float)cfg->max_speed; kf.min_speed = (float)cfg->min_speed;
     kf.dmax = (float)(cfg->max_dsteer * cfg->dt); kf.c0 = 1.f; kf.s0 = 0.f; kf.v0 = 0.f;
     return kf;
