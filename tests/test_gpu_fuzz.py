@@ -94,8 +94,9 @@ def test_random_lattice_configurations(ctx, orc, seed):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("F1P_FUZZ_SEEDS", "100"))))
 def test_random_kmpc_configurations(ctx, orc, seed):
-    """Random horizons, rollout counts (not multiples of the workgroup), weights and bounds (steering limits on both sides of the
-    polynomial-tan range): the mixed-precision schedule is bit-identical to the all-fp64 kernel and both match the oracle's index."""
+    """Random horizons, rollout counts (not multiples of the workgroup), weights (equal position weights in half of the seeds, a
+    negative one now and then) and bounds (steering limits on both sides of the polynomial-tan range): the mixed-precision schedule
+    is bit-identical to the all-fp64 kernel and both match the oracle's index."""
     rng = np.random.default_rng(5000 + seed)
     cl = synth.make_centerline(seed=2 + seed % 3)
     ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
@@ -106,9 +107,14 @@ def test_random_kmpc_configurations(ctx, orc, seed):
     states = np.column_stack([cl[k, 1] + rng.normal(0, 0.2, E), cl[k, 2] + rng.normal(0, 0.2, E), rng.uniform(0.0, 6.5, E),
                               cl[k, 3] + rng.normal(0, 0.3, E) + 2 * np.pi * rng.integers(-3, 4, E)])
     max_steer = float(rng.choice([0.2, 0.4189, 0.44, 0.5, 0.9]))
+    q, qf = rng.uniform(0, 20, 4), rng.uniform(0, 20, 4)
+    if seed % 2:                                                      # equal position weights (the reference's Q): the filter's ego-frame variant
+        q[1], qf[1] = q[0], qf[0]
+    if seed % 11 == 5:                                                # a negative weight has no square root: the all-fp64 path decides
+        q[int(rng.integers(0, 4))] = -1.0
     cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R, dt=float(rng.choice([0.05, 0.1, 0.2])), max_steer=max_steer,
                         max_dsteer=float(rng.uniform(0.5, 4.0)), max_speed=float(rng.uniform(3.0, 8.0)), min_speed=float(rng.choice([0.0, -1.0])),
-                        max_accel=float(rng.uniform(1.0, 5.0)), q=tuple(rng.uniform(0, 20, 4)), qf=tuple(rng.uniform(0, 20, 4)),
+                        max_accel=float(rng.uniform(1.0, 5.0)), q=tuple(q), qf=tuple(qf),
                         r=tuple(rng.uniform(0, 50, 2)), rd=tuple(rng.uniform(0, 50, 2)))
     ref = ctx.kmpc_ref(states, T, cfg.dt, 0.03)
     ctrl = synth.make_controls(E, T, R, seed=seed, sigma_a=float(rng.uniform(0.5, 4.0)), sigma_d=float(rng.uniform(0.05, 0.6)),
