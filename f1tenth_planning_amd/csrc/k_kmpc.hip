@@ -441,9 +441,15 @@ __device__ __forceinline__ double kmpc_rollout_lanes(const Src& src, const doubl
     // inf - inf), so clampd returns dc -- and its speed bounds are both sv, so whatever finite sum reaches it comes out as sv.
     const double dm = first ? __builtin_huge_val() : dmax;
     const double v_lo = first ? sv : cfg.min_speed, v_hi = first ? sv : cfg.max_speed;
-    for (int s = 1; s <= T; ++s) {
-        const double pd = lane_up1(d), pv = lane_up1(v);
-        d = clampd(dc, pd - dm, pd + dm);
+    for (int s = 1; s <= T; ++s) {                                     // the rate limit: to its fixed point (see the !COST branch), a few sweeps
+        const double pd = lane_up1(d);
+        const double d1 = clampd(dc, pd - dm, pd + dm);
+        const bool moved = j < T && d1 != d;
+        d = d1;
+        if (!__any(moved)) break;
+    }
+    for (int s = 1; s <= T; ++s) {                                     // the speed: a running sum, all T sweeps
+        const double pv = lane_up1(v);
         const double vn = pv + vinc;                                   // :236
         v = vn > v_hi ? v_hi : (vn < v_lo ? v_lo : vn);                // :238-241
     }
