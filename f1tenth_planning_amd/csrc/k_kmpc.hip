@@ -582,8 +582,20 @@ __device__ __forceinline__ void kmpc_refine_block(const double* __restrict__ ref
             if (j == T) { bc = c; bi = mine; }
         }
         F1P_KST(9);
-        if (one_wave) wave_argmin_dpp(bc, bi);
-        else block_argmin(bc, bi, red_d, red_i);
+        if (one_wave) {
+            // at most two groups (GL = 32) or one (GL = 64): their costs sit in lanes T and GL + T -- two v_readlane pairs and one comparison
+            // instead of a butterfly over 64 lanes
+            const int clo = __double2loint(bc), chi = __double2hiint(bc);
+            bc = __hiloint2double(__builtin_amdgcn_readlane(chi, T), __builtin_amdgcn_readlane(clo, T));
+            bi = __builtin_amdgcn_readlane(bi, T);
+            if (n > 1) {
+                const double c1 = __hiloint2double(__builtin_amdgcn_readlane(chi, GL + T), __builtin_amdgcn_readlane(clo, GL + T));
+                const int i1 = list[1];
+                if (argmin_better(c1, i1, bc, bi)) { bc = c1; bi = i1; }
+            }
+        } else {
+            block_argmin(bc, bi, red_d, red_i);
+        }
         F1P_KST(10);
         if (mine == bi) kmpc_emit_lanes(cfg, sv, e, j, a, d, bi, bc, steer, speed, best_idx, best_cost, best_seq, warm_out);
         F1P_KST(11);
