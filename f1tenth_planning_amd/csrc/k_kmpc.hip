@@ -705,8 +705,8 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
 
 // ---------------------------------------------------------------------------------------------------
 // Shooting with IN-KERNEL control generation (f1p_kmpc_plan_*): the same f32 filter + fp64 refinement as k_kmpc_shoot_mixed, the
-// controls coming from SrcGen instead of HBM.  No 8 B per rollout-step stream: the kernel is VALU-bound (Philox4x32-10 is ~75
-// integer instructions per rollout-step, the packed rollout ~20 per rollout).
+// controls coming from SrcGen instead of HBM.  No 8 B per rollout-step stream: the kernel is VALU-bound (round 4: 70 VALU instructions
+// per rollout-step, 26 of them Philox4x32-10 called once per two steps; a chunk of six steps is one basic block of ~900 instructions).
 // Grid = E x G workgroups: workgroup (e, g) filters rollouts [g Rs, (g+1) Rs) of ego e.  G > 1 (launcher: E < 2 x CUs, e.g. the
 // 128 egos per GPU of BASELINE configs[4]) spreads one ego's rollouts over several CUs; the filter costs go to a global
 // [E][R] f32 scratch, a per-ego ticket counts the finished workgroups and the LAST one to arrive runs the second stage --
