@@ -561,6 +561,127 @@ def leg_kmpc_c4(rk, args, steps):
     return out
 
 
+def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True):
+    """the headline workload (E x C x S, steady state of a closed loop, default schedule) on scenes it was NOT tuned on.
+      centred       today's bench scene (sigma 0.3 m around the raceline, nothing inside the corridor)
+      wall_hugging  sigma 0.9 m of a 1.1 m half-width corridor: many egos next to (or inside) a wall
+      obstacles     discs of occupied cells ON the raceline every 10 m: the cheapest candidates of the egos behind one collide, so
+                    the collision semantics the reference left as a stub (utils/utils.py:297-301) decide the plan
+      moving        the centred fleet advancing 8 cm along the raceline per plan (a 10 m/s vehicle at 125 Hz): plan k's previous
+                    path belongs to the pose of plan k-1
+    Per scene: ms per plan over `steps` chained plans (HIP events on the ctx stream), the four kernels' own durations, what the lazy station
+    pass looked at (f1p_lattice_debug_pass: candidates per ego, rounds), the refinement queue, the runtime audit, bit-identity of every
+    output with the all-fp64 kernel (f1p_lattice_set_mode 0) on all E egos and best-index mismatches against the CPU oracle."""
+    import numpy as np
+    from f1tenth_planning_amd import _abi, synth
+    from f1tenth_planning_amd.runtime import Context
+    from oracle import oracle    # the checker
+    nthr = oracle.max_threads()
+    fleet = synth.make_line_egos(rl, E, seed=11)
+    img_obs, _ = synth.stamp_obstacles(img, origin, res, rl, spacing=10.0, radius=0.30)
+    n_plans = warmup + steps + 1
+    all_scenes = {
+        "centred": (img, lambda k: synth.make_egos(rl, E, seed=1)),
+        "wall_hugging": (img, lambda k: synth.make_egos(rl, E, seed=1, pos_sigma=0.9)),
+        "obstacles": (img_obs, lambda k: synth.make_egos(rl, E, seed=1)),
+        "obstacles_moving": (img_obs, lambda k: synth.poses_along(rl, fleet, 0.08 * k)),
+        "moving": (img, lambda k: synth.poses_along(rl, fleet, 0.08 * k)),
+    }
+    names = scenes or ["centred", "wall_hugging", "obstacles", "moving", "obstacles_moving"]
+    out = {}
+    for name in names:
+        im, pose_of = all_scenes[name]
+        moving = "moving" in name
+        ctx = Context(0)
+        try:
+            ctx.set_waypoints(rl); ctx.set_grid(im, res, origin, 206)
+            ctx.lattice_set_closed_loop(True)
+            ctx.lattice_set_order(order)
+            pose_sets = [pose_of(k) for k in range(n_plans)] if moving else [pose_of(0)]
+            d_pose = [ctx.to_device(p) for p in pose_sets]
+            outs = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
+            k = 0
+
+            def plan(d_prev=None):
+                nonlocal k
+                ctx.lattice_plan_dev(d_pose[k % len(d_pose)], E, cfg, *outs, d_prev_theta=d_prev)
+                k += 1
+            for _ in range(warmup):
+                plan()
+            ctx.sync()
+            ctx.timer_begin()
+            for _ in range(steps):
+                plan()
+            ms = ctx.timer_end() / steps
+            # the chain's next plan: the one every comparison below repeats with its previous path handed over explicitly
+            prev_in = ctx.lattice_closed_loop_prev()
+            d_prev_in = ctx.to_device(prev_in)
+            k_last = k
+            plan()
+            ctx.sync()
+            ctx.lattice_set_closed_loop(False)
+            poses_last = pose_sets[k_last % len(pose_sets)]
+            got = {n: b.download(t, sh) for n, b, t, sh in (("steer", outs[0], np.float64, (E,)), ("speed", outs[1], np.float64, (E,)),
+                                                          ("best_idx", outs[2], np.int32, (E,)), ("best_cost", outs[3], np.float64, (E,)),
+                                                          ("status", outs[4], np.int32, (E,)), ("near_idx", outs[5], np.int32, (E,)),
+                                                          ("best_traj", outs[6], np.float64, (E, S, 4)))}
+            # (i) all fp64, same poses and previous path: every output bit for bit
+            alt = [ctx.alloc(b.nbytes) for b in outs]
+            ctx.lattice_set_mode(0)
+            ctx.lattice_plan_dev(d_pose[k_last % len(d_pose)], E, cfg, *alt, d_prev_theta=d_prev_in)
+            ctx.sync()
+            ident = all(np.array_equal(alt[i].download(got[n].dtype, got[n].shape), got[n], equal_nan=(got[n].dtype != np.int32))
+                        for i, n in enumerate(("steer", "speed", "best_idx", "best_cost", "status", "near_idx", "best_traj")))
+            ctx.lattice_set_mode(1)
+            # (ii) per-kernel durations + the station pass's statistics on that same plan
+            ctx.lattice_profile(True)
+            acc = np.zeros(4)
+            n_prof = 10
+            for _ in range(n_prof):
+                k = k_last; plan(d_prev_in)
+                acc += np.array(ctx.lattice_profile(True, read=True))
+            ctx.lattice_profile(False)
+            acc /= n_prof
+            d_pass = ctx.to_device(np.zeros((E, 4), np.int32))
+            ctx.lattice_debug_pass(d_pass)
+            k = k_last; plan(d_prev_in); ctx.sync()
+            ctx.lattice_debug_pass(None)
+            ps = d_pass.download(np.int32, (E, 4))
+            nq = ctx.lattice_debug_queue(E)
+            stat = lambda v: {"mean": float(v.mean()), "p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": int(v.max())}   # noqa: E731
+            # (iii) runtime audit over the chain's plans (moving: different poses every plan)
+            ctx.lattice_audit_read(reset=True)
+            ctx.lattice_set_audit(1, min(256, E))
+            for j in range(16):
+                k = k_last; plan(d_prev_in)
+            audit = ctx.lattice_audit_read(reset=True)
+            ctx.lattice_set_audit(0)
+            # (iv) the oracle on the first egos of that plan
+            n_or = min(oracle_egos, E)
+            want = oracle.lattice_plan_batch(poses_last[:n_or], rl, cfg, grid=(im, res, origin[0], origin[1], 206), prev_theta=prev_in[:n_or], nthreads=nthr)
+            out[name] = {
+                "ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3),
+                "kernels_ms": {"k_lattice_prologue": float(acc[0]), "k_lattice_filter3": float(acc[1]), "k_lattice_refine": float(acc[2]), "k_lattice_select": float(acc[3])},
+                "station_pass_candidates_per_ego": dict(stat(ps[:, 0]), of=C),
+                "station_pass_lane_per_candidate_share": float(ps[:, 1].sum()) / max(1.0, float(ps[:, 0].sum())),
+                "station_pass_rounds_per_ego": stat(ps[:, 2]),
+                "station_pass_second_looks_per_ego": stat(ps[:, 3]),
+                "refinement_queue_entries_per_ego": stat(nq),
+                "blocked_egos": int((got["status"] == _abi.ST_ALL_BLOCKED).sum()),
+                "outputs_bit_identical_to_all_fp64": bool(ident),
+                "audit": audit,
+                "oracle": {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != got["best_idx"][:n_or]).sum()),
+                           "max_abs_dsteer": float(np.abs(want["steer"] - got["steer"][:n_or]).max())},
+            }
+        finally:
+            ctx.close()
+    base = out.get("centred", {}).get("ms_per_plan")
+    if base:
+        for name in out:
+            out[name]["vs_centred"] = out[name]["ms_per_plan"] / base
+    return out
+
+
 def filter_shape(S, r):
     """What k_lattice_filter3 does (csrc/k_lattice_mixed.hip): EVERY candidate gets the f32 fit and the four cost terms with their bracket
     (bracket_f2: nothing there looks at positions); the station pass -- positions and occupancy look-ups -- runs only for the candidates whose

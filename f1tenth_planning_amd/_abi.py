@@ -198,6 +198,8 @@ PROTOTYPES = {
     "f1p_lattice_debug_margins": (C.c_int, [_P, _I, C.c_float, C.c_float]),
     "f1p_lattice_debug_bound": (C.c_int, [_P, _P]),
     "f1p_lattice_debug_queue": (C.c_int, [_P, _P, _I]),
+    "f1p_lattice_debug_pass": (C.c_int, [_P, _P]),
+    "f1p_lattice_set_order": (C.c_int, [_P, _I]),
     "f1p_lattice_profile": (C.c_int, [_P, _I, _P]),
     "f1p_lattice_emit_dev": (C.c_int, [_P, _P, _P, _I, C.POINTER(LatticeCfg), _P, _P, _P, _P, _P, _P, _P]),
     "f1p_clothoid_g1_batch": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),

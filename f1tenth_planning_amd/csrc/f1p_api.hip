@@ -309,7 +309,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     f1p_comm_destroy(ctx);
-    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1], ctx->d_step, ctx->d_comm_rec};
+    void* ptrs[] = {ctx->d_wx, ctx->d_wy, ctx->d_wv, ctx->d_wpsi, ctx->d_wkappa, ctx->d_wbox, ctx->d_bits, ctx->d_bits0, ctx->d_bits_clear, ctx->d_bb_scratch, ctx->d_arena, ctx->d_comm_key, ctx->d_comm_idx, ctx->d_kmpc_warm, ctx->d_kmpc_scratch, ctx->d_mix_scratch, ctx->d_split_scratch, ctx->d_rec_scratch, ctx->d_st_scratch, ctx->d_audit, ctx->d_audit_buf, ctx->d_cl_theta[0], ctx->d_cl_theta[1], ctx->d_step, ctx->d_comm_rec, ctx->d_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -994,6 +994,19 @@ int f1p_lattice_debug_queue(f1p_ctx* ctx, int32_t* entries_per_ego, int32_t E) {
 int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound) {
     if (!ctx) return F1P_EINVAL;
     ctx->d_dbg_lat_bound = d_bound;
+    return F1P_OK;
+}
+
+int f1p_lattice_set_order(f1p_ctx* ctx, int32_t heavy_first) {
+    if (!ctx) return F1P_EINVAL;
+    if (heavy_first < 0 || heavy_first > 1) return set_error(ctx, F1P_EINVAL, "heavy_first must be 0 or 1");
+    ctx->lattice_order = heavy_first;
+    return F1P_OK;
+}
+
+int f1p_lattice_debug_pass(f1p_ctx* ctx, int32_t* d_pass) {
+    if (!ctx) return F1P_EINVAL;
+    ctx->d_dbg_lat_pass = d_pass;
     return F1P_OK;
 }
 

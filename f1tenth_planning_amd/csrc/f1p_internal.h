@@ -92,12 +92,18 @@ struct f1p_ctx {
     int lattice_chunks = 0;            // pipeline chunks of a mixed plan: 0 = automatic, 1 = off (f1p_lattice_set_pipeline)
     hipStream_t pipe_stream[2] = {};   // the pipeline's two internal streams
     hipEvent_t ev_pipe[4] = {};        // done (x2), start, stagger
+    char* d_order = nullptr;           // dispatch order of k_lattice_filter3: slots | counters | per-ego heavy flags (MixArgs::perm, round 5)
+    size_t order_bytes = 0;
+    int order_E = 0;                   // batch size the heavy flags belong to
+    int lattice_order = 1;             // f1p_lattice_set_order: 1 = heavy egos first (default), 0 = ego order
+    bool mix_q_dirty_prev = false;
     bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule
     hipEvent_t ev_prof[5] = {};        // before the prologue | before the filter | before the refinement | before the selection | after it
     float* d_dbg_lat_bound = nullptr;  // [E][C] per-candidate a-priori cost error bounds (test hook: f1p_lattice_debug_bound), or null
     float* d_dbg_lat_cost32 = nullptr; // [E][C] filter costs of the following launches (test hook), or null
     int32_t* d_dbg_lat_state = nullptr;// [E][C] filter states
+    int32_t* d_dbg_lat_pass = nullptr; // [E][4] station-pass statistics of k_lattice_filter3 (f1p_lattice_debug_pass), or null
 
     // closed-loop mode (f1p_lattice_set_closed_loop): the heading column of every plan's winners stays on the device and is the next
     // plan's prev_theta (get_similarity_cost's previous path, lattice_planner.py:287-296) -- two buffers used alternately

@@ -79,6 +79,22 @@ namespace f1p {
 #ifndef F1P_MIX_COOP_MAX
 #define F1P_MIX_COOP_MAX 4           // selected candidates per wave up to which the station pass runs wave-cooperatively (station_pass_wave), one after the other
 #endif
+#ifndef F1P_MIX_COOP_MAX_X
+#define F1P_MIX_COOP_MAX_X 24        // second looks (every station) a wave has pending up to which it takes them F1P_MIX_COOP_MAX per round, lowest lo first; beyond:
+                                     // all at once lane-per-candidate (a chain of S single intervals and S look-ups, ~1 800 instructions at 50 stations)
+#endif
+#ifndef F1P_MIX_OREG
+#define F1P_MIX_OREG 64              // regions of the candidate kernel's dispatch order (MixArgs::perm): 2 x 64 counters take the prologue's atomics
+#endif
+#ifndef F1P_MIX_HEAVY_MEMORY
+#define F1P_MIX_HEAVY_MEMORY 16      // plans an ego stays at the front of the dispatch order after its station pass last took more than one round
+#endif
+#ifndef F1P_MIX_ORDER_MIN_EGOS
+#define F1P_MIX_ORDER_MIN_EGOS 1024  // batches from this size are ordered (below: fewer workgroups than resident slots, nothing queues behind anything)
+#endif
+#ifndef F1P_MIX_ROUNDS
+#define F1P_MIX_ROUNDS 10            // rounds of the station pass (what is still undecided below T after the last one goes to fp64)
+#endif
 #ifndef F1P_MIX_F3_EGOS_PER_WG
 #define F1P_MIX_F3_EGOS_PER_WG 1     // egos a k_lattice_filter3 workgroup evaluates one after the other (grid = egos / this)
 #endif
@@ -103,6 +119,9 @@ namespace f1p {
 #define F1P_ST_HIT 1
 #define F1P_ST_UNSURE 2
 #define F1P_ST_BAD 3
+#define F1P_ST_PENDING 4           // bracket known, collision state not looked at (yet)
+#define F1P_ST_PENDING2 5          // ... looked at in the clearance mode and undecided (a tested station in a cell that is not clear, a spacing beyond the
+                                   // map's, a piece outside the integrated series' range): the every-station pass on the real bitmap can still decide it in f32
 #define F1P_INV_2PI_F 0.15915494309189535f
 
 __constant__ float c_gl16_xf[16] = {5.299532504e-03f, 2.771248846e-02f, 6.718439881e-02f, 1.222977958e-01f, 1.910618778e-01f, 2.709916112e-01f, 3.591982246e-01f, 4.524937451e-01f, 5.475062549e-01f, 6.408017754e-01f, 7.290083888e-01f, 8.089381222e-01f, 8.777022042e-01f, 9.328156012e-01f, 9.722875115e-01f, 9.947004675e-01f};
@@ -159,6 +178,17 @@ struct MixArgs {
     float* dbg_bound;             // [E][C] test hook (nullable): the candidate's a-priori cost error bound (filter3)
     float* dbg_cost32;            // [E][C] test hook (nullable)
     int32_t* dbg_state;           // [E][C] test hook (nullable)
+    // Round 5 -- dispatch order of k_lattice_filter3.  An ego whose station pass needs more than one round (its cheapest candidates collide:
+    // next to a wall, behind an obstacle) lives 1.6-2.5x as long as the others, and 4096 workgroups are only two dispatch rounds: such a
+    // workgroup in the second round IS the kernel's tail (scene sweep: +9 us with 1.4 % of them).  They are the same egos from one plan of a
+    // control loop to the next, so every plan leaves a flag per ego (heavy[]) and the next plan's prologue places the flagged egos FIRST:
+    // region r = e % F1P_MIX_OREG holds its egos heavy-first (two counters per region, placed from both ends), block b takes slot b / OREG of
+    // region b % OREG.  A stale or missing flag costs time, never correctness.
+    int32_t* perm;                // [F1P_MIX_OREG * perm_rs] ego + 1 per slot (0: none), or null: block b takes ego e0 + b
+    unsigned int* ocnt;           // [F1P_MIX_OREG][64]: [0] heavy egos placed so far (from the front), [32] light ones (from the back)
+    unsigned char* heavy;         // [E] written by k_lattice_filter3, read by the next plan's k_lattice_prologue
+    int perm_rs;                  // slots per region
+    int32_t* dbg_pass;            // [E][4] measurement hook (nullable): candidates the station pass looked at, lane-per-candidate passes, rounds, second looks
 };
 
 // ek0 / edk / eLrel: a-priori bounds of |k0 - k0_64|, |dk - dk_64| and |L - L_64| / L for THIS candidate
@@ -896,7 +926,7 @@ __global__ __launch_bounds__(256, 6) void k_lattice_filter(LatticeArgs a, f1p_la
         const int c = cb + tid;
         if (c >= c1) continue;
         const int st = c_st[c - c0];
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         mine += (need | (none_free & (c == c0))) ? 1 : 0;
     }
     int pos = 0;
@@ -915,7 +945,7 @@ __global__ __launch_bounds__(256, 6) void k_lattice_filter(LatticeArgs a, f1p_la
         const int c = cb + tid;
         if (c >= c1) continue;
         const int st = c_st[c - c0];
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         if (need | (none_free & (c == c0))) {
             double gx = 0.0, gy = 0.0, gth = 0.0;
             const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
@@ -977,6 +1007,7 @@ struct EgoParamsF2 {
     float margin_rel, margin_abs, edge0, edge1;
     float clear_ds_cap, inv_den, inv_S, fS;
     float cells_per_m, sqrt_S;    // |(txx, txy)|: cells per metre of the ego -> tile transform (the position bound in cells); sqrt(S)
+    float inv_nw, pad0;           // 1 / n_width (candidate -> look-ahead row; read from LDS where it is needed instead of held in a register)
     const double* prev;
     // moments of the previous path's heading column p_j = prev[j + n_shift], j < sim_m (k_lattice_prologue, fp64): with them the similarity
     // term sum_j (theta_j - p_j)^2 of a candidate whose theta_j = A j + B j^2 is a closed form -- no per-station loop in the filter
@@ -994,7 +1025,6 @@ struct EgoParamsF2 {
 // bracket_f2 (fit -> cost, [lo, hi], what is already known about its state), and station_pass_f2 -- positions, look-ups -- runs in
 // rounds on the few candidates that can still matter (k_lattice_filter3).  The states and brackets of the candidates that reach the
 // refinement queue are the ones the every-candidate loop produced, so the queue -- and every output -- is unchanged.
-#define F1P_ST_PENDING 4           // bracket known, collision state not looked at (yet)
 struct Brk32 { float cost, lo, hi, ebound; int state; bool never_free; };
 
 // The band around a cell edge inside which a look-up of THIS candidate decides nothing: farther than the f32 POSITION error -- the
@@ -1124,7 +1154,8 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     o.lo = o.cost - m; o.hi = o.cost + m;
     // what is known without the positions: outside the series' range nothing they say counts (UNSURE, final); a candidate beyond the
     // clearance map's spacing or with a position bound beyond its slack can still turn out a certain HIT, never FREE
-    o.state = untrusted ? F1P_ST_UNSURE : F1P_ST_PENDING;
+    const bool untrusted1 = !(kmax * h <= 0.4f) || !(fabsf(b) <= 0.05f);     // ... of a single interval (what the every-station pass integrates)
+    o.state = untrusted ? ((macro && !untrusted1) ? F1P_ST_PENDING2 : F1P_ST_UNSURE) : F1P_ST_PENDING;
     o.never_free = unsure;
     if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.never_free = true; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }   // no bracket: HIT or UNSURE
     return o;
@@ -1136,10 +1167,11 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
 // station: the kernel's tail grew to 54 us.)
 template <int R>
 __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
-                                               const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, float& xe, float& ye) {
+                                               const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, float& xe, float& ye, bool exact_all) {
     const int S = __builtin_amdgcn_readfirstlane(ep->S);
     const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
-    const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
+    // exact_all (wave-uniform): every station against the real bitmap, single intervals -- an ego that stands in a cell that is not clear
+    // (EgoParamsF2::exact_all), or the SECOND look at a candidate whose clearance-mode pass met a cell that is not clear (round 5)
     const float ds = L * ep->inv_den, h = 0.5f * ds;
     const float b = 0.5f * dk * h * h;
     constexpr int G = 2 * R + 1;
@@ -1202,14 +1234,19 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
     int base = 0;
     float ub = 0.5f;                                                         // u of interval `base`
     if (!macro) {
+        bool all_hit = false;                                                // (wave-uniform) every lane in this pass already holds a certain hit
         for (; base + G < S; base += G, ub += (float)G) {                    // whole groups with a station after them
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 if (exact_all || j == R) test();
                 step(ub + (float)j);
             }
+            // round 5: an ego inside a wall (every candidate occupied at station 0) or behind one ran all S stations of this chain on every
+            // lane -- ~1 800 instructions per wave to learn what the first look-ups said.  A certain hit is final (the positions up to that
+            // station were finite: checked below on the current x, y), so the chain ends when every lane in it has one.
+            if (exact_all && !__ballot(((flags & 2u) == 0u) | !(x == x) | !(y == y))) { all_hit = true; break; }
         }
-        {                                                                    // tail of <= G stations: one test covers it
+        if (!all_hit) {                                                      // tail of <= G stations: one test covers it
             const int t = base + R < S - 1 ? base + R : S - 1;
             for (int i = base; i < S; ++i, ub += 1.0f) {
                 if (exact_all || i == t) test();
@@ -1347,7 +1384,7 @@ __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, fl
 // round, the kernel 87 us).  As two kernels the prologue is executed by one wave per ego at four waves per SIMD (latency hidden
 // by occupancy), and the candidate kernel is uniform VALU work.
 // ===================================================================================================================
-struct EgoRecHdr {                 // 184 bytes; followed by cen_x[nl], cen_y[nl], sin psi[nl], cos psi[nl], goal heading[nl] (fp64: what candidate_goal
+struct EgoRecHdr {                 // 192 bytes; followed by cen_x[nl], cen_y[nl], sin psi[nl], cos psi[nl], goal heading[nl] (fp64: what candidate_goal
                                    // computes per look-ahead ROW, so a queue entry's goal is ten fp64 operations) and GoalFrame32[nl]
     double px, py, theta, ct, st;  // candidate_goal's inputs
     EgoParamsF2 p;                 // the station loop's parameters (exact_all is decided by the filter kernel: it needs the tile)
@@ -1368,6 +1405,12 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     const int nl = cfg.n_lookahead, S = cfg.n_stations;
     double* cen_x = s_cen[wave]; double* cen_y = cen_x + F1P_MAX_LOOKAHEADS; double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
     int* cen_ok = s_ok[wave];
+    // the ego's slot in the candidate kernel's dispatch order (MixArgs::perm): requested first, stored with the record
+    int o_slot = 0;
+    if (mx.perm && lane == 0) {
+        const unsigned r = (unsigned)e % F1P_MIX_OREG;
+        o_slot = mx.heavy[e] ? (int)atomicAdd(&mx.ocnt[r * 64u], 1u) : mx.perm_rs - 1 - (int)atomicAdd(&mx.ocnt[r * 64u + 32u], 1u);
+    }
 #ifdef F1P_PRO_PHASES
     long long pph[10]; int npp = 0;
 #define F1P_PPH() do { __builtin_amdgcn_s_waitcnt(0); pph[npp++] = clock64(); } while (0)
@@ -1504,6 +1547,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         p.clear_ds_cap = mx.clear_ds_cap;
         p.inv_den = __builtin_amdgcn_rcpf((float)den);
         p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
+        p.inv_nw = 1.0f / (float)cfg.n_width; p.pad0 = 0.f;
         { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
         p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
         p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
@@ -1511,6 +1555,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
         p.exact_all = own_bit < 0 ? 1 : (int)((own_word >> own_bit) & 1u);
         *reinterpret_cast<EgoRecHdr*>(rec) = h;
+        if (mx.perm) mx.perm[((unsigned)e % F1P_MIX_OREG) * (unsigned)mx.perm_rs + (unsigned)o_slot] = e + 1;
     }
     F1P_PPH();
 #ifdef F1P_PRO_PHASES
@@ -1555,20 +1600,26 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     double* wtab = reinterpret_cast<double*>(rec + rec_bytes);   // [64] lateral offsets (LDS copy: indexed per lane)
     float* red_f = reinterpret_cast<float*>(wtab + F1P_MAX_WIDTHS);   // [3 reductions][2 values][4 waves]
     int* cnt = reinterpret_cast<int*>(red_f + 24);               // [4]: refine count, queue base
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: a scalar register, not one of the 64 VGPRs)
     const int C = nl * cfg.n_width;
     const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
     const int nc = c1 - c0;
     float* c_lo = reinterpret_cast<float*>(cnt + 4);             // [nc] per-candidate lower bound of the fp64 cost
     float* c_hi = c_lo + nc;                                     // [nc] ... and upper bound
-    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_hi + nc);          // [nc] state (bit 7: can no longer turn out FREE)
+    // [6][nc] the fit (k0, dk, L) and its error bounds (ek0, edk, eLrel) when every thread has ONE candidate (nc <= 256, the usual case): only
+    // a candidate that takes the station pass reads them back -- six registers less across the rounds (several candidates per thread: the
+    // selected one is fitted again)
+    float* c_fit = c_hi + nc;
+    const int nfit = nc <= (int)blockDim.x ? nc : 0;
+    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_fit + 6 * nfit);   // [nc] state (bit 7: can no longer turn out FREE)
     // a workgroup takes egos blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher sizes the grid: F1P_MIX_F3_EGOS_PER_WG egos each)
 #if F1P_MIX_F3_EGOS_PER_WG > 1
     for (int e = a.e0 + blockIdx.x; e < a.E; e += gridDim.x) {
 #else
     {
-    const int e = a.e0 + blockIdx.x;                             // (no loop in the default build: under the 64-register cap its live ranges spill)
-    if (e >= a.E) return;
+    int e = a.e0 + blockIdx.x;                                   // (no loop in the default build: under the 64-register cap its live ranges spill)
+    if (mx.perm) e = mx.perm[(blockIdx.x % F1P_MIX_OREG) * (unsigned)mx.perm_rs + blockIdx.x / F1P_MIX_OREG] - 1;   // heavy egos first (MixArgs::perm); an empty slot: -1
+    if (e >= a.E || e < 0) return;
 #endif
     // ---- the ego's record: one coalesced copy into LDS ----------------------------------------------------------------------------
     {
@@ -1579,7 +1630,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
     if (tid == 0) cnt[0] = 0;
 #ifdef F1P_F3_PHASES
-    long long fph[10]; int nfp = 0;
+    long long fph[10]; int nfp = 0, n_rounds = 0;
 #define F1P_FPH() do { fph[nfp++] = clock64(); } while (0)
 #else
 #define F1P_FPH() do {} while (0)
@@ -1594,15 +1645,20 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     // workgroup -- and wave w of every resident workgroup shares SIMD w, so one SIMD per CU ran every pass while three idled (measured:
     // filter 53 us against 41 before the lazy pass).
     const int ptid = blockDim.x == 256 ? (tid + (int)((((unsigned)e * 0x9E3779B1u) >> 30) << 6)) & 255 : tid;
+    // Round 5: within a full block of 256 candidates the map is also INTERLEAVED -- candidate cb + (29 p mod 256) on thread p -- so that
+    // neighbours in the goal grid (next width, next look-ahead row: neighbours in cost) sit in different waves (same-wave neighbour pairs of a
+    // 16 x 16 grid: 2 256 -> 421).  The station pass takes a workgroup's few selected candidates a wave at a time: with 64 consecutive
+    // candidates per wave one wave took them all, one after the other, while three waited at the barrier -- the tail of the kernel.
+    auto cand_of = [&](int cb) { return cb + ((blockDim.x == 256 && cb + 256 <= c1) ? (int)(__umul24((unsigned)ptid, 29u) & 255u) : ptid); };   // (formed where needed: no register held for it)
     const bool all_states = DBG && mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
-    const float inv_nw = 1.0f / (float)cfg.n_width;
+
     const float INF = __builtin_huge_valf();
 
     // ---- phase 1, every candidate in f32: goal -> G1 fit -> cost and bracket [lo, hi]; nothing looks at positions -------------------
-    float kf_k0 = 0.f, kf_dk = 0.f, kf_L = 0.f, kf_ek0 = 0.f, kf_edk = 0.f, kf_eL = 0.f;    // the one-pass thread's fit (and its error bounds) for the station pass
+
     auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& ek0, float& edk, float& eL, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
         // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
-        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
+        const int l = (int)(((float)c + 0.5f) * ep->inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
         const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
         const bool gok = gf->ok != 0;
         const double w = ((const F1P_LDS(double)*)wtab)[k];
@@ -1624,13 +1680,18 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     };
     float my_hi_p = INF;                                          // min hi over this thread's PENDING candidates
     for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + ptid;
+        const int c = cand_of(cb);
         if (c >= c1) continue;
         float lo, hi, gx, gy; Brk32 o; int dbg_code;
-        const int st = bracket_of(c, kf_k0, kf_dk, kf_L, kf_ek0, kf_edk, kf_eL, lo, hi, gx, gy, o, dbg_code);
+        float f_k0, f_dk, f_L, f_ek0, f_edk, f_eL;
+        const int st = bracket_of(c, f_k0, f_dk, f_L, f_ek0, f_edk, f_eL, lo, hi, gx, gy, o, dbg_code);
         c_lo[c - c0] = lo; c_hi[c - c0] = hi;
+        if (one_pass) {
+            float* q = c_fit + (c - c0);
+            q[0] = f_k0; q[nc] = f_dk; q[2 * nc] = f_L; q[3 * nc] = f_ek0; q[4 * nc] = f_edk; q[5 * nc] = f_eL;
+        }
         c_st[c - c0] = (unsigned char)st;
-        if ((st & 0x7f) == F1P_ST_PENDING) my_hi_p = fminf(my_hi_p, hi);
+        if ((st & 0x7f) == F1P_ST_PENDING || (st & 0x7f) == F1P_ST_PENDING2) my_hi_p = fminf(my_hi_p, hi);
 #if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES)
         if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
         if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
@@ -1638,7 +1699,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = 0.0f;
         if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
 #endif
-        if (DBG && mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
+        if (DBG && mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING && (st & 0x7f) != F1P_ST_PENDING2) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
     }
     // ---- the tiles for the station pass: requested now, behind the candidates' arithmetic; the first reduction's barrier publishes them
     {
@@ -1683,59 +1744,122 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     };
 
     // ---- phase 2, the station pass in rounds.  Needed: T = min hi over the FREE candidates, and the state of every candidate with
-    // lo <= T.  Round 1 looks at the candidates whose bracket reaches below the smallest hi (the apparent winner and whatever it cannot
-    // be told from); with a FREE one among them T1 = its hi bounds T, and round 2 looks at the remaining candidates below T1 (usually
-    // none: the round is skipped); without one, round 2 looks at everything left.  A wave with no selected lane skips its pass.
+    // lo <= T.  Round 0 looks at the candidates whose bracket reaches below the smallest hi (the apparent winner and whatever it cannot
+    // be told from); with a FREE one among them T bounds the rest and round 1 looks at the remaining candidates below it (usually
+    // none: the round is skipped); without one, round 1 looks at everything left.  A wave with no selected lane skips its pass.
+    // Round 5 -- TWO looks per candidate.  The clearance-mode pass (10 look-ups at 50 stations) says FREE, HIT or "met a cell that is not
+    // clear": next to an obstacle or a wall that is most candidates, and each of them used to go to the fp64 refinement (scene sweep,
+    // obstacles on the raceline: 8.3 entries per ego, k_lattice_refine 20 -> 64 us).  Such a candidate (F1P_ST_PENDING2) now takes the
+    // EVERY-STATION pass on the real bitmap -- what an ego standing in such a cell always ran (exact_all) -- by a whole wave, lane = station:
+    // ~110 instructions decide FREE / HIT unless a station sits within the f32 position bound of a cell edge.  Right after the first look
+    // when a wave took it cooperatively or T is known; in the next round otherwise (with T known then, only below it).
     const bool exact_all_wg = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
-    const PassPlan plan = pass_plan<CR>(__builtin_amdgcn_readfirstlane(ep->S), exact_all_wg);
+    const int S_u = __builtin_amdgcn_readfirstlane(ep->S);
+    const PassPlan plan = pass_plan<CR>(S_u, exact_all_wg);
+    const PassPlan plan_x = pass_plan<CR>(S_u, true);               // every station
+    const F1P_LDS(unsigned char)* tile_b = (const F1P_LDS(unsigned char)*)lds_raw;
+    const unsigned pitch_b = (unsigned)pitch * 8u;
     float t_free = INF;                                           // min hi over this thread's FREE candidates
     float thr = my_hi_p;
+    bool thr_is_T = false;                                        // thr is a bound of T (a FREE candidate exists), not just the apparent winner's hi
     F1P_FPH();
     wg_min1(0, thr);
     F1P_FPH();
-    for (int round = 0; round < 2; ++round) {
-        float my_lo_p = INF;                                      // min lo over this thread's candidates still PENDING after the round
+    int rounds_run = 0;
+    for (int round = 0; round < F1P_MIX_ROUNDS; ++round) {
+        rounds_run = round + 1;
+        float my_lo_p = INF;                                      // min lo over this thread's candidates still undecided after the round
         for (int cb = c0; cb < c1; cb += blockDim.x) {
-            const int c = cb + ptid;
+            const int c = cand_of(cb);
             const int st = c < c1 ? (int)c_st[c - c0] : F1P_ST_BAD;
             const float lo = c < c1 ? c_lo[c - c0] : INF;
-            const bool sel = (st & 0x7f) == F1P_ST_PENDING && (all_states || !(lo > thr));
-            const unsigned long long selm = __ballot(sel);
-            if (selm) {                                           // wave-uniform
-                float k0 = kf_k0, dk = kf_dk, L = kf_L, ek0 = kf_ek0, edk = kf_edk, eL = kf_eL;
-                if (!one_pass && sel) {                           // several candidates per thread: the selected one is fitted again
-                    float lo2, hi2, gx, gy; Brk32 o; int dbg_code;
-                    (void)bracket_of(c, k0, dk, L, ek0, edk, eL, lo2, hi2, gx, gy, o, dbg_code);
-                }
-                // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
-                float edge = 2.0f;
-                bool nfree = (st & 0x80) != 0;
-                if (sel) { edge = edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, exact_all_wg); nfree |= !(edge < 0.8f); }
-                int ns = F1P_ST_PENDING;
-                [[maybe_unused]] float xe = 0.f, ye = 0.f;
-#ifndef F1P_MIX_DEBUG_END
-                // (test hook: with every state wanted, odd egos take the cooperative pass for all their candidates, even egos the lane-per-candidate
-                // pass -- tests/test_gpu_lattice_mixed.py checks the claims of both)
-                if (F1P_MIX_MACRO && plan.nt <= 64 && (__builtin_popcountll(selm) <= F1P_MIX_COOP_MAX || (all_states && (e & 1)))) {
-                    // a few selected candidates: the whole wave takes them one at a time (lane = test point)
-                    for (unsigned long long m = selm; m; m &= m - 1) {
-                        const int sl = __ffsll((long long)m) - 1;
-                        const float uk0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k0), sl)), udk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), sl));
-                        const float uL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L), sl)), uedge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edge), sl));
-                        const bool unf = __builtin_amdgcn_readlane(nfree ? 1 : 0, sl) != 0;
-                        const int r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, lane, plan, exact_all_wg);
-                        if (lane == sl) ns = r;
-                    }
-                } else
-#endif
-                if (sel) ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, (const F1P_LDS(unsigned char)*)lds_raw, (unsigned)pitch * 8u, xe, ye);
+            const int st7 = st & 0x7f;
+            const bool pend = (st7 == F1P_ST_PENDING) | (st7 == F1P_ST_PENDING2);
+            const bool sel = pend && (all_states || !(lo > thr));
+            const bool sel1 = sel && st7 == F1P_ST_PENDING;
+            const unsigned long long m1 = __ballot(sel1);
+            unsigned long long m2 = __ballot(sel && st7 == F1P_ST_PENDING2);
+            int ns = st7;
+            if (m1 | m2) {                                        // wave-uniform
+                float k0 = 0.f, dk = 0.f, L = 0.f, ek0 = 0.f, edk = 0.f, eL = 0.f;
                 if (sel) {
+                    if (one_pass) { const float* q = c_fit + (c - c0); k0 = q[0]; dk = q[nc]; L = q[2 * nc]; ek0 = q[3 * nc]; edk = q[4 * nc]; eL = q[5 * nc]; }
+                    else {                                        // several candidates per thread: the selected one is fitted again
+                        float lo2, hi2, gx, gy; Brk32 o; int dbg_code;
+                        (void)bracket_of(c, k0, dk, L, ek0, edk, eL, lo2, hi2, gx, gy, o, dbg_code);
+                    }
+                }
+                [[maybe_unused]] float xe = 0.f, ye = 0.f;
+                // look 0: the clearance-mode pass (the every-station pass for an ego that stands in a cell that is not clear); look 1: the every-station
+                // pass for what look 0 left undecided.  ONE loop body for both (not unrolled): a second inlined copy of the passes cost the kernel its
+                // 64-register budget.
+#pragma nounroll
+                for (int look = 0; look < 2; ++look) {
+                    const unsigned long long m = look == 0 ? m1 : m2;
+                    if (!m) continue;                             // wave-uniform
+                    const bool ex = look == 0 ? exact_all_wg : true;
+                    const bool mine = ((m >> lane) & 1ull) != 0ull;
+                    // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
+                    float edge = 2.0f;
+                    bool nfree = look == 0 && (st & 0x80) != 0;
+                    if (mine) { edge = edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex); nfree |= !(edge < 0.8f); }
+                    const int nt = ex ? plan_x.nt : plan.nt;
+                    bool coop = false;
+#ifndef F1P_MIX_DEBUG_END
+                    // a few selected candidates: the whole wave takes them one at a time (lane = test point).  (Test hook: with every state wanted, odd
+                    // egos take the cooperative pass for all their candidates, even egos the lane-per-candidate pass -- tests/test_gpu_lattice_mixed.py
+                    // checks the claims of both)
+                    coop = F1P_MIX_MACRO && nt <= 64 && (__builtin_popcountll(m) <= ((look == 1 && !thr_is_T) ? 2 * F1P_MIX_COOP_MAX : F1P_MIX_COOP_MAX) || (look == 0 && all_states && (e & 1)));
+#endif
+                    if (coop) {
+                        PassPlan pl;
+                        pl.nt = nt; pl.nm = ex ? plan_x.nm : plan.nm; pl.first_m = ex ? plan_x.first_m : plan.first_m;
+                        pl.tail_m = ex ? plan_x.tail_m : plan.tail_m; pl.tail_pos = ex ? plan_x.tail_pos : plan.tail_pos;
+                        for (unsigned long long mm = m; mm; mm &= mm - 1) {
+                            const int sl = __ffsll((long long)mm) - 1;
+                            const float uk0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k0), sl)), udk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), sl));
+                            const float uL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L), sl)), uedge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edge), sl));
+                            const bool unf = __builtin_amdgcn_readlane(nfree ? 1 : 0, sl) != 0;
+                            const int r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex);
+                            if (lane == sl) ns = r;
+                        }
+                    } else if (mine) {
+                        ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex);
+                        if (DBG && mx.dbg_pass) atomicAdd(&mx.dbg_pass[4 * (size_t)e + 1], 1);
+                    }
+                    if (DBG && mx.dbg_pass && mine) atomicAdd(&mx.dbg_pass[4 * (size_t)e + (look == 0 ? 0 : 3)], 1);
+                    if (look == 0) {
+                        // undecided by the first look: the second one now (a few candidates a wave took, or T known: everything selected is needed
+                        // anyway) or in the next round (the first look at everything left: T comes out of this round's reduction)
+                        const bool again = mine && ns == F1P_ST_UNSURE && !ex;
+                        if (again) ns = F1P_ST_PENDING2;
+                        if (coop | thr_is_T) m2 |= __ballot(again);
+                        // A wave takes at most F1P_MIX_COOP_MAX second looks per round, the candidates with the lowest lo first: a FREE one among them
+                        // lowers T, and what then lies above it is never looked at (the rest stays PENDING2 for the next round).  Many of them
+                        // -- an ego boxed in: nothing FREE anywhere -- go through the lane-per-candidate form at once.
+                        const int n2 = __builtin_popcountll(m2);
+                        if (n2 > F1P_MIX_COOP_MAX && n2 <= F1P_MIX_COOP_MAX_X && thr_is_T && !all_states) {   // (T unknown: every one of them is needed, now)
+                            unsigned long long pick = 0ull, rem = m2;
+#pragma unroll
+                            for (int i = 0; i < F1P_MIX_COOP_MAX; ++i) {
+                                const bool in = ((rem >> lane) & 1ull) != 0ull;
+                                const int key = f32_order_key(in ? lo : INF);
+                                const int kmin = wave_min_key(key);
+                                const unsigned long long eq = __ballot(in && key == kmin);
+                                const unsigned long long one = eq & (0ull - eq);       // lowest lane among equals
+                                pick |= one; rem &= ~one;
+                            }
+                            m2 = pick;
+                        }
+                    }
+                }
+                if (ns != st7) {                                  // (only lanes that took a pass)
                     c_st[c - c0] = (unsigned char)ns;
                     if (ns == F1P_ST_FREE) t_free = fminf(t_free, c_hi[c - c0]);
                     if (DBG && mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = ns;
 #ifdef F1P_MIX_DEBUG_END
                     if (DBG && mx.dbg_cost32) {
-                        const int l = (int)(((float)c + 0.5f) * inv_nw), k = c - l * cfg.n_width;
+                        const int l = (int)(((float)c + 0.5f) * ep->inv_nw), k = c - l * cfg.n_width;
                         const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
                         const double w = ((const F1P_LDS(double)*)wtab)[k];
                         const float gx = (float)__builtin_fma(w, gf->nx, gf->cx), gy = (float)__builtin_fma(w, gf->ny, gf->cy);
@@ -1744,26 +1868,30 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 #endif
                 }
             }
-            if (!sel && (st & 0x7f) == F1P_ST_PENDING) my_lo_p = fminf(my_lo_p, lo);
+            if ((ns == F1P_ST_PENDING) | (ns == F1P_ST_PENDING2)) my_lo_p = fminf(my_lo_p, lo);
         }
         float t = t_free;
-        F1P_FPH();
-        wg_min2(1 + round, t, my_lo_p);
-        F1P_FPH();
-        thr = t < INF ? t : INF;                                  // round 2: below T1 -- or, with nothing FREE yet, everything left
+        wg_min2(1 + (round & 1), t, my_lo_p);
+#ifdef F1P_F3_PHASES
+        ++n_rounds;
+#endif
+        if (DBG && mx.dbg_pass && tid == 0) atomicAdd(&mx.dbg_pass[4 * (size_t)e + 2], 1);
+        thr_is_T = t < INF;
+        thr = t;                                                  // the next round: below T -- or, with nothing FREE yet (+inf), everything left
         t_free = t;
-        if (round == 0 && !(my_lo_p <= thr)) break;               // nothing PENDING reaches below T1 (or nothing is PENDING): done, workgroup-uniform
+        if (!(my_lo_p <= thr) && !(all_states && my_lo_p < INF)) break;   // nothing undecided reaches below T (or nothing is undecided): done, workgroup-uniform (test hook: every state is wanted)
     }
+    F1P_FPH();                                                    // (stamps: 0 start, 1 record barrier, 2 phase 1, 3 first reduction, 4 rounds, 5 queue)
     const float t_min = t_free;                                   // (after its reduction: the workgroup's T)
 
     // ---- the candidates only fp64 can rank: count, reserve queue space, write the entries (goals by the fp64 arithmetic of candidate_goal)
     const bool none_free = !(t_min < INF);
     int mine = 0;
     for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + ptid;
+        const int c = cand_of(cb);
         if (c >= c1) continue;
         const int st = c_st[c - c0] & 0x7f;
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         mine += (need | (none_free & (c == c0))) ? 1 : 0;
     }
     int pos = 0;
@@ -1775,13 +1903,17 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         const unsigned int base = sh * mx.q_shard_cap + atomicAdd(&mx.qcount[sh * 32u], (unsigned int)n);
         cnt[1] = (int)base;
         mx.ego_base[e] = (int)base; mx.ego_n[e] = n;
+        // the next plans' dispatch order: a count-down, not a flag -- whether an ego near a wall takes the long path flips with every few
+        // centimetres it moves (measured on a moving fleet: 45 % of a plan's long-path egos had taken it in the plan before), so an ego stays
+        // among the first for F1P_MIX_HEAVY_MEMORY plans after its last long pass; a false positive costs nothing
+        if (mx.heavy) { const int h = mx.heavy[e]; mx.heavy[e] = (unsigned char)(rounds_run >= 2 ? F1P_MIX_HEAVY_MEMORY : (h > 0 ? h - 1 : 0)); }
     }
     // (one candidate per thread, the usual case: the entry's fp64 goal is formed while thread 0's queue-reserving atomic is on its way)
     double g1x = 0.0, g1y = 0.0, g1th = 0.0;
     int ok1 = 0;
     bool need1 = false;
-    if (one_pass && c0 + ptid < c1) {
-        const int c = c0 + ptid;
+    if (one_pass && cand_of(c0) < c1) {
+        const int c = cand_of(c0);
         need1 = mine != 0;                                           // (one candidate per thread: what the count above found)
         if (need1) {
             const int st = c_st[c - c0] & 0x7f;
@@ -1794,17 +1926,17 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     if (one_pass) {
         if (need1) {
             RefEntry r;
-            r.e = e; r.c = c0 + ptid; r.gx = g1x; r.gy = g1y; r.gth = g1th;
+            r.e = e; r.c = cand_of(c0); r.gx = g1x; r.gy = g1y; r.gth = g1th;
             // ok: 0 = no goal (infeasible), -1 = evaluate, -2 = evaluate, certainly collision-free (the occupancy test is skipped)
             r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = ok1; r.pad = 0;
             mx.q[base + pos] = r;
         }
     } else
     for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + ptid;
+        const int c = cand_of(cb);
         if (c >= c1) continue;
         const int st = c_st[c - c0] & 0x7f;
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE)) & !(c_lo[c - c0] > t_min);
+        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         if (need | (none_free & (c == c0))) {
             double gx = 0.0, gy = 0.0, gth = 0.0;
             const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
@@ -1820,7 +1952,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     if (DBG && mx.dbg_cost32 && !mx.dbg_state && lane == 0) {           // per wave: stamps relative to the first, slot 16 w ..
         float* d = mx.dbg_cost32 + (size_t)e * C + 16 * wave;
         for (int k = 1; k < nfp; ++k) d[k] = (float)(fph[k] - fph[0]);
-        d[0] = (float)nfp; d[15] = (float)(fph[0] & 0xffffff);
+        d[0] = (float)nfp; d[14] = (float)n_rounds; d[15] = (float)(fph[0] & 0xffffff);
     }
 #endif
 #if F1P_MIX_F3_EGOS_PER_WG > 1
@@ -2287,6 +2419,11 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = a.e0 + blockIdx.x * 4 + wave;
     if (blockIdx.x == 0 && tid < F1P_MIX_QSHARDS) mx.qcount[tid * 32u] = 0u;   // the refinement kernel is done with them: ready for the next plan
+    if (mx.perm) {                                               // ... and the dispatch order's counters and slots (the candidate kernel has consumed them)
+        if (blockIdx.x == 0 && tid < 2 * F1P_MIX_OREG) mx.ocnt[tid * 32u] = 0u;
+        const int np = F1P_MIX_OREG * mx.perm_rs;
+        if (lane == 0) { if (e < np) mx.perm[e] = 0; if (e + a.E < np && e < a.E) mx.perm[e + a.E] = 0; }   // (np < 2 E whenever the order is in use)
+    }
     if (e >= a.E) return;
     const int S = cfg.n_stations;
     double* tr_x = reinterpret_cast<double*>(lds_raw) + (size_t)wave * 4 * S;
@@ -2519,7 +2656,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             MixArgs mx;
             mx.margin_rel = F1P_MIX_MARGIN_REL; mx.margin_abs = F1P_MIX_MARGIN_ABS; mx.edge0 = F1P_MIX_EDGE0; mx.edge1 = F1P_MIX_EDGE1;
             if (ctx->dbg_margins) { mx.margin_rel = ctx->dbg_margin_rel; mx.margin_abs = ctx->dbg_margin_abs; }   // test hook (f1p_lattice_debug_margins)
-            mx.dbg_cost32 = ctx->d_dbg_lat_cost32; mx.dbg_state = ctx->d_dbg_lat_state; mx.dbg_bound = ctx->d_dbg_lat_bound;
+            mx.dbg_cost32 = ctx->d_dbg_lat_cost32; mx.dbg_state = ctx->d_dbg_lat_state; mx.dbg_bound = ctx->d_dbg_lat_bound; mx.dbg_pass = ctx->d_dbg_lat_pass;
             {   // sum_{j < sim_m} j^2, j^3, j^4: exact in fp64 for every admissible station count (validate_lattice caps S)
                 double s2 = 0.0, s3 = 0.0, s4 = 0.0;
                 for (int j = 0; j < S - cfg->n_shift - cfg->n_cull; ++j) { const double fj = (double)j; s2 += fj * fj; s3 += fj * fj * fj; s4 += (fj * fj) * (fj * fj); }
@@ -2539,7 +2676,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             // ... as two kernels (prologue: one wave per ego; filter3: candidates only)
             const size_t rec_stride = ego_rec_stride(cfg->n_lookahead);
             const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
-            size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + 16;
+            size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + (n_cand <= F1P_MIX_FILTER_BLOCK ? (size_t)n_cand * 24 : 0) + 16;
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const bool v3 = F1P_MIX_FILTER_V3 && !a.goals && mx.n_disc == 0 && (mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
                             (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3)
@@ -2590,6 +2727,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             }
             // k_lattice_select re-arms the counters at the end of every plan; a plan that failed after its filter ran leaves them dirty
             if (fresh || ctx->mix_q_dirty) F1P_HIP(ctx, hipMemsetAsync(mx.qcount, 0, qc_bytes, ctx->stream));
+            ctx->mix_q_dirty_prev = ctx->mix_q_dirty;                // (the dispatch order's counters share the fate of the queue's)
             ctx->mix_q_dirty = true;                                 // until the selection kernels of THIS plan are enqueued
             if (v3) {
                 const size_t need_rec = rec_stride * (size_t)E;
@@ -2600,6 +2738,30 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     F1P_HIP(ctx, hipMalloc((void**)&ctx->d_rec_scratch, need_rec));
                     ctx->rec_scratch_bytes = need_rec;
                 }
+            }
+            // dispatch order of the candidate kernel (MixArgs::perm): one unpipelined chunk of a batch large enough to queue
+            mx.perm = nullptr; mx.ocnt = nullptr; mx.heavy = nullptr; mx.perm_rs = 0;
+            if (v3 && nch == 1 && E >= F1P_MIX_ORDER_MIN_EGOS && F1P_MIX_F3_EGOS_PER_WG == 1 && ctx->lattice_order) {
+                const int rs = (E + F1P_MIX_OREG - 1) / F1P_MIX_OREG;
+                const size_t perm_bytes = (sizeof(int32_t) * (size_t)F1P_MIX_OREG * rs + 255) & ~(size_t)255, ocnt_bytes = sizeof(unsigned int) * 64 * F1P_MIX_OREG;
+                const size_t need_o = perm_bytes + ocnt_bytes + (size_t)E;
+                if (need_o > ctx->order_bytes || ctx->order_E != E) {
+                    if (need_o > ctx->order_bytes) {
+                        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        if (ctx->d_order) (void)hipFree(ctx->d_order);
+                        ctx->d_order = nullptr; ctx->order_bytes = 0;
+                        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_order, need_o));
+                        ctx->order_bytes = need_o;
+                    }
+                    F1P_HIP(ctx, hipMemsetAsync(ctx->d_order, 0, need_o, ctx->stream));   // no slots, no counts, no flags: the first plan of this size runs in ego order
+                    ctx->order_E = E;
+                } else if (fresh || ctx->mix_q_dirty_prev) {
+                    F1P_HIP(ctx, hipMemsetAsync(ctx->d_order, 0, perm_bytes + ocnt_bytes, ctx->stream));   // a plan failed before its selection kernel re-armed them
+                }
+                mx.perm = reinterpret_cast<int32_t*>(ctx->d_order);
+                mx.ocnt = reinterpret_cast<unsigned int*>(ctx->d_order + perm_bytes);
+                mx.heavy = reinterpret_cast<unsigned char*>(ctx->d_order + perm_bytes + ocnt_bytes);
+                mx.perm_rs = rs;
             }
             if (nch > 1) {                                           // even chunks on the caller's stream, odd chunks on ONE side stream: two cross-stream edges per plan
                 if (!ctx->pipe_stream[0]) F1P_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[0], hipStreamNonBlocking));
@@ -2627,8 +2789,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         F1P_HIP(ctx, hipEventRecord(ctx->ev_pipe[0], st));
                         F1P_HIP(ctx, hipStreamWaitEvent(ctx->pipe_stream[0], ctx->ev_pipe[0], 0));
                     }
-                    const unsigned f3_grid = (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
-                    const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound;      // (test hooks: their own instantiation)
+                    const unsigned f3_grid = mk.perm ? (unsigned)(F1P_MIX_OREG * mk.perm_rs) : (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
+                    const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
                     if (mk.clear_r == 1) {
                         if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
                         else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);

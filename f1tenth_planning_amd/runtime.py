@@ -437,6 +437,15 @@ class Context:
         """test hook: [E][C] f32 device buffer for the f32 filter's per-candidate a-priori cost error bounds (None = off)"""
         self._check(self.lib.f1p_lattice_debug_bound(self.h, None if d_bound is None else d_bound.ptr))
 
+    def lattice_set_order(self, heavy_first=True):
+        """dispatch order of the candidate kernel: egos whose previous plan took the long station pass first (default) or ego order; outputs identical"""
+        self._check(self.lib.f1p_lattice_set_order(self.h, 1 if heavy_first else 0))
+
+    def lattice_debug_pass(self, d_pass=None):
+        """measurement hook: [E][4] i32 device buffer (zeroed by the caller) for the lazy station pass's per-ego statistics -- candidates
+        looked at, of them lane-per-candidate, rounds, queue entries (None = off)"""
+        self._check(self.lib.f1p_lattice_debug_pass(self.h, None if d_pass is None else d_pass.ptr))
+
     def lattice_set_audit(self, every_n=0, n_egos=64):
         """every every_n-th mixed plan is re-planned on a moving window of n_egos egos by the all-fp64 kernel and compared bit for bit"""
         self._check(self.lib.f1p_lattice_set_audit(self.h, int(every_n), int(n_egos)))

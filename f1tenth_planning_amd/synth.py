@@ -130,3 +130,53 @@ def bench_lattice_cfg(n_cand=256, n_stations=50, generator="clothoid", prune=Fal
     return lattice_cfg(lookaheads=np.linspace(0.6, 3.0, n_l), widths=np.linspace(-1.0, 1.0, n_w),
                        n_stations=n_stations, weights=(0.25, 0.25, 0.25, 0.25), n_shift=1, n_cull=1,
                        check_collision=True, generator=generator, prune=prune)
+
+
+# ---- scenes the headline is NOT tuned on (bench.py's scene_sweep; tests) ------------------------------------------------------------
+
+def stamp_obstacles(img, origin, resolution, raceline, spacing=10.0, radius=0.30, lateral=0.0, value=0):
+    """A copy of the occupancy image with discs of occupied cells stamped ON the raceline every `spacing` metres of arc length (a parked
+    car per disc; `lateral` shifts them along the path normal).  The cheapest candidates of an ego behind a disc run through it: the scene
+    where the collision semantics the reference left as a stub (utils/utils.py:297-301) decide the plan.  Returns (img, centres [n, 2])."""
+    out = np.array(img, copy=True)
+    h, w = out.shape
+    xy = np.asarray(raceline)[:, :2]
+    seg = np.hypot(np.diff(xy[:, 0]), np.diff(xy[:, 1]))
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    at = np.arange(0.5 * spacing, s[-1] - 0.25 * spacing, spacing)
+    cx, cy = np.interp(at, s, xy[:, 0]), np.interp(at, s, xy[:, 1])
+    if lateral != 0.0:
+        psi = np.interp(at, s, np.unwrap(np.asarray(raceline)[:, 3]))
+        cx, cy = cx - lateral * np.sin(psi), cy + lateral * np.cos(psi)
+    rc = int(np.ceil(radius / resolution)) + 1
+    yy, xx = np.mgrid[-rc:rc + 1, -rc:rc + 1]
+    for x0, y0 in zip(cx, cy):
+        gx0, gy0 = int(np.floor((x0 - origin[0]) / resolution)), int(np.floor((y0 - origin[1]) / resolution))
+        # cell centres within `radius` of the disc centre
+        ccx = origin[0] + (gx0 + xx + 0.5) * resolution; ccy = origin[1] + (gy0 + yy + 0.5) * resolution
+        m = (ccx - x0) ** 2 + (ccy - y0) ** 2 <= radius * radius
+        gy, gx = gy0 + yy[m], gx0 + xx[m]
+        ok = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)
+        out[h - 1 - gy[ok], gx[ok]] = value
+    return np.ascontiguousarray(out), np.column_stack([cx, cy])
+
+
+def make_line_egos(raceline, n, seed=1, lat_sigma=0.3, yaw_sigma=0.15):
+    """Egos described RELATIVE to the raceline -- arc length s0, lateral offset d, heading offset dyaw, speed v -- so that a fleet can be
+    moved along it (poses_along).  Returns a dict of [n] arrays."""
+    rng = np.random.default_rng(seed)
+    xy = np.asarray(raceline)[:, :2]
+    total = np.hypot(np.diff(xy[:, 0]), np.diff(xy[:, 1])).sum()
+    return dict(s0=rng.uniform(0.0, total, n), d=rng.normal(0, lat_sigma, n), dyaw=rng.normal(0, yaw_sigma, n), v=rng.uniform(0.5, 6.0, n))
+
+
+def poses_along(raceline, fleet, advance=0.0):
+    """[n, 4] fp64 poses of make_line_egos' fleet after every vehicle moved `advance` metres along the (closed) raceline, keeping its lateral
+    and heading offsets: what a simulator hands the planner a few control steps later."""
+    rl = np.asarray(raceline)
+    xy = rl[:, :2]
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(xy[:, 0]), np.diff(xy[:, 1])))])
+    at = np.mod(fleet["s0"] + advance, s[-1])
+    x, y = np.interp(at, s, xy[:, 0]), np.interp(at, s, xy[:, 1])
+    psi = np.interp(at, s, np.unwrap(rl[:, 3]))
+    return np.ascontiguousarray(np.column_stack([x - fleet["d"] * np.sin(psi), y + fleet["d"] * np.cos(psi), psi + fleet["dyaw"], fleet["v"]]))

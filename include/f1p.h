@@ -360,6 +360,16 @@ int f1p_lattice_debug_queue(f1p_ctx* ctx, int32_t* entries_per_ego, int32_t E);
  * mixed plans (the running bound of DESIGN.md 5c that widens the candidate's bracket when it exceeds the calibrated margin); the tests
  * check bound >= |cost32 - cost64| candidate by candidate. */
 int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound);
+/* Dispatch order of the mixed schedule's candidate kernel (round 5).  1 (default): every plan of >= 1024 egos leaves one flag per ego -- its
+ * cheapest candidates collided, so its workgroup took the long path -- and the next plan of the same batch size starts those egos' workgroups
+ * first, where their longer lifetime overlaps the others instead of ending the kernel (a control loop meets the same obstacle in consecutive
+ * plans).  0: ego order.  Outputs are identical either way; the order only moves time. */
+int f1p_lattice_set_order(f1p_ctx* ctx, int32_t heavy_first);
+/* MEASUREMENT HOOK (round 5): d_pass [E][4] i32 (device pointer, nullable; the caller zeroes it) receives, per ego of the following mixed
+ * plans, what the candidate kernel's LAZY station pass looked at: [0] candidates whose positions were integrated and looked up (certain
+ * hits included -- f1p_lattice_debug_queue only counts what reaches the fp64 refinement), [1] passes that ran lane-per-candidate,
+ * [2] rounds of the pass, [3] candidates that took the SECOND look (every station against the real bitmap).  The pass itself is unchanged (bench.py's scene_sweep reads it). */
+int f1p_lattice_debug_pass(f1p_ctx* ctx, int32_t* d_pass);
 
 /* Pipelining of one mixed-schedule plan: the ego batch is cut into `chunks` contiguous chunks whose kernels (prologue, candidate
  * filter, fp64 refinement, selection) run on two internal streams, the second one stage behind the first, so one chunk's
