@@ -364,9 +364,9 @@ int f1p_host_alloc(f1p_ctx* ctx, void** hptr, size_t bytes) {
 int f1p_host_free(f1p_ctx* ctx, void* hptr) {
     F1P_ENTER(ctx);
     if (hptr) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));             // a kernel may still be writing into it (zero-copy outputs).  FIRST: a failed sync returns with the block still tracked
         for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
             if (ctx->host_blocks[i].base == (char*)hptr) { ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i); break; }
-        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));             // a kernel may still be writing into it (zero-copy outputs)
         F1P_HIP(ctx, hipHostFree(hptr));
     }
     return F1P_OK;
@@ -698,7 +698,13 @@ static int cl_begin(f1p_ctx* ctx, const double* d_prev_caller, int E, int S, boo
         F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (auto& b : ctx->d_cl_theta) { if (b) (void)hipFree(b); b = nullptr; }
         ctx->cl_bytes = 0; ctx->cl_valid = false;
-        for (auto& b : ctx->d_cl_theta) F1P_HIP(ctx, hipMalloc((void**)&b, need));
+        for (auto& b : ctx->d_cl_theta) {
+            if (hipMalloc((void**)&b, need) != hipSuccess) {         // both buffers or none (a failed second allocation left the first behind with cl_bytes = 0)
+                (void)hipGetLastError();
+                for (auto& q : ctx->d_cl_theta) { if (q) (void)hipFree(q); q = nullptr; }
+                return set_error(ctx, F1P_ENOMEM, "closed-loop heading buffers: out of device memory");
+            }
+        }
         ctx->cl_bytes = need;
     }
     if (ctx->cl_valid && (ctx->cl_E != E || ctx->cl_S != S)) ctx->cl_valid = false;   // another batch shape: a first plan again
@@ -731,6 +737,9 @@ static int lattice_plan_dev_cl(f1p_ctx* ctx, const double* d_poses, const double
                                int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
                                double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32) {
     ClosedLoop cl;
+    // the configuration is validated BEFORE cl_begin touches the kept headings (an invalid cfg -- a huge n_stations -- used to free
+    // them and fail in hipMalloc instead of returning F1P_EINVAL); lattice_plan_dev_impl validates again, with the output pointers
+    if (const int rcv = validate_lattice(ctx, cfg, E, d_goals == nullptr, true)) return rcv;
     if (cfg && E > 0 && cfg->n_stations >= 2) {
         const int rc0 = cl_begin(ctx, d_prev_theta, E, cfg->n_stations, cfg->cand_count == 0, &cl);
         if (rc0) return rc0;
@@ -776,12 +785,13 @@ int f1p_lattice_set_closed_loop(f1p_ctx* ctx, int32_t on) {
     if (!ctx) return F1P_EINVAL;
     ctx->lattice_closed_loop = on != 0;
     ctx->cl_valid = false;                                         // (re)armed: the next plan is a first plan
+    ctx->step_chain = false;
     return F1P_OK;
 }
 
 int f1p_lattice_closed_loop_state(f1p_ctx* ctx, const double** d_prev_theta, int32_t* E, int32_t* S) {
     if (!ctx) return F1P_EINVAL;
-    const bool v = ctx->lattice_closed_loop && ctx->cl_valid;
+    const bool v = (ctx->lattice_closed_loop || ctx->step_chain) && ctx->cl_valid;   // (the headings the next plan -- or, for a step chain, the next STEP -- would use)
     if (d_prev_theta) *d_prev_theta = v ? ctx->d_cl_theta[ctx->cl_cur] : nullptr;
     if (E) *E = v ? ctx->cl_E : 0;
     if (S) *S = v ? ctx->cl_S : 0;
@@ -932,13 +942,21 @@ int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f
     if (own_speed) k_speed = (double*)pinned_device_ptr(ctx, h_speed, 8 * e);
     if (own_status) k_status = (int32_t*)pinned_device_ptr(ctx, h_status, 4 * e);
     if (!k_poses || !k_steer || !k_speed || (status && !k_status)) return set_error(ctx, F1P_ESTATE, "page-locked step block is not device-visible");
-    if (!ctx->lattice_closed_loop) { ctx->lattice_closed_loop = true; ctx->cl_valid = false; }   // a step IS a link of a closed loop
+    // a step IS a link of a closed loop -- for the duration of the step.  The mode the caller set with f1p_lattice_set_closed_loop is restored
+    // afterwards (the step used to arm it for good, and a later f1p_lattice_plan_* with prev_theta == NULL and the same batch shape
+    // silently picked up -- and overwrote -- the step chain's headings).  The chain's headings stay in the context between steps.
+    const bool was_armed = ctx->lattice_closed_loop;
+    if (!was_armed && !ctx->step_chain) ctx->cl_valid = false;      // the first step of a chain of its own
+    ctx->lattice_closed_loop = true;
     ClosedLoop cl;
-    if ((rc = cl_begin(ctx, nullptr, E, S, true, &cl))) return rc;
-    rc = launch_lattice(ctx, LATTICE_FULL, k_poses, nullptr, cl.prev, E, cfg, nullptr, nullptr, k_steer, k_speed, d_idx, nullptr, k_status, d_near,
-                        d_traj, nullptr, nullptr, nullptr, cl.out, d_pose_copy);
+    rc = cl_begin(ctx, nullptr, E, S, true, &cl);
+    if (rc == F1P_OK)
+        rc = launch_lattice(ctx, LATTICE_FULL, k_poses, nullptr, cl.prev, E, cfg, nullptr, nullptr, k_steer, k_speed, d_idx, nullptr, k_status, d_near,
+                            d_traj, nullptr, nullptr, nullptr, cl.out, d_pose_copy);
+    ctx->lattice_closed_loop = was_armed;
     if (rc) return rc;
     cl_commit(ctx, cl, E, S);
+    ctx->step_chain = !was_armed;
     ctx->step_traj_E = keep_traj ? E : 0; ctx->step_traj_S = S;
     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (own_steer) memcpy(steer, h_steer, 8 * e);

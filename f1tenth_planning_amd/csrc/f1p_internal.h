@@ -96,6 +96,7 @@ struct f1p_ctx {
     size_t order_bytes = 0;
     int order_E = 0;                   // batch size the heavy flags belong to
     int lattice_order = 1;             // f1p_lattice_set_order: 1 = heavy egos first (default), 0 = ego order
+    bool step_chain = false;           // the kept headings belong to a chain of f1p_lattice_step_batch calls made with closed-loop mode off
     bool mix_q_dirty_prev = false;
     bool mix_q_dirty = false;          // a mixed plan failed between its filter and its selection kernel: zero the queue counter first
     bool lattice_profile = false, lattice_profile_valid = false;   // HIP events between the three kernels of the mixed schedule

@@ -1161,6 +1161,27 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     return o;
 }
 
+// Every-station look-ups, a station within the band of a cell edge (round 5).  The fp64 position is then in THIS cell or in the one across
+// that edge (the band is the bound of |pos32 - pos64|, below half a cell for the callers), and the verdict only depends on which when the
+// cells differ in occupancy: the neighbours across the near edge(s) -- one, or three at a corner -- are looked up; true = they all agree with
+// the station's own cell (oc) and lie on the tile, i.e. the station is decided after all.  Such a station used to decide nothing: 2.4e-3 of
+// the stations, one every-station pass in nine ended UNSURE and went to fp64.
+__device__ __forceinline__ bool near_edge_neighbours_agree(const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h,
+                                                           int lx, int ly, float rx, float ry, float edge, float edge_hi, uint32_t oc) {
+    const int dx = rx < edge ? -1 : (rx > edge_hi ? 1 : 0), dy = ry < edge ? -1 : (ry > edge_hi ? 1 : 0);
+    bool ok = true;
+    auto agrees = [&](int cx, int cy) {
+        ok &= ((unsigned)cx < tile_w) & ((unsigned)cy < tile_h);
+        const unsigned ux = min((unsigned)cx, tile_w), uy = min((unsigned)cy, tile_h);
+        const unsigned a2 = __umul24(uy, pitch_bytes) + ((ux >> 2) & ~7u);
+        ok &= __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(tile + a2 + 4u), ux, 1u) == oc;   // the bitmap word of the (clearance, bitmap) pair
+    };
+    if (dx != 0) agrees(lx + dx, ly);
+    if (dy != 0) agrees(lx, ly + dy);
+    if (dx != 0 && dy != 0) agrees(lx + dx, ly + dy);
+    return ok;
+}
+
 // The collision state of ONE clothoid in f32: station positions by integrated pieces, one look-up per tested station against the ego's
 // LDS tile.  Runs for the few candidates per ego that k_lattice_filter3's rounds select.  (Look-ups straight from global memory -- no
 // tile -- were measured: ~1 000 cycles per dependent look-up, 14.7 k cycles per pass, and 50 of them for an ego that tests every
@@ -1227,7 +1248,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
             fl = (hitbit << 1) | nc;
         } else {
             const bool off = (lx != (int)lxc) | (ly != (int)lyc);          // on the guard: the fp64 path reads the global bitmap
-            fl = (near | off) ? 1u : (oc << 1);
+            fl = (near | off) ? 1u : (oc << 1);                            // (the lane-per-candidate form keeps the plain band: the neighbour look-ups of near_edge_neighbours_agree cost this chain its registers)
         }
         flags |= fl;
     };
@@ -1364,7 +1385,14 @@ __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, fl
     const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
     bool undecided, hitc;
     if (!exact_all) { undecided = nc != 0u; hitc = !near && (nc & oc) != 0u; }
-    else { const bool off = (lx != (int)lxc) | (ly != (int)lyc); undecided = near | off; hitc = !undecided && oc != 0u; }
+    else {
+        const bool off = (lx != (int)lxc) | (ly != (int)lyc);
+        bool amb = near;                                            // the fp64 position may lie in another cell than the f32 one
+        if (edge < 0.5f && __ballot(mine & near & !off) != 0ull) {    // (wave-uniform branch: most passes have no station within the band of a cell edge)
+            if (near & !off) amb = !near_edge_neighbours_agree(tile, pitch_bytes, tile_w, tile_h, lx, ly, rx, ry, edge, edge_hi, oc);
+        }
+        undecided = amb | off; hitc = !undecided && oc != 0u;
+    }
     const bool nanpos = !(x == x) | !(y == y);                     // a NaN position converts to cell 0: nothing was decided
     const bool any_nan = __ballot(mine & nanpos) != 0ull;
     const bool hit_sure = __ballot(mine & hitc) != 0ull && !any_nan;
@@ -1405,12 +1433,12 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     const int nl = cfg.n_lookahead, S = cfg.n_stations;
     double* cen_x = s_cen[wave]; double* cen_y = cen_x + F1P_MAX_LOOKAHEADS; double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
     int* cen_ok = s_ok[wave];
-    // the ego's slot in the candidate kernel's dispatch order (MixArgs::perm): requested first, stored with the record
+    // the ego's slot in the candidate kernel's dispatch order (MixArgs::perm): the flag is requested with the first loads, the returning atomic
+    // is issued BEHIND the wave's last load (loads and returning atomics come back in order: issued first, the atomic's two round trips stood in
+    // front of the pose -- prologue + 1.2 us) and its slot is stored with the record, after the goal frames' arithmetic
     int o_slot = 0;
-    if (mx.perm && lane == 0) {
-        const unsigned r = (unsigned)e % F1P_MIX_OREG;
-        o_slot = mx.heavy[e] ? (int)atomicAdd(&mx.ocnt[r * 64u], 1u) : mx.perm_rs - 1 - (int)atomicAdd(&mx.ocnt[r * 64u + 32u], 1u);
-    }
+    int o_heavy = 0;
+    if (mx.perm && lane == 0) o_heavy = mx.heavy[e];
 #ifdef F1P_PRO_PHASES
     long long pph[10]; int npp = 0;
 #define F1P_PPH() do { __builtin_amdgcn_s_waitcnt(0); pph[npp++] = clock64(); } while (0)
@@ -1491,6 +1519,10 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     F1P_PPH();
+    if (mx.perm && lane == 0) {
+        const unsigned r = (unsigned)e % F1P_MIX_OREG;
+        o_slot = o_heavy ? (int)atomicAdd(&mx.ocnt[r * 64u], 1u) : mx.perm_rs - 1 - (int)atomicAdd(&mx.ocnt[r * 64u + 32u], 1u);
+    }
     sn_t = shfl_d(sn_t, 0); cs_t = shfl_d(cs_t, 0);
     if (a.prev_theta) {
 #pragma unroll
@@ -1790,6 +1822,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     }
                 }
                 [[maybe_unused]] float xe = 0.f, ye = 0.f;
+                bool bound_known = false;                         // (wave-uniform) a FREE candidate of this wave bounds T although the workgroup's T is not known yet
                 // look 0: the clearance-mode pass (the every-station pass for an ego that stands in a cell that is not clear); look 1: the every-station
                 // pass for what look 0 left undecided.  ONE loop body for both (not unrolled): a second inlined copy of the passes cost the kernel its
                 // 64-register budget.
@@ -1809,7 +1842,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     // a few selected candidates: the whole wave takes them one at a time (lane = test point).  (Test hook: with every state wanted, odd
                     // egos take the cooperative pass for all their candidates, even egos the lane-per-candidate pass -- tests/test_gpu_lattice_mixed.py
                     // checks the claims of both)
-                    coop = F1P_MIX_MACRO && nt <= 64 && (__builtin_popcountll(m) <= ((look == 1 && !thr_is_T) ? 2 * F1P_MIX_COOP_MAX : F1P_MIX_COOP_MAX) || (look == 0 && all_states && (e & 1)));
+                    coop = F1P_MIX_MACRO && nt <= 64 && (__builtin_popcountll(m) <= ((look == 1 && !(thr_is_T | bound_known)) ? 2 * F1P_MIX_COOP_MAX : F1P_MIX_COOP_MAX) || (all_states && (e & 1)));
 #endif
                     if (coop) {
                         PassPlan pl;
@@ -1834,11 +1867,18 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                         const bool again = mine && ns == F1P_ST_UNSURE && !ex;
                         if (again) ns = F1P_ST_PENDING2;
                         if (coop | thr_is_T) m2 |= __ballot(again);
+                        else {
+                            // the first look at everything left (T unknown): a FREE candidate of THIS wave already bounds T from above -- the
+                            // candidates are interleaved over the waves, so its hi is close to T -- and the wave's undecided ones below it take
+                            // their second look in this round instead of waiting for the reduction (one round less for an ego behind an obstacle)
+                            const float t_w = f32_from_order_key(wave_min_key(f32_order_key((mine && ns == F1P_ST_FREE) ? c_hi[c - c0] : INF)));
+                            if (t_w < INF) { m2 |= __ballot(again && !(lo > t_w)); bound_known = true; }
+                        }
                         // A wave takes at most F1P_MIX_COOP_MAX second looks per round, the candidates with the lowest lo first: a FREE one among them
                         // lowers T, and what then lies above it is never looked at (the rest stays PENDING2 for the next round).  Many of them
                         // -- an ego boxed in: nothing FREE anywhere -- go through the lane-per-candidate form at once.
                         const int n2 = __builtin_popcountll(m2);
-                        if (n2 > F1P_MIX_COOP_MAX && n2 <= F1P_MIX_COOP_MAX_X && thr_is_T && !all_states) {   // (T unknown: every one of them is needed, now)
+                        if (n2 > F1P_MIX_COOP_MAX && n2 <= F1P_MIX_COOP_MAX_X && (thr_is_T | bound_known) && !all_states) {   // (no bound of T at all: every one of them is needed, now)
                             unsigned long long pick = 0ull, rem = m2;
 #pragma unroll
                             for (int i = 0; i < F1P_MIX_COOP_MAX; ++i) {

@@ -314,7 +314,10 @@ class LatticePlanner():
         """Batched closed loop: every plan_batch / step_batch keeps its winners' headings on the device and the next one (same batch
         shape, prev_theta=None) uses them as the previous path of get_similarity_cost (lattice_planner.py:287-296) -- what the single-
         vehicle plan() does on the host with self.prev_traj.  (Re)arming forgets the previous path."""
+        self._closed_loop = bool(on)
         self._context().lattice_set_closed_loop(on)
+        if getattr(self, "_mc", None) is not None:           # the multi-GPU replicas too (ADVICE r4: they used to plan with the term silently zero)
+            self._mc.lattice_set_closed_loop(on)
 
     def step_batch(self, poses, waypoints=None, keep_traj=False):
         """One control step for E vehicles: poses [E, 4] -> dict(steer, speed, status) (page-locked arrays owned by the context, valid
@@ -339,6 +342,8 @@ class LatticePlanner():
                 self._mc.close()
             self._mc = MultiContext(None if key == "all" else key)
             self._mc_key, self._mc_map = key, None
+            if getattr(self, "_closed_loop", False):          # armed before the replicas existed
+                self._mc.lattice_set_closed_loop(True)
         want = (self._map_gen, self._inflate, self._foot)
         if self._map is not None and self._mc_map != want:
             self._mc.set_grid(*self._map)                    # (clears inflation and footprint on every replica)

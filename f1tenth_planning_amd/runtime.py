@@ -713,6 +713,16 @@ class MultiContext:
     def sync(self):
         self._each(lambda c, g: c.sync())
 
+    def lattice_set_closed_loop(self, on=True):
+        """closed-loop mode on every replica: the ego ranges of a batch are stable, so each context keeps the headings of ITS
+        egos' winners and the chain equals the single-context chain"""
+        self._each(lambda c, g: c.lattice_set_closed_loop(on))
+
+    def lattice_closed_loop_prev(self):
+        """the headings the next closed-loop plan would use, concatenated in ego order (None when no replica holds any)"""
+        parts = [p for p in self._each(lambda c, g: c.lattice_closed_loop_prev()) if p is not None]
+        return np.concatenate(parts, axis=0) if parts else None
+
     # ---- batched planners: ego-sharded -----------------------------------------------------------------------------
     def _sharded(self, n_items, call):
         """call(ctx, lo, hi) -> dict of arrays with leading dimension hi - lo; concatenated over the ego ranges"""

@@ -304,8 +304,9 @@ int f1p_lattice_closed_loop_state(f1p_ctx* ctx, const double** d_prev_theta, int
 
 /* One closed-loop control step for E egos -- what a simulator / vehicle fleet calls once per tick (the loop of
  * examples/control/pure_pursuit.py:35-58 with LatticePlanner.plan, lattice_planner.py:174-214, for E vehicles): poses [E][4] in,
- * steer [E], speed [E] and (nullable) status [E] out.  It always runs in closed-loop mode (turns it on): the previous plan's headings
- * are the similarity term's previous path and never leave the device; best_traj is NOT returned (keep_traj = 1 keeps the winners'
+ * steer [E], speed [E] and (nullable) status [E] out.  It always runs as a link of a closed loop: the previous STEP's headings
+ * are the similarity term's previous path and never leave the device (round 5: the mode is scoped to the step -- a context whose caller never
+ * called f1p_lattice_set_closed_loop(ctx, 1) keeps the chain between steps, and its f1p_lattice_plan_* calls neither read nor overwrite it); best_traj is NOT returned (keep_traj = 1 keeps the winners'
  * rows in HBM, f1p_lattice_fetch_traj copies them out on request: [E][S][4] fp64).  No copy is submitted in either direction: the
  * kernels read the poses from, and store the results into, page-locked host memory -- the caller's own arrays when they are
  * page-locked (f1p_host_alloc / hipHostRegister), a block of the context otherwise.  Device-sampled goals, whole egos

@@ -152,6 +152,36 @@ def test_planner_classes_accept_devices():
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
 
 
+def test_closed_loop_reaches_the_multi_gpu_replicas():
+    """LatticePlanner.set_closed_loop armed only the single context, so plan_batch(devices=...) planned with the similarity
+    term silently zero.  The chain over two replicas (stable ego ranges, each keeps its own egos' headings) equals the single-context
+    chain, armed before or after the replicas exist."""
+    from f1tenth_planning_amd.planning.lattice_planner.lattice_planner import LatticePlanner
+    n_dev = _abi.load_library().f1p_device_count()
+    devices = list(range(n_dev)) if n_dev >= 2 else [0, 0]
+    rl = synth.make_raceline(seed=0)
+    fleet = synth.make_line_egos(rl, 211, seed=4)
+    def make():
+        lp = LatticePlanner(waypoints=rl)
+        lp.configure(weights=(0.25, 0.25, 0.25, 0.25))                                # the similarity term carries weight
+        return lp
+    one, many, late = make(), make(), make()
+    one.set_closed_loop(True); many.set_closed_loop(True)
+    late.plan_batch(synth.poses_along(rl, fleet, 0.0), devices=devices)          # the replicas exist before the loop is armed
+    late.set_closed_loop(True)
+    plain = None
+    for k in range(3):
+        poses = synth.poses_along(rl, fleet, 0.08 * k)
+        a = one.plan_batch(poses)
+        b = many.plan_batch(poses, devices=devices)
+        c = late.plan_batch(poses, devices=devices)
+        for key in a:
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"plan {k} {key}")
+            np.testing.assert_array_equal(a[key], c[key], err_msg=f"plan {k} {key} (armed late)")
+        plain = make().plan_batch(poses)
+    assert (plain["best_cost"] != a["best_cost"]).any()                            # the similarity term is live in the chain
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_real_rccl_ranks(world):
     if _abi.load_library().f1p_device_count() < world:

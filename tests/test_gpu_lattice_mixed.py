@@ -132,10 +132,81 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         # candidate (measured: >= 140x above the actual error; it is a worst-case first-order bound)
         assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())
         assert np.median(bound[both] / np.abs(c64[both])) < 1e-3                   # ... without being vacuous
-        assert 0.02 < ((st == 2) | (st >= 4)).mean() < 0.35                        # the uncertain share stays small (r = 2 clearance, the default since round 3: ~0.27; r = 1: ~0.13)
+        assert ((st == 2) | (st >= 4)).mean() < 0.35                               # the uncertain share stays small (r = 2 clearance, round 3: ~0.27; with round 5's second look far less)
         for b in out + [d_all, d_c32, d_st, d_bd, d_poses] + ([prev] if prev is not None else []):
             b.free()
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
+
+
+def test_second_look_and_dispatch_order_on_obstacle_maps(scene):
+    """round 5: discs of occupied cells on the raceline (the cheapest candidates of the egos behind one collide, the ones that skirt it meet
+    cells that are not clear).  (a) the filter's claims hold with the second look in play: FREE is free and HIT collides in fp64, on every
+    candidate (debug hook: both the cooperative and the lane-per-candidate form); (b) a moving closed-loop chain of 1500 egos -- large enough
+    for the heavy-first dispatch order -- is bit-identical with the order on, off, and to the all-fp64 kernel with the previous path handed
+    over; (c) the second look does happen, and what reaches the fp64 refinement stays a few entries per ego"""
+    from f1tenth_planning_amd.runtime import Context
+    rl, img, origin = scene
+    res = 0.058
+    C, S = 256, 50
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    for spacing, radius, lateral in ((10.0, 0.30, 0.0), (4.0, 0.18, 0.35)):
+        img_o, cen = synth.stamp_obstacles(img, origin, res, rl, spacing=spacing, radius=radius, lateral=lateral)
+        assert (img_o != img).sum() > 500 and len(cen) > 20
+        with Context(0) as a, Context(0) as b, Context(0) as f:
+            for c in (a, b, f):
+                c.set_waypoints(rl); c.set_grid(img_o, res, origin, 206)
+            # (a) claims
+            E = 700
+            poses = synth.make_egos(rl, E, seed=int(spacing), pos_sigma=0.35)
+            d_poses = a.to_device(poses)
+            out = [a.alloc(8 * E), a.alloc(8 * E), a.alloc(4 * E), a.alloc(8 * E), a.alloc(4 * E), a.alloc(4 * E), a.alloc(8 * E * S * 4)]
+            d_all, d_c32, d_st = a.alloc(8 * E * C), a.alloc(4 * E * C), a.alloc(4 * E * C)
+            a.set_grid(img, res, origin, 206)                                                   # the same egos without the obstacles: the share f32 cannot decide anyway
+            a.lattice_set_mode(2, d_c32, d_st)
+            a.lattice_plan_dev(d_poses, E, cfg, *out)
+            st_plain = d_st.download(np.int32, (E, C))
+            a.set_grid(img_o, res, origin, 206)
+            a.lattice_set_mode(0)
+            a.lattice_plan_dev(d_poses, E, cfg, *out, d_all_cost=d_all)
+            c64 = d_all.download(np.float64, (E, C))
+            a.lattice_set_mode(2, d_c32, d_st)
+            a.lattice_plan_dev(d_poses, E, cfg, *out)
+            a.lattice_set_mode(1)
+            st = d_st.download(np.int32, (E, C))
+            fin = np.isfinite(c64)
+            assert not ((st == 0) & ~fin).any(), "a FREE candidate collides in fp64"
+            assert not ((st == 1) & fin).any(), "a HIT candidate is collision-free in fp64"
+            assert (st == 1).mean() > 0.02 and (st == 0).mean() > 0.3 and (st == 4).sum() == 0     # obstacles are met; nothing stays pending under the hook (5, 40..45: untrusted f32 fits)
+            und, und_plain = ((st == 2) | (st >= 4)) & fin, (st_plain == 2) | (st_plain >= 4)
+            # the second look decides most of what the clearance map could not: the obstacles add little to the undecided share (odd egos: the
+            # cooperative form with the neighbour look-ups at cell edges; even egos: the lane-per-candidate form, one pass in nine undecided)
+            assert und.mean() < und_plain.mean() + 0.08, (und.mean(), und_plain.mean())
+            assert und[1::2].mean() < und_plain[1::2].mean() + 0.03, (und[1::2].mean(), und_plain[1::2].mean())
+            # (b) + (c): a moving chain
+            E = 1500
+            fleet = synth.make_line_egos(rl, E, seed=3)
+            a.lattice_set_closed_loop(True); b.lattice_set_closed_loop(True); b.lattice_set_order(False)
+            f.lattice_set_mode(0)
+            prev = None
+            for k in range(5):
+                p = synth.poses_along(rl, fleet, 0.08 * k)
+                d_pass = a.to_device(np.zeros((E, 4), np.int32))
+                a.lattice_debug_pass(d_pass if k == 4 else None)
+                ga = a.lattice_plan(p, cfg); nq = a.lattice_debug_queue(E)
+                gb = b.lattice_plan(p, cfg)
+                want = f.lattice_plan(p, cfg, prev_theta=prev)
+                for n in NAMES:
+                    np.testing.assert_array_equal(ga[n], want[n], err_msg=f"plan {k} {n} (heavy egos first)")
+                    np.testing.assert_array_equal(gb[n], want[n], err_msg=f"plan {k} {n} (ego order)")
+                prev = want["best_traj"][:, :, 2].copy()
+            a.lattice_debug_pass(None)
+            ps = d_pass.download(np.int32, (E, 4))
+            assert ps[:, 3].sum() > E // 10 and ps[:, 2].max() >= 2 and (ps[:, 2] >= 1).all()
+            assert 1.0 <= nq.mean() < 6.0 and (want["status"] == 0).mean() > 0.8
+            # a different batch size forgets the flags and still plans the same
+            p2 = synth.poses_along(rl, fleet, 0.5)[:1100]
+            a.lattice_set_closed_loop(False)
+            np.testing.assert_array_equal(a.lattice_plan(p2, cfg)["best_cost"], f.lattice_plan(p2, cfg)["best_cost"])
 
 
 def test_lazy_station_pass_agrees_with_the_eager_one(ctx, scene):
@@ -157,7 +228,10 @@ def test_lazy_station_pass_agrees_with_the_eager_one(ctx, scene):
         ctx.lattice_set_mode(2, d_c, d_s)
         eager = ctx.lattice_plan(poses, cfg); n_eager = ctx.lattice_debug_queue(E)
         st_a = d_s.download(np.int32, (E + 1, C))[:E].copy()
-        np.testing.assert_array_equal(n_lazy, n_eager)
+        # (round 5: the two forms of the every-station look differ in what they can decide at a cell edge -- the cooperative one looks at the
+        # neighbour cells, the lane-per-candidate one does not -- so a candidate may reach the fp64 queue under one and not the other; the
+        # outputs below are identical regardless)
+        assert (n_lazy == n_eager).mean() > 0.9 and abs(float(n_lazy.mean()) - float(n_eager.mean())) < 0.3, ((n_lazy == n_eager).mean(), n_lazy.mean(), n_eager.mean())
         for k in lazy:
             np.testing.assert_array_equal(lazy[k], eager[k], err_msg=k)
         assert 1.0 <= n_lazy.mean() < 6.0 and (n_lazy >= 1).all()
@@ -165,7 +239,11 @@ def test_lazy_station_pass_agrees_with_the_eager_one(ctx, scene):
         ctx.lattice_plan(shifted, cfg)
         st_b = d_s.download(np.int32, (E + 1, C))[1:].copy()
         ctx.lattice_set_mode(1)
-        assert (st_a != st_b).mean() < 2e-3, float((st_a != st_b).mean())
+        # the two forms never contradict each other (FREE against HIT); since round 5 they differ in what they can decide: the cooperative form
+        # of the every-station look resolves stations at cell edges through the neighbour cells, the lane-per-candidate form leaves them UNSURE
+        assert not (((st_a == 0) & (st_b == 1)) | ((st_a == 1) & (st_b == 0))).any()
+        dec = (st_a < 2) & (st_b < 2)
+        assert dec.mean() > 0.5 and (st_a[dec] == st_b[dec]).all()
         assert ((st_a == 0).mean() > 0.2) and ((st_b == 0).mean() > 0.2)
         d_c.free(); d_s.free()
 
