@@ -150,6 +150,7 @@ class Ranks:
 
     def __init__(self):
         self.rccl_ok, self.rccl_hung, self.rccl_note = True, False, None
+        self.last_per_rank_s = None
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,6 +187,15 @@ class Ranks:
         t = torch.tensor([float(x)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(self, x):
+        """every rank's value of x, in rank order (a list of floats on every rank)"""
+        if not self.dist:
+            return [float(x)]
+        import torch
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, torch.tensor([float(x)], dtype=torch.float64))
+        return [float(t.item()) for t in out]
 
     def all_equal_int(self, v):
         """True when every rank holds the same integer"""
@@ -277,6 +287,7 @@ def timed_region(rk, ctx, step, warmup, steps):
     kernel_ms_total = ctx.timer_end()                       # synchronises the stream
     ctx.sync()
     elapsed = time.perf_counter() - t0
+    rk.last_per_rank_s = rk.gather(elapsed)                 # launch skew is the only thing ego sharding can lose: min / max over the ranks go into the line
     elapsed = rk.max(elapsed)
     rk.barrier()
     return elapsed, kernel_ms_total
@@ -561,7 +572,7 @@ def leg_kmpc_c4(rk, args, steps):
     return out
 
 
-def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True):
+def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True, device=0):
     """the headline workload (E x C x S, steady state of a closed loop, default schedule) on scenes it was NOT tuned on.
       centred       today's bench scene (sigma 0.3 m around the raceline, nothing inside the corridor)
       wall_hugging  sigma 0.9 m of a 1.1 m half-width corridor: many egos next to (or inside) a wall
@@ -592,7 +603,7 @@ def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes
     for name in names:
         im, pose_of = all_scenes[name]
         moving = "moving" in name
-        ctx = Context(0)
+        ctx = Context(device)
         try:
             ctx.set_waypoints(rl); ctx.set_grid(im, res, origin, 206)
             ctx.lattice_set_closed_loop(True)
@@ -830,6 +841,7 @@ def main_lattice(args):
                                  d_prev_theta=d_prev, d_all_cost=d_all_cost, d_all_traj=d_all_traj)
 
     elapsed, kernel_ms_total = timed_region(rk, ctx, step, args.warmup, args.steps)
+    per_rank_s = list(rk.last_per_rank_s or [elapsed])
 
     # outputs the parity gate and the other schedules are compared with: ONE more plan of the chain, whose previous path (the headings the
     # last timed plan left) is copied first so that every comparison below can hand it over explicitly
@@ -926,6 +938,11 @@ def main_lattice(args):
         audit["note"] = ("every audited plan (similarity term live): all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs "
                          "compared bit for bit; mismatching_egos must be 0")
 
+    # the headline workload on scenes it was NOT tuned on: wall-hugging egos, obstacles on the raceline, a moving fleet
+    scene_sweep = None
+    if rank == 0 and world == 1 and secondary and not (args.all_fp64 or args.prune or cand_sharded or args.only_timed) and E >= 512:
+        scene_sweep = leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, max(20, min(args.steps, 100)), device=rk.local_rank)
+
     env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
     if secondary and not cand_sharded and rk.rccl_ok:
@@ -970,8 +987,17 @@ def main_lattice(args):
                 # instruction mix (transcendentals at 8.3 cycles, everything else priced at the cheapest class: a lower bound of its time)
                 valu["frac_of_measured_f32_issue_peak"] = valu_tlanes / VALU_PEAK_F32_MEASURED
                 valu["measured_f32_issue_peak"] = VALU_PEAK_F32_MEASURED
-                if pmc.get("SQ_INSTS_VALU_TRANS"):
-                    trans = pmc["SQ_INSTS_VALU_TRANS"] / pmc["waves"]
+                # instruction classes of the kernel's own stream (gfx950's per-class counters; whatever they do not name -- min / max / compare /
+                # select / bit operations / DPP moves / readlane -- is "other")
+                cls = {k: pmc[n] / pmc["waves"] for k, n in (("add_f32", "SQ_INSTS_VALU_ADD_F32"), ("mul_f32", "SQ_INSTS_VALU_MUL_F32"), ("fma_f32", "SQ_INSTS_VALU_FMA_F32"),
+                                                              ("trans_f32", "SQ_INSTS_VALU_TRANS_F32"), ("cvt", "SQ_INSTS_VALU_CVT"), ("int32", "SQ_INSTS_VALU_INT32"),
+                                                              ("add_f64", "SQ_INSTS_VALU_ADD_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"), ("fma_f64", "SQ_INSTS_VALU_FMA_F64"),
+                                                              ("trans_f64", "SQ_INSTS_VALU_TRANS_F64"), ("int64", "SQ_INSTS_VALU_INT64")) if pmc.get(n) is not None}
+                if cls:
+                    cls["other"] = per_cand - sum(cls.values())
+                    valu["instr_classes_per_candidate"] = cls
+                if pmc.get("SQ_INSTS_VALU_TRANS_F32") is not None:
+                    trans = pmc["SQ_INSTS_VALU_TRANS_F32"] / pmc["waves"]
                     floor_cyc = (per_cand - trans) * VALU_CYC["fast"] + trans * VALU_CYC["trans"]
                     floor_ms = floor_cyc * (E * C / 64.0) / 1024.0 / 2.4e9 * 1e3
                     valu["trans_instr_per_candidate"] = trans
@@ -1085,9 +1111,44 @@ def main_lattice(args):
             "kmpc_c4": kmpc_c4,
             "two_plans_in_flight": two_in_flight,
             "audit": audit,
+            "scene_sweep": scene_sweep,
+            "per_rank_ms_per_step": {"min": min(per_rank_s) / args.steps * 1e3, "max": max(per_rank_s) / args.steps * 1e3, "ranks": len(per_rank_s),
+                                     "note": "wall time of the timed region on every rank / steps: ego sharding has no collective, so launch skew between the ranks is all it can lose"},
             "roofline": roofline,
             "blocked_egos": None if status is None else int((status == _abi.ST_ALL_BLOCKED).sum()),
         }
+        # every number README / DESIGN quote, as top-level scalars: the driver's record keeps top-level keys and truncates nested objects
+        def _g(d, *ks):
+            for k in ks:
+                if not isinstance(d, dict) or d.get(k) is None:
+                    return None
+                d = d[k]
+            return d
+        out.update({
+            "steady_state_ms_per_plan": _g(steady_state, "ms_per_step"), "first_plan_ms_per_plan": _g(first_plan, "ms_per_step"),
+            "every_station_ms": _g(every_station, "kernel_ms"), "every_station_value": _g(every_station, "candidate_steps_per_s_equivalent"),
+            "all_fp64_ms": _g(fp64, "kernel_ms"), "all_fp64_value": _g(fp64, "candidate_steps_per_s_equivalent"),
+            "branch_and_bound_ms": _g(bnb, "kernel_ms"),
+            "other_schedules_bit_identical": None if fp64 is None else bool(all(x is None or x["outputs_bit_identical_to_the_timed_plan"] for x in (fp64, bnb, every_station))),
+            "host_boundary_p50_ms": _g(lat, "p50_ms"), "host_boundary_f32_traj_p50_ms": _g(lat, "f32_best_traj", "p50_ms"),
+            "host_boundary_no_traj_p50_ms": _g(lat, "without_best_traj", "p50_ms"), "closed_loop_step_p50_ms": _g(lat, "closed_loop", "p50_ms"),
+            "config1_single_ego_p50_ms": _g(lat, "config1_single_ego", "p50_ms"),
+            "two_plans_in_flight_ms_per_plan": _g(two_in_flight, "ms_per_plan"),
+            "kernel_ms_prologue": _g(mixed_ms, "k_lattice_prologue"), "kernel_ms_filter3": _g(mixed_ms, "k_lattice_filter3"),
+            "kernel_ms_refine": _g(mixed_ms, "k_lattice_refine"), "kernel_ms_select": _g(mixed_ms, "k_lattice_select"),
+            "valu_instr_per_candidate": _g(valu, "valu_instr_per_candidate"), "valu_frac_of_issue_floor": _g(valu, "frac_of_issue_floor"),
+            "traffic_over_algorithmic_bytes": None if traffic is None else traffic / abytes,
+            "audit_mismatching_egos": _g(audit, "mismatching_egos"),
+            "kmpc_c4_streamed_ms": _g(kmpc_c4, "ms_per_plan"), "kmpc_c4_generated_ms": _g(kmpc_c4, "generated_in_kernel", "ms_per_plan"),
+            "kmpc_c4_roofline_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
+        })
+        if scene_sweep:
+            out.update({"scene_sweep_worst_vs_centred": max(v["vs_centred"] for v in scene_sweep.values()),
+                        "scene_sweep_all_bit_identical": bool(all(v["outputs_bit_identical_to_all_fp64"] for v in scene_sweep.values())),
+                        "scene_sweep_oracle_mismatches": int(sum(v["oracle"]["best_idx_mismatches"] for v in scene_sweep.values())),
+                        "scene_sweep_audit_mismatching_egos": int(sum(v["audit"]["mismatching_egos"] for v in scene_sweep.values()))})
+            for nm, v in scene_sweep.items():
+                out["scene_" + nm + "_ms_per_plan"] = v["ms_per_plan"]
         if not args.no_cpu_baseline and not cand_sharded:
             from oracle import oracle   # the checker / CPU baseline leg only
             nthr = oracle.max_threads()

@@ -91,7 +91,7 @@ int launch_grid_edt(f1p_ctx* ctx, int cap, uint32_t thr2, float* d_dist_img, uin
 
 // CLEARANCE map of the active collision bitmap (ctx->d_bits): bit = 1 where the centre of the cell is within `dist_cells` of the
 // centre of an occupied (or out-of-image) cell.  The f32 lattice filter tests one station in 2 r + 1 against it: a station in a
-// cell whose bit is 0 proves the r stations before and after it collision-free.  Rebuilt when the bitmap or the
+// cell whose bit is 0 proves the r stations before and after it collision-free (LABNOTES.md 5a).  Rebuilt when the bitmap or the
 // distance changes; a map built for a larger distance (up to 1.3 x) is reused -- it is only more conservative.
 int ensure_clear_map(f1p_ctx* ctx, double dist_cells) {
     if (!ctx->has_grid || !(dist_cells > 0.0) || dist_cells > 4096.0) return F1P_EINVAL;

@@ -191,7 +191,7 @@ struct MixArgs {
     int32_t* dbg_pass;            // [E][4] measurement hook (nullable): candidates the station pass looked at, lane-per-candidate passes, rounds, second looks
 };
 
-// ek0 / edk / eLrel: a-priori bounds of |k0 - k0_64|, |dk - dk_64| and |L - L_64| / L for THIS candidate
+// ek0 / edk / eLrel: a-priori bounds of |k0 - k0_64|, |dk - dk_64| and |L - L_64| / L for THIS candidate (LABNOTES.md 5c)
 struct Fit32 { float k0, dk, L; bool ok; int why; float ek0, edk, eLrel; };
 
 // Clothoid.G1Hermite(0,0,0,x,y,theta) in f32: the structure of g1_fit (published guess, one quadrature pass, degree-5 Taylor
@@ -256,7 +256,7 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     f.L = L; f.k0 = (delta - A) * iL; f.dk = 2.0f * A * (iL * iL);
     f.ok = c40 & c41 & c42 & c43 & c44 & c45;
     f.why = !c40 ? 40 : (!c41 ? 41 : (!c42 ? 42 : (!c43 ? 43 : (!c44 ? 44 : 45))));   // the first test that failed (debug hook)
-    // ---- a-priori error of THIS fit against the fp64 fit of the same goal (u = 2^-24 = 6e-8) ----------------------------
+    // ---- a-priori error of THIS fit against the fp64 fit of the same goal (LABNOTES.md 5c; u = 2^-24 = 6e-8) ----------------------------
     //   node phase [rev]: coefficient and fma roundings <= 4 u P / 2 pi with P = |A0| + |delta - A0| + |phi0| [rad]; v_sin / v_cos: 2.1 u
     //   absolute (EXHAUSTIVE over |x| <= 8 rev, profiles/r03_hw_f32_primitive_errors.txt)  =>  each node value within (2.1 + 4 P) u;
     //   a moment = sum_j (w u^k)_j {cos, sin}_j with sum_j |w u^k| <= 1, 16 fma roundings        =>  e_m <= (18.1 + 4 P) u  (24 + 4 P used)
@@ -380,7 +380,7 @@ __device__ __forceinline__ Filt32 station_loop_f32(const Fit32& f, const F1P_LDS
     return o;
 }
 
-// The same with the CLEARANCE map: `tile` (LDS offset 0) holds, per cell, "the centre of an occupied or off-map cell
+// The same with the CLEARANCE map (LABNOTES.md 5a): `tile` (LDS offset 0) holds, per cell, "the centre of an occupied or off-map cell
 // lies within R ds_cap + (sqrt 2 + 1) cells of this cell's centre"; the real bitmap's tile follows at byte offset `occ_off`.
 // Only stations R, 3R + 1, 5R + 2, ... (and one in the tail) are looked up.  A clear cell proves the R stations before and
 // after it free in fp64: they are within R ds <= R ds_cap of the tested one along the curve, and the + 1 cell absorbs the f32
@@ -1029,12 +1029,12 @@ struct Brk32 { float cost, lo, hi, ebound; int state; bool never_free; };
 
 // The band around a cell edge inside which a look-up of THIS candidate decides nothing: farther than the f32 POSITION error -- the
 // calibrated band (edge0 + edge1 L: 5-10x the measured end-point error, tools/mixed_endpoint_error.py) or, when larger, the candidate's
-// a-priori bound:
+// a-priori bound (LABNOTES.md 5c):
 //   heading error from the fit e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, midpoint phase and v_sin / v_cos (2.1 + 4 TH) u, S - 1
 //   accumulations u each, the one-piece series' remainder (below) per unit length (z = (kappa h)^2 <= 0.16, |b| <= 0.05),
 //   all times the arc length, in cells (the transform's own rounding: 2 u x 300 cells is inside edge0)
 // In the clearance mode a "clear" verdict proves the neighbouring stations free only while the f32 position of the tested station is
-// within the ONE cell of slack the clearance map was built with: a candidate whose band reaches 0.8 cells decides nothing
+// within the ONE cell of slack the clearance map was built with (LABNOTES.md 5a): a candidate whose band reaches 0.8 cells decides nothing
 // by its positions (the caller's never_free; ADVICE r3 -- never observed: the bound is three orders inside it for every trusted candidate).
 // Only the candidates that take the station pass need it (round 4: it used to be formed for all 256).
 template <int R>
@@ -1124,7 +1124,7 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * ep->inv_S), t4 = ep->w_sim * sim;
     o.cost = ((t1 + t2) + t3) + t4;
     // the bracket: the calibrated margin (rel * sum|terms| + abs, 30x the measured error) or, when larger, this candidate's own
-    // a-priori bound: first-order propagation of the fit's error bounds through the four cost terms
+    // a-priori bound (LABNOTES.md 5c): first-order propagation of the fit's error bounds through the four cost terms
     //   1/L: relative eLrel;  any kappa(s) = k0 + dk s, s <= L (s itself scales with L): e_kap = ek0 + L edk + |dk| L eLrel;
     //   max|kappa| and mean|kappa| (closed form: a station within e_kap of kappa = 0 on the other side of the sign change moves the
     //   sum by < 2 e_kap) both within e_kap;  theta(s) within e_th = L ek0 + L^2 edk / 2 + 2 TH eLrel, TH = |k0| L + |dk| L^2 / 2,
@@ -1514,7 +1514,8 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     if (lane == 0 && mx.dbg_cost32) for (int k = 0; k < 4; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 40 + k] = (float)lstat[k];
     if (lane == 0 && mx.dbg_cost32) for (int k = 0; k < 4; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 48 + k] = (float)(lat[k + 1] - lat[k]);
 #else
-    wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, nullptr, a.wbox, F1P_MAX_LOOKAHEADS);
+    // (host-supplied goals, round 5: no look-ahead pass -- the caller's [E][C][3] array IS the goal set; the candidate kernel reads it)
+    if (!a.goals) wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, 0, 1, cen_x, cen_y, cen_psi, cen_ok, s_first[wave], s_pairs[wave], nd, nullptr, a.wbox, F1P_MAX_LOOKAHEADS);
 #endif
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -1532,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     double* r_cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
     GoalFrame32* r_gf = reinterpret_cast<GoalFrame32*>(r_cen + 5 * (size_t)nl);
     // ---- goal frames: lane l = look-ahead row l (two passes beyond 64 rows never happen: F1P_MAX_LOOKAHEADS = 64) -------------------
-    if (lane < nl) {
+    if (lane < nl && !a.goals) {
         const int l = lane;
         GoalFrame32 g;
         g.cx = 0.0; g.cy = 0.0; g.nx = 0.0; g.ny = 0.0; g.gth = 0.f; g.ok = cen_ok[l];
@@ -1597,6 +1598,13 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
 
 // candidate_goal for a queue entry, from the ego's record in LDS: the SAME fp64 operations in the same order -- the per-row ones
 // (sincos of the path heading, the goal heading's remainder) were done once per row by k_lattice_prologue
+// candidate_goal's host-goal branch (lattice_device.h): the caller's row, feasible when all three values are finite
+__device__ __forceinline__ bool candidate_goal_host(const double* __restrict__ goals, int e, int C, int c, double& gx, double& gy, double& gth) {
+    const double* g = goals + ((size_t)e * C + c) * 3;
+    gx = g[0]; gy = g[1]; gth = g[2];
+    return isfinite(gx) && isfinite(gy) && isfinite(gth);
+}
+
 __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, int c, const volatile EgoRecHdr* h, const double* cen, int nl,
                                                    const GoalFrame32* gf, double& gx, double& gy, double& gth) {
     const int l = c / cfg.n_width, k = c - l * cfg.n_width;
@@ -1683,6 +1691,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     // candidates per wave one wave took them all, one after the other, while three waited at the barrier -- the tail of the kernel.
     auto cand_of = [&](int cb) { return cb + ((blockDim.x == 256 && cb + 256 <= c1) ? (int)(__umul24((unsigned)ptid, 29u) & 255u) : ptid); };   // (formed where needed: no register held for it)
     const bool all_states = DBG && mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
+    const bool collide_on = cfg.check_collision && a.has_grid;
 
     const float INF = __builtin_huge_valf();
 
@@ -1690,19 +1699,33 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 
     auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& ek0, float& edk, float& eL, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
         // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
-        const int l = (int)(((float)c + 0.5f) * ep->inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
-        const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
-        const bool gok = gf->ok != 0;
-        const double w = ((const F1P_LDS(double)*)wtab)[k];
-        gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+        bool gok, th_ok = true;
+        float gth32;
+        if (a.goals) {
+            // host-supplied goals (add_sample_function's return value, lattice_planner.py:57-70, 113-128): [E][C][3] fp64 in the ego frame, a non-
+            // finite row = infeasible.  Round 5: they used to take the one-kernel fallback filter from 320 egos and the all-fp64 kernel below
+            const double* g = a.goals + ((size_t)e * C + c) * 3;
+            const double g0 = g[0], g1 = g[1], g2 = g[2];
+            gok = (__builtin_fabs(g0) < HUGE_VAL) & (__builtin_fabs(g1) < HUGE_VAL) & (__builtin_fabs(g2) < HUGE_VAL);   // (NaN compares false)
+            gx = (float)g0; gy = (float)g1; gth32 = (float)g2;
+            th_ok = __builtin_fabs(g2) <= 7.0;                                  // a heading far outside (-pi, pi]: its f32 rounding is not in the fit's error bound -> fp64 decides
+        } else {
+            const int l = (int)(((float)c + 0.5f) * ep->inv_nw), k = c - l * cfg.n_width;      // c < 4096, n_width <= 64: exact
+            const F1P_LDS(GoalFrame32)* gf = (const F1P_LDS(GoalFrame32)*)gfr + l;
+            gok = gf->ok != 0;
+            const double w = ((const F1P_LDS(double)*)wtab)[k];
+            gx = (float)__builtin_fma(w, gf->nx, gf->cx); gy = (float)__builtin_fma(w, gf->ny, gf->cy);
+            gth32 = gf->gth;
+        }
         const float r2 = gx * gx + gy * gy;
-        const bool r_ok = (r2 > 1e-8f) & (r2 < 1e20f);                          // (tiny, huge or NaN in f32: the fp64 tests decide; g1_fit rejects r <= 1e-12 itself)
-        const Fit32 f = g1_fit_f32(gx, gy, gf->gth);
+        const bool r_ok = (r2 > 1e-8f) & (r2 < 1e20f) & th_ok;                  // (tiny, huge or NaN in f32: the fp64 tests decide; g1_fit rejects r <= 1e-12 itself)
+        const Fit32 f = g1_fit_f32(gx, gy, gth32);
         o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
         const bool trusted = r_ok & f.ok;
         k0 = f.k0; dk = f.dk; L = f.L; ek0 = f.ek0; edk = f.edk; eL = f.eLrel;
         // no goal: BAD (infeasible in fp64 too);  no trusted bracket: UNSURE with lo = -inf (the fp64 tests decide);  else what bracket_f2 says
-        int st = trusted ? (o.state | (o.never_free ? 0x80 : 0)) : F1P_ST_UNSURE;
+        // -- without a collision check (no map, or cfg.check_collision = 0) a trusted bracket is all there is to know: FREE
+        int st = trusted ? (collide_on ? (o.state | (o.never_free ? 0x80 : 0)) : F1P_ST_FREE) : F1P_ST_UNSURE;
         st = gok ? st : F1P_ST_BAD;
         lo = gok ? (trusted ? o.lo : -INF) : INF;
         hi = (gok & trusted) ? o.hi : INF;
@@ -1711,6 +1734,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         return st;
     };
     float my_hi_p = INF;                                          // min hi over this thread's PENDING candidates
+    float t_free = INF;                                           // min hi over this thread's FREE candidates
     for (int cb = c0; cb < c1; cb += blockDim.x) {
         const int c = cand_of(cb);
         if (c >= c1) continue;
@@ -1724,6 +1748,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         }
         c_st[c - c0] = (unsigned char)st;
         if ((st & 0x7f) == F1P_ST_PENDING || (st & 0x7f) == F1P_ST_PENDING2) my_hi_p = fminf(my_hi_p, hi);
+        if (st == F1P_ST_FREE) t_free = fminf(t_free, hi);           // (only without a collision check)
 #if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES)
         if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
         if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
@@ -1791,7 +1816,6 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     const PassPlan plan_x = pass_plan<CR>(S_u, true);               // every station
     const F1P_LDS(unsigned char)* tile_b = (const F1P_LDS(unsigned char)*)lds_raw;
     const unsigned pitch_b = (unsigned)pitch * 8u;
-    float t_free = INF;                                           // min hi over this thread's FREE candidates
     float thr = my_hi_p;
     bool thr_is_T = false;                                        // thr is a bound of T (a FREE candidate exists), not just the apparent winner's hi
     F1P_FPH();
@@ -1957,7 +1981,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         need1 = mine != 0;                                           // (one candidate per thread: what the count above found)
         if (need1) {
             const int st = c_st[c - c0] & 0x7f;
-            const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
+            const bool gok = a.goals ? candidate_goal_host(a.goals, e, C, c, g1x, g1y, g1th) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
             ok1 = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0;
         }
     }
@@ -1979,7 +2003,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         if (need | (none_free & (c == c0))) {
             double gx = 0.0, gy = 0.0, gth = 0.0;
-            const bool gok = candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
+            const bool gok = a.goals ? candidate_goal_host(a.goals, e, C, c, gx, gy, gth) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
             RefEntry r;
             r.e = e; r.c = c; r.gx = gx; r.gy = gy; r.gth = gth;
             r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0; r.pad = 0;
@@ -2657,12 +2681,16 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     double clear_ds_cap = 0.0, clear_dist = 0.0;
     bool clear_ok = false;
     int clear_r_eff = 0;
-    if (a.has_grid && cfg->check_collision && !a.goals && ctx->lattice_clear_r > 0 && ctx->lattice_clear_r <= 2) {
+    const bool collide = a.has_grid && cfg->check_collision;
+    if (collide && ctx->lattice_clear_r > 0 && ctx->lattice_clear_r <= 2) {
         double la = 0.0, wd = 0.0;
         for (int l = 0; l < cfg->n_lookahead; ++l) la = fmax(la, fabs(cfg->lookahead[l]));
         for (int k = 0; k < cfg->n_width; ++k) wd = fmax(wd, fabs(cfg->width[k]));
         const int den = S - 1 > 1 ? S - 1 : 1;
         clear_ds_cap = 1.2 * hypot(la, wd) / (double)den;              // clothoids to the sampled goals are rarely longer; longer ones go to fp64
+        // host-supplied goals (round 5): their reach is the caller's, not the configuration's -- the tile was sized for 4 m (launch_lattice), and the
+        // clearance map for a station spacing of 4 m / (S - 1) x 1.2; a longer candidate's first look decides nothing and the every-station look takes it
+        if (a.goals) clear_ds_cap = 1.2 * 4.0 / (double)den;
         if (foot) {                                                    // + the rotation of the largest disc offset at a typical curvature bound
             double mo = 0.0;
             for (int d = 0; d < ctx->n_disc; ++d) mo = fmax(mo, fabs(ctx->disc_off[d]));
@@ -2676,7 +2704,9 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
         }
     }
     // (the plans that will take the prologue + candidate-kernel pair -- decided for good below -- switch to the mixed schedule from one ego)
-    const bool v3_likely = F1P_MIX_FILTER_V3 && !a.goals && !foot && clear_ok && (clear_r_eff == 1 || clear_r_eff == 2) && a.tile_words + 1 <= 16;
+    // round 5: host-supplied goals and plans WITHOUT a collision check (no map set: the reference's own default, utils/utils.py:297-301 is a stub)
+    // take the pair too -- they used to fall to the one-kernel fallback filter from 320 egos and to the all-fp64 kernel below
+    const bool v3_likely = F1P_MIX_FILTER_V3 && !foot && (!collide || (clear_ok && (clear_r_eff == 1 || clear_r_eff == 2))) && a.tile_words + 1 <= 16;
     const int min_egos = v3_likely ? F1P_MIX_MIN_EGOS_V3 : F1P_MIX_MIN_EGOS;
     if (ctx->lattice_mixed && (!foot || clear_ok) && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
         (E >= min_egos || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
@@ -2718,7 +2748,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
             size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + (n_cand <= F1P_MIX_FILTER_BLOCK ? (size_t)n_cand * 24 : 0) + 16;
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
-            const bool v3 = F1P_MIX_FILTER_V3 && !a.goals && mx.n_disc == 0 && (mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
+            const bool v3 = F1P_MIX_FILTER_V3 && mx.n_disc == 0 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
                             (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3)
                                               : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3));
             // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the

@@ -358,7 +358,7 @@ int f1p_lattice_debug_margins(f1p_ctx* ctx, int32_t enable, float margin_rel, fl
  * fp64 refinement (the f32 winner plus whatever the brackets could not rank; synchronises the stream). */
 int f1p_lattice_debug_queue(f1p_ctx* ctx, int32_t* entries_per_ego, int32_t E);
 /* TEST HOOK: d_bound [E][C] f32 (device pointer, nullable) receives every candidate's A-PRIORI cost error bound of the following
- * mixed plans (the running bound of DESIGN.md 5c that widens the candidate's bracket when it exceeds the calibrated margin); the tests
+ * mixed plans (the running bound of LABNOTES.md 5c that widens the candidate's bracket when it exceeds the calibrated margin); the tests
  * check bound >= |cost32 - cost64| candidate by candidate. */
 int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound);
 /* Dispatch order of the mixed schedule's candidate kernel (round 5).  1 (default): every plan of >= 1024 egos leaves one flag per ego -- its

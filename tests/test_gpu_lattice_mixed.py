@@ -128,7 +128,7 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         both = fin & (st < 3) & np.isfinite(c32)
         err = np.abs(c32[both] - c64[both])                                        # (masked first: inf - inf elsewhere)
         worst = max(worst, float((err / np.abs(c64[both])).max()))
-        # round 3: every candidate's bracket is at least its own A-PRIORI error bound -- and the bound holds, candidate by
+        # round 3: every candidate's bracket is at least its own A-PRIORI error bound (LABNOTES.md 5c) -- and the bound holds, candidate by
         # candidate (measured: >= 140x above the actual error; it is a worst-case first-order bound)
         assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())
         assert np.median(bound[both] / np.abs(c64[both])) < 1e-3                   # ... without being vacuous

@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
 # scratch bytes per lane a kernel may carry (mangled-name substring -> budget).  Everything else must have none.
 #   ILb1E...            the materialising variants (all_traj requested): HBM-write-bound, not VALU-bound
 #   k_kmpc_*            spills sit in the once-per-workgroup setup blocks and the rarely taken serial fp64 fallback, not in the
-#                       filter loop (tools/isa_loops.py); a lower register cap was measured slower
+#                       filter loop (tools/isa_loops.py); a lower register cap was measured slower (LABNOTES.md 5b)
 #   k_lattice / g1      the out-of-line fp64 fit's 8-byte frame
 #   k_lattice_filter3<CR, true>   the TEST-HOOK instantiation of the candidate kernel (debug pointers + their stores: never the production launch)
 BUDGET = {"ILb1E": 160, "k_kmpc_plan_gen": 80, "k_kmpc_shoot_mixed": 32, "k_clothoid_g1": 8, "9k_latticeILb0E": 8,

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root:  bash tools/profile_gpu.sh <tag> <headline-kernel-substring> <schedule> [bench args...]
+# (round 5: gfx950 has no SQ_INSTS_VALU_TRANS; the per-class counters are SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_{F32,F64}, _CVT, _INT32, _INT64)
 # Kernel trace + separate PMC passes (never combined with other trace domains), outputs under gpurun_out/<tag>_*; the markdown
 # summary and the machine-readable <tag>_pmc.json (parsed by bench.py at run time) are what gets copied into profiles/.
 set -u
@@ -11,7 +12,7 @@ ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-secondary --latency-iters 0
 export TMPDIR=/tmp
 cd $ROOT
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o run -- python3 bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
-for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/${TAG}_pmc_$N -o run -- python3 bench.py $ARGS > $OUT/${TAG}_pmc_$N.log 2>&1 || echo "pmc pass $C failed (see log)"
 done
