@@ -693,6 +693,108 @@ def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes
     return out
 
 
+def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
+    """The other ways north_star / BASELINE.md section 4 name of running the same workload, each on a context of its own (rank 0):
+      host_goals     the caller's goal set [E][C][3] instead of the device sampler -- what the reference's add_sample_function plug-in returns
+                     (lattice_planner.py:57-70, 113-128); BASELINE.md section 4 row 2 (0.3816 B per candidate-step)
+      cubic          cfg.generator = cubic Hermite spline candidates (north_star "clothoid / cubic-spline"); all fp64 (no f32 bracket yet)
+      materialised   all_traj [E][C][S][4] + all_cost written to HBM, the reference's own data flow (lattice_planner.py:194-201);
+                     BASELINE.md section 4 row 3 (32.38 B per candidate-step, HBM-bound) on a bounded ego count
+    Each: ms per plan (HIP events on the ctx stream), steady state of a closed loop where the schedule supports it, bit-identity with the
+    all-fp64 kernel and best-index mismatches against the CPU oracle on the first egos."""
+    import copy
+    import numpy as np
+    from f1tenth_planning_amd import synth
+    from f1tenth_planning_amd.runtime import Context
+    from oracle import oracle    # the checker
+    nthr = oracle.max_threads()
+    grid = (img, res, origin[0], origin[1], 206)
+    poses = synth.make_egos(rl, E, seed=1)
+    names = ("steer", "speed", "best_idx", "best_cost", "status", "near_idx", "best_traj")
+    out = {}
+
+    def bufs(ctx, n):
+        return [ctx.alloc(8 * n), ctx.alloc(8 * n), ctx.alloc(4 * n), ctx.alloc(8 * n), ctx.alloc(4 * n), ctx.alloc(4 * n), ctx.alloc(8 * n * S * 4)]
+
+    def fetch(b, n):
+        return {k: x.download(t, sh) for k, x, t, sh in zip(names, b, (np.float64, np.float64, np.int32, np.float64, np.int32, np.int32, np.float64),
+                                                           ((n,), (n,), (n,), (n,), (n,), (n,), (n, S, 4)))}
+
+    def timed(ctx, fn):
+        for _ in range(warmup):
+            fn()
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(steps):
+            fn()
+        return ctx.timer_end() / steps
+
+    # ---- host goals ---------------------------------------------------------------------------------------------------------------------
+    cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
+    goals = synth.make_goals(rl, poses, np.linspace(0.6, 3.0, 16), np.linspace(-1.0, 1.0, C // 16))
+    with Context(rk.local_rank) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, res, origin, 206)
+        ctx.lattice_set_closed_loop(True)
+        d_p, d_g, b = ctx.to_device(poses), ctx.to_device(goals), bufs(ctx, E)
+        ms = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg, *b, d_goals=d_g))
+        prev = ctx.lattice_closed_loop_prev(); d_prev = ctx.to_device(prev)
+        ctx.lattice_set_closed_loop(False)
+        ctx.lattice_plan_dev(d_p, E, cfg, *b, d_goals=d_g, d_prev_theta=d_prev); got = fetch(b, E)
+        ctx.lattice_profile(True); acc = np.zeros(4)
+        for _ in range(10):
+            ctx.lattice_plan_dev(d_p, E, cfg, *b, d_goals=d_g, d_prev_theta=d_prev); acc += np.array(ctx.lattice_profile(True, read=True))
+        ctx.lattice_profile(False)
+        nq = ctx.lattice_debug_queue(E)
+        ctx.lattice_set_mode(0)
+        b2 = bufs(ctx, E)
+        ms64 = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg, *b2, d_goals=d_g, d_prev_theta=d_prev)); ref = fetch(b2, E)
+        n_or = min(256, E)
+        want = oracle.lattice_plan_batch(poses[:n_or], rl, cfg, grid=grid, goals=goals[:n_or], prev_theta=prev[:n_or], nthreads=nthr)
+        abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0], device_goals=False)
+        out["host_goals"] = {"ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3), "all_fp64_ms_per_plan": ms64,
+                             "kernels_ms": dict(zip(("k_lattice_prologue", "k_lattice_filter3", "k_lattice_refine", "k_lattice_select"), (float(v) / 10 for v in acc))),
+                             "refinement_queue_entries_per_ego": float(nq.mean()),
+                             "algorithmic_bytes_per_plan": abytes, "bytes_per_candidate_step": abytes / (float(E) * C * S),
+                             "hbm_frac_of_8TBs": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "outputs_bit_identical_to_all_fp64": bool(all(np.array_equal(got[k], ref[k], equal_nan=(got[k].dtype != np.int32)) for k in names)),
+                             "oracle": {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != got["best_idx"][:n_or]).sum()),
+                                        "max_abs_dsteer": float(np.abs(want["steer"] - got["steer"][:n_or]).max())},
+                             "note": "goals [E][C][3] fp64 resident in HBM (synth.make_goals: arc-length look-aheads x lateral offsets in the ego frame), steady state of a "
+                                     "closed loop; schedule: k_lattice_prologue (no look-ahead pass) -> k_lattice_filter3<HG> -> refine -> select"}
+    # ---- cubic generator ------------------------------------------------------------------------------------------------------------------
+    cfg_c = synth.bench_lattice_cfg(n_cand=C, n_stations=S, generator="cubic")
+    with Context(rk.local_rank) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, res, origin, 206)
+        ctx.lattice_set_closed_loop(True)
+        d_p, b = ctx.to_device(poses), bufs(ctx, E)
+        ms = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg_c, *b))
+        prev = ctx.lattice_closed_loop_prev(); d_prev = ctx.to_device(prev)
+        ctx.lattice_set_closed_loop(False)
+        ctx.lattice_plan_dev(d_p, E, cfg_c, *b, d_prev_theta=d_prev); got = fetch(b, E)
+        n_or = min(128, E)
+        want = oracle.lattice_plan_batch(poses[:n_or], rl, cfg_c, grid=grid, prev_theta=prev[:n_or], nthreads=nthr)
+        out["cubic"] = {"ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3),
+                        "oracle": {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != got["best_idx"][:n_or]).sum()),
+                                   "max_abs_dsteer": float(np.abs(want["steer"] - got["steer"][:n_or]).max())},
+                        "note": "cubic Hermite spline candidates, steady state of a closed loop (similarity term live)"}
+    # ---- all_traj materialised (HBM-bound) ----------------------------------------------------------------------------------------------
+    Em = min(E, 1024)
+    with Context(rk.local_rank) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, res, origin, 206)
+        d_p, b = ctx.to_device(poses[:Em]), bufs(ctx, Em)
+        d_ac, d_at = ctx.alloc(8 * Em * C), ctx.alloc(8 * Em * C * S * 4)
+        ms = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, Em, cfg, *b, d_all_cost=d_ac, d_all_traj=d_at))
+        abytes = algorithmic_bytes_lattice(Em, C, S, rl.shape[0], img.shape[1], img.shape[0]) + Em * C * S * 32 + Em * C * 8
+        gbs = abytes / (ms * 1e-3) / 1e9
+        out["materialised"] = {"egos": Em, "ms_per_plan": ms, "nominal_candidate_steps_per_s": float(Em) * C * S / (ms * 1e-3),
+                               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_launch": abytes, "bytes_per_candidate_step": abytes / (float(Em) * C * S),
+                                            "traffic": None, "kernel": "k_lattice<STAGING> (all fp64, rows staged per wave in LDS and flushed as 128-byte chunks)"},
+                               "note": "the reference's all_traj data flow (lattice_planner.py:194-201): every candidate's rows written once; "
+                                       "the store-only ceiling of this chip is 4.1-4.4 TB/s (tools/microbench/stream.hip)"}
+    return out
+
+
 def filter_shape(S, r):
     """What k_lattice_filter3 does (csrc/k_lattice_mixed.hip): EVERY candidate gets the f32 fit and the four cost terms with their bracket
     (bracket_f2: nothing there looks at positions); the station pass -- positions and occupancy look-ups -- runs only for the candidates whose
@@ -943,6 +1045,10 @@ def main_lattice(args):
     if rank == 0 and world == 1 and secondary and not (args.all_fp64 or args.prune or cand_sharded or args.only_timed) and E >= 512:
         scene_sweep = leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, max(20, min(args.steps, 100)), device=rk.local_rank)
 
+    variants = None
+    if rank == 0 and world == 1 and secondary and not (args.all_fp64 or args.prune or cand_sharded or args.only_timed) and E >= 512:
+        variants = leg_variants(rk, rl, img, res, origin, E, C, S, max(20, min(args.steps, 100)))
+
     env_ok = rk.env_ok()
     selftest = kmpc_c4 = None
     if secondary and not cand_sharded and rk.rccl_ok:
@@ -1112,6 +1218,7 @@ def main_lattice(args):
             "two_plans_in_flight": two_in_flight,
             "audit": audit,
             "scene_sweep": scene_sweep,
+            "variants": variants,
             "per_rank_ms_per_step": {"min": min(per_rank_s) / args.steps * 1e3, "max": max(per_rank_s) / args.steps * 1e3, "ranks": len(per_rank_s),
                                      "note": "wall time of the timed region on every rank / steps: ego sharding has no collective, so launch skew between the ranks is all it can lose"},
             "roofline": roofline,
@@ -1142,6 +1249,12 @@ def main_lattice(args):
             "kmpc_c4_streamed_ms": _g(kmpc_c4, "ms_per_plan"), "kmpc_c4_generated_ms": _g(kmpc_c4, "generated_in_kernel", "ms_per_plan"),
             "kmpc_c4_roofline_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
         })
+        if variants:
+            out.update({"host_goals_ms_per_plan": _g(variants, "host_goals", "ms_per_plan"), "host_goals_kernel_ms_filter3": _g(variants, "host_goals", "kernels_ms", "k_lattice_filter3"),
+                        "host_goals_bit_identical": _g(variants, "host_goals", "outputs_bit_identical_to_all_fp64"),
+                        "host_goals_oracle_mismatches": _g(variants, "host_goals", "oracle", "best_idx_mismatches"),
+                        "cubic_ms_per_plan": _g(variants, "cubic", "ms_per_plan"), "cubic_oracle_mismatches": _g(variants, "cubic", "oracle", "best_idx_mismatches"),
+                        "materialised_ms_per_plan": _g(variants, "materialised", "ms_per_plan"), "materialised_hbm_frac": _g(variants, "materialised", "roofline", "frac")})
         if scene_sweep:
             out.update({"scene_sweep_worst_vs_centred": max(v["vs_centred"] for v in scene_sweep.values()),
                         "scene_sweep_all_bit_identical": bool(all(v["outputs_bit_identical_to_all_fp64"] for v in scene_sweep.values())),

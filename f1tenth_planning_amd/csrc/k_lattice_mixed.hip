@@ -1624,7 +1624,9 @@ __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, i
 // DBG: the instantiation with the test hooks (MixArgs::dbg_*; the phase-stamp builds).  The production instantiation has none of their
 // code and none of their pointers to keep in scalar registers (the kernel spills SGPRs into VGPR lanes: every one less is two 4-cycle
 // instructions less per use).
-template <int CR, bool DBG = false>
+// HG: host-supplied goals (the caller's [E][C][3] rows instead of the prologue's goal frames) -- an instantiation of its own, so that the
+// headline kernel carries neither the pointer nor the branches (as runtime branches they cost it 12 more spilled SGPRs and 1.5 us)
+template <int CR, bool DBG = false, bool HG = false>
 __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
@@ -1701,7 +1703,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
         bool gok, th_ok = true;
         float gth32;
-        if (a.goals) {
+        if (HG) {
             // host-supplied goals (add_sample_function's return value, lattice_planner.py:57-70, 113-128): [E][C][3] fp64 in the ego frame, a non-
             // finite row = infeasible.  Round 5: they used to take the one-kernel fallback filter from 320 egos and the all-fp64 kernel below
             const double* g = a.goals + ((size_t)e * C + c) * 3;
@@ -1981,7 +1983,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         need1 = mine != 0;                                           // (one candidate per thread: what the count above found)
         if (need1) {
             const int st = c_st[c - c0] & 0x7f;
-            const bool gok = a.goals ? candidate_goal_host(a.goals, e, C, c, g1x, g1y, g1th) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
+            const bool gok = HG ? candidate_goal_host(a.goals, e, C, c, g1x, g1y, g1th) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, g1x, g1y, g1th);
             ok1 = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0;
         }
     }
@@ -2003,7 +2005,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
         if (need | (none_free & (c == c0))) {
             double gx = 0.0, gy = 0.0, gth = 0.0;
-            const bool gok = a.goals ? candidate_goal_host(a.goals, e, C, c, gx, gy, gth) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
+            const bool gok = HG ? candidate_goal_host(a.goals, e, C, c, gx, gy, gth) : candidate_goal_rec(cfg, c, hdr, cen, nl, gfr, gx, gy, gth);
             RefEntry r;
             r.e = e; r.c = c; r.gx = gx; r.gy = gy; r.gth = gth;
             r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0; r.pad = 0;
@@ -2749,8 +2751,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + (n_cand <= F1P_MIX_FILTER_BLOCK ? (size_t)n_cand * 24 : 0) + 16;
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const bool v3 = F1P_MIX_FILTER_V3 && mx.n_disc == 0 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
-                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3)
-                                              : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3));
+                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
+                                              : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
             // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the
             // first (it waits for the first prologue): one chunk's latency-bound kernels (prologue, refinement, selection: a few waves
             // per SIMD) run beside the other's VALU-bound candidate kernel instead of after it.  Every chunk has its own queue region
@@ -2861,12 +2863,16 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     }
                     const unsigned f3_grid = mk.perm ? (unsigned)(F1P_MIX_OREG * mk.perm_rs) : (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
                     const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
-                    if (mk.clear_r == 1) {
-                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
-                        else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                    const unsigned char* recs = (const unsigned char*)ctx->d_rec_scratch;
+                    if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
+                        if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        else hipLaunchKernelGGL((k_lattice_filter3<2, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                    } else if (mk.clear_r == 1) {
+                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     } else {
-                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
-                        else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, (const unsigned char*)ctx->d_rec_scratch);
+                        if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     }
                 }
                 else if (mk.n_disc > 0 && mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter<1, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);

@@ -180,3 +180,29 @@ def poses_along(raceline, fleet, advance=0.0):
     x, y = np.interp(at, s, xy[:, 0]), np.interp(at, s, xy[:, 1])
     psi = np.interp(at, s, np.unwrap(rl[:, 3]))
     return np.ascontiguousarray(np.column_stack([x - fleet["d"] * np.sin(psi), y + fleet["d"] * np.cos(psi), psi + fleet["dyaw"], fleet["v"]]))
+
+
+def make_goals(raceline, poses, lookaheads, widths):
+    """Host-side goal sampler for the `goals=` / add_sample_function path (lattice_planner.py:57-70, 113-128): [E, L*W, 3] fp64 goals
+    (x, y, heading) in each ego's frame -- the raceline point `lookahead` metres of ARC LENGTH ahead of the ego's nearest waypoint, shifted
+    by `width` along the path normal.  (The device sampler intersects a circle instead; this is a caller's sampler of the same shape.)"""
+    rl = np.asarray(raceline); poses = np.asarray(poses, dtype=np.float64)
+    xy = rl[:, :2]
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(xy[:, 0]), np.diff(xy[:, 1])))])
+    psi_u = np.unwrap(rl[:, 3])
+    E = poses.shape[0]
+    near = np.empty(E, np.int64)
+    for lo in range(0, E, 512):                                   # (chunked: E x N distances)
+        d2 = (poses[lo:lo + 512, None, 0] - xy[None, :, 0]) ** 2 + (poses[lo:lo + 512, None, 1] - xy[None, :, 1]) ** 2
+        near[lo:lo + 512] = np.argmin(d2, axis=1)
+    la = np.asarray(lookaheads, dtype=np.float64); wd = np.asarray(widths, dtype=np.float64)
+    at = np.mod(s[near][:, None] + la[None, :], s[-1])            # [E, L]
+    cx, cy, cpsi = np.interp(at, s, xy[:, 0]), np.interp(at, s, xy[:, 1]), np.interp(at, s, psi_u)
+    gx = cx[:, :, None] - wd[None, None, :] * np.sin(cpsi)[:, :, None]
+    gy = cy[:, :, None] + wd[None, None, :] * np.cos(cpsi)[:, :, None]
+    dx, dy = gx - poses[:, 0, None, None], gy - poses[:, 1, None, None]
+    ct, st = np.cos(poses[:, 2])[:, None, None], np.sin(poses[:, 2])[:, None, None]
+    ex, ey = ct * dx + st * dy, -st * dx + ct * dy
+    eth = np.remainder(cpsi[:, :, None] - poses[:, 2, None, None] + np.pi, 2 * np.pi) - np.pi
+    eth = np.broadcast_to(eth, ex.shape)
+    return np.ascontiguousarray(np.stack([ex, ey, eth], axis=-1).reshape(E, la.size * wd.size, 3))
