@@ -95,6 +95,7 @@ struct f1p_ctx {
     char* d_order = nullptr;           // dispatch order of k_lattice_filter3: slots | counters | per-ego heavy flags (MixArgs::perm, round 5)
     size_t order_bytes = 0;
     int order_E = 0;                   // batch size the heavy flags belong to
+    bool order_valid = false;          // the last mixed plan of that size left a complete dispatch order for the next one
     int lattice_order = 1;             // f1p_lattice_set_order: 1 = heavy egos first (default), 0 = ego order
     bool step_chain = false;           // the kept headings belong to a chain of f1p_lattice_step_batch calls made with closed-loop mode off
     bool mix_q_dirty_prev = false;

@@ -185,6 +185,9 @@ struct MixArgs {
     // region r = e % F1P_MIX_OREG holds its egos heavy-first (two counters per region, placed from both ends), block b takes slot b / OREG of
     // region b % OREG.  A stale or missing flag costs time, never correctness.
     int32_t* perm;                // [F1P_MIX_OREG * perm_rs] ego + 1 per slot (0: none), or null: block b takes ego e0 + b
+    int32_t* perm_fill;           // the same array (or null): THIS plan's kernels prepare it for the next plan -- k_lattice_refine clears it (the candidate
+                                  // kernel has consumed it), extra workgroups of k_lattice_select place every ego (one returning atomic each, beside the
+                                  // selection waves instead of inside a prologue wave's chain: prologue 15.7 -> 14.3 us)
     unsigned int* ocnt;           // [F1P_MIX_OREG][64]: [0] heavy egos placed so far (from the front), [32] light ones (from the back)
     unsigned char* heavy;         // [E] written by k_lattice_filter3, read by the next plan's k_lattice_prologue
     int perm_rs;                  // slots per region
@@ -1433,12 +1436,6 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     const int nl = cfg.n_lookahead, S = cfg.n_stations;
     double* cen_x = s_cen[wave]; double* cen_y = cen_x + F1P_MAX_LOOKAHEADS; double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
     int* cen_ok = s_ok[wave];
-    // the ego's slot in the candidate kernel's dispatch order (MixArgs::perm): the flag is requested with the first loads, the returning atomic
-    // is issued BEHIND the wave's last load (loads and returning atomics come back in order: issued first, the atomic's two round trips stood in
-    // front of the pose -- prologue + 1.2 us) and its slot is stored with the record, after the goal frames' arithmetic
-    int o_slot = 0;
-    int o_heavy = 0;
-    if (mx.perm && lane == 0) o_heavy = mx.heavy[e];
 #ifdef F1P_PRO_PHASES
     long long pph[10]; int npp = 0;
 #define F1P_PPH() do { __builtin_amdgcn_s_waitcnt(0); pph[npp++] = clock64(); } while (0)
@@ -1520,10 +1517,6 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     F1P_PPH();
-    if (mx.perm && lane == 0) {
-        const unsigned r = (unsigned)e % F1P_MIX_OREG;
-        o_slot = o_heavy ? (int)atomicAdd(&mx.ocnt[r * 64u], 1u) : mx.perm_rs - 1 - (int)atomicAdd(&mx.ocnt[r * 64u + 32u], 1u);
-    }
     sn_t = shfl_d(sn_t, 0); cs_t = shfl_d(cs_t, 0);
     if (a.prev_theta) {
 #pragma unroll
@@ -1588,7 +1581,6 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
         p.exact_all = own_bit < 0 ? 1 : (int)((own_word >> own_bit) & 1u);
         *reinterpret_cast<EgoRecHdr*>(rec) = h;
-        if (mx.perm) mx.perm[((unsigned)e % F1P_MIX_OREG) * (unsigned)mx.perm_rs + (unsigned)o_slot] = e + 1;
     }
     F1P_PPH();
 #ifdef F1P_PRO_PHASES
@@ -2064,6 +2056,11 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
     const int S_arg = cfg.n_stations;
+    if (mx.perm_fill) {                                          // the dispatch order's slots and counters: consumed by the candidate kernel, cleared here, filled by k_lattice_select
+        const int np = F1P_MIX_OREG * mx.perm_rs;
+        for (int i = (int)(blockIdx.x * blockDim.x) + tid; i < np; i += (int)(gridDim.x * blockDim.x)) mx.perm_fill[i] = 0;
+        if (blockIdx.x == 0 && tid < 2 * F1P_MIX_OREG) mx.ocnt[tid * 32u] = 0u;
+    }
     // the 16-node rule's nodes and weight table (the rule of all but pathological goals) in LDS, once per workgroup: a lane's
     // sixteen-step moment chain then reads its operands from LDS with all reads in flight together -- from constant memory every step was
     // a dependent global round trip (16 x ~500 cycles: most of the fit's time, tools/refine_phases.py)
@@ -2483,13 +2480,18 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_sel = (a.E - a.e0 + 3) / 4;                      // selection workgroups; the ones behind them (launched when mx.perm_fill is set) place the egos
+    if ((int)blockIdx.x >= n_sel) {                              // ... in the NEXT plan's dispatch order, heavy egos from the front of their region, the others from its back
+        const int eo = a.e0 + ((int)blockIdx.x - n_sel) * (int)blockDim.x + tid;
+        if (mx.perm_fill && eo < a.E) {
+            const unsigned r = (unsigned)eo % F1P_MIX_OREG;
+            const int slot = mx.heavy[eo] ? (int)atomicAdd(&mx.ocnt[r * 64u], 1u) : mx.perm_rs - 1 - (int)atomicAdd(&mx.ocnt[r * 64u + 32u], 1u);
+            mx.perm_fill[r * (unsigned)mx.perm_rs + (unsigned)slot] = eo + 1;
+        }
+        return;
+    }
     const int e = a.e0 + blockIdx.x * 4 + wave;
     if (blockIdx.x == 0 && tid < F1P_MIX_QSHARDS) mx.qcount[tid * 32u] = 0u;   // the refinement kernel is done with them: ready for the next plan
-    if (mx.perm) {                                               // ... and the dispatch order's counters and slots (the candidate kernel has consumed them)
-        if (blockIdx.x == 0 && tid < 2 * F1P_MIX_OREG) mx.ocnt[tid * 32u] = 0u;
-        const int np = F1P_MIX_OREG * mx.perm_rs;
-        if (lane == 0) { if (e < np) mx.perm[e] = 0; if (e + a.E < np && e < a.E) mx.perm[e + a.E] = 0; }   // (np < 2 E whenever the order is in use)
-    }
     if (e >= a.E) return;
     const int S = cfg.n_stations;
     double* tr_x = reinterpret_cast<double*>(lds_raw) + (size_t)wave * 4 * S;
@@ -2812,7 +2814,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 }
             }
             // dispatch order of the candidate kernel (MixArgs::perm): one unpipelined chunk of a batch large enough to queue
-            mx.perm = nullptr; mx.ocnt = nullptr; mx.heavy = nullptr; mx.perm_rs = 0;
+            mx.perm = nullptr; mx.perm_fill = nullptr; mx.ocnt = nullptr; mx.heavy = nullptr; mx.perm_rs = 0;
             if (v3 && nch == 1 && E >= F1P_MIX_ORDER_MIN_EGOS && F1P_MIX_F3_EGOS_PER_WG == 1 && ctx->lattice_order) {
                 const int rs = (E + F1P_MIX_OREG - 1) / F1P_MIX_OREG;
                 const size_t perm_bytes = (sizeof(int32_t) * (size_t)F1P_MIX_OREG * rs + 255) & ~(size_t)255, ocnt_bytes = sizeof(unsigned int) * 64 * F1P_MIX_OREG;
@@ -2825,12 +2827,12 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         F1P_HIP(ctx, hipMalloc((void**)&ctx->d_order, need_o));
                         ctx->order_bytes = need_o;
                     }
-                    F1P_HIP(ctx, hipMemsetAsync(ctx->d_order, 0, need_o, ctx->stream));   // no slots, no counts, no flags: the first plan of this size runs in ego order
-                    ctx->order_E = E;
-                } else if (fresh || ctx->mix_q_dirty_prev) {
-                    F1P_HIP(ctx, hipMemsetAsync(ctx->d_order, 0, perm_bytes + ocnt_bytes, ctx->stream));   // a plan failed before its selection kernel re-armed them
-                }
-                mx.perm = reinterpret_cast<int32_t*>(ctx->d_order);
+                    F1P_HIP(ctx, hipMemsetAsync(ctx->d_order, 0, need_o, ctx->stream));   // no flags yet
+                    ctx->order_E = E; ctx->order_valid = false;
+                } else if (fresh || ctx->mix_q_dirty_prev) ctx->order_valid = false;            // a plan failed before its selection kernel filled the order
+                // this plan runs in the order the PREVIOUS plan of this batch size left (or in ego order), and leaves one for the next
+                mx.perm = ctx->order_valid ? reinterpret_cast<int32_t*>(ctx->d_order) : nullptr;
+                mx.perm_fill = reinterpret_cast<int32_t*>(ctx->d_order);
                 mx.ocnt = reinterpret_cast<unsigned int*>(ctx->d_order + perm_bytes);
                 mx.heavy = reinterpret_cast<unsigned char*>(ctx->d_order + perm_bytes + ocnt_bytes);
                 mx.perm_rs = rs;
@@ -2897,8 +2899,9 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 }
                 if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_refine launch"))) break;
                 if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[3], st));
-                hipLaunchKernelGGL(k_lattice_select, dim3((Ek + 3) / 4), dim3(256), lds_s, st, ak, *cfg, mk);
+                hipLaunchKernelGGL(k_lattice_select, dim3((Ek + 3) / 4 + (mk.perm_fill ? (Ek + 255) / 256 : 0)), dim3(256), lds_s, st, ak, *cfg, mk);
                 rc = check_hip(ctx, hipGetLastError(), "k_lattice_select launch");
+                if (mk.perm_fill) ctx->order_valid = rc == F1P_OK;
             }
             if (nch > 1) {                                           // join: the caller's stream continues after the side stream
                 F1P_HIP(ctx, hipEventRecord(ctx->ev_pipe[1], ctx->pipe_stream[0]));
