@@ -11,6 +11,9 @@
 // HBM-streaming kernel of the path: 8 B of controls per rollout-step, fp64 arithmetic on them.
 #include "f1p_internal.h"
 
+#ifndef F1P_K4_RING
+#define F1P_K4_RING 3                 // register buffers of the streamed filter's prefetch ring (3: two chunks in flight; 4 measured beside it)
+#endif
 #ifndef F1P_K4_WAVES
 #define F1P_K4_WAVES 4
 #endif
@@ -337,6 +340,91 @@ __device__ __forceinline__ f1p_f2 kmpc_rollout_cost_f32x2(const Src& src, const 
     return s.cost;
 }
 
+// The STREAMED filter (round 5): the same steps, fed differently.  (i) A thread's two rollouts are NEIGHBOURS (r, r + 1) when R is even, so
+// one 8-byte load per lane brings a control of both (a wave reads 512 contiguous bytes per instruction, half as many load instructions);
+// (ii) the controls of the next TWO chunks are in flight while a chunk is computed -- a ring of three register buffers, the loop unrolled by
+// three so that every buffer is indexed statically.  Round 4's loop loaded a chunk, waited for it, computed it: the wave's own loads never
+// overlapped its own arithmetic, and at four waves per SIMD the others covered only part of it (0.54 of the HBM peak with the VALU 59 % busy).
+template <bool FULL, bool ADJ>
+__device__ __forceinline__ void kmpc_load_chunk_adj(const SrcStream& src, int T, int r0, int t0, int r1, f1p_f2 (&av)[2], f1p_f2 (&dv)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = FULL || t0 + j < T ? t0 + j : T - 1;
+        const float* pa = src.ce + ((size_t)t * 2 + 0) * src.R, *pd = src.ce + ((size_t)t * 2 + 1) * src.R;
+        // (non-temporal: the control stream is read once -- 4.8 -> 5.0 TB/s at 8192 egos)
+        if (ADJ) {
+            av[j] = __builtin_nontemporal_load(reinterpret_cast<const f1p_f2*>(pa + r0));
+            dv[j] = __builtin_nontemporal_load(reinterpret_cast<const f1p_f2*>(pd + r0));
+        } else { av[j].x = __builtin_nontemporal_load(pa + r0); av[j].y = __builtin_nontemporal_load(pa + r1); dv[j].x = __builtin_nontemporal_load(pd + r0); dv[j].y = __builtin_nontemporal_load(pd + r1); }
+    }
+}
+
+// (ADJ is a template parameter and the prefetches are unconditional -- past the horizon's end they re-read its last whole chunk -- so that the
+// loop body is straight-line code: with a branch around every load the compiler's wait-count pass put an s_waitcnt vmcnt(0) in front of every
+// chunk and the ring bought nothing, measured)
+template <bool POLY, bool ISO, bool ADJ>
+__device__ __forceinline__ f1p_f2 kmpc_rollout_cost_stream(const SrcStream& src, const float* sref32, const KmpcF32& k, int T, int r0, int r1) {
+    KmpcState2 s;
+    s.x = 0.f; s.y = 0.f; s.v = k.v0; s.yaw = 0.f; s.cost = 0.f; s.pa = 0.f; s.pd = 0.f;
+    constexpr int CH = 2;
+    const int nch = T / CH;                                            // whole chunks
+    f1p_f2 a0[CH], d0[CH], a1[CH], d1[CH], a2[CH], d2[CH];
+#if F1P_K4_RING == 4
+    f1p_f2 a3[CH], d3[CH];
+#endif
+    if (nch >= 1) {
+        const int last = nch - 1;
+        auto at = [&](int c) { return (c < last ? c : last) * CH; };   // (scalar min: the chunk index is wave-uniform)
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(0), r1, a0, d0);
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(1), r1, a1, d1);
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(2), r1, a2, d2);
+#if F1P_K4_RING == 4
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(3), r1, a3, d3);
+        kmpc_steps2<POLY, ISO, true, true, CH>(s, sref32, k, T, 0, a0, d0);
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(4), r1, a0, d0);
+        int c = 1;                                                     // chunk c sits in buffer 1, c + 1 in 2, c + 2 in 3, c + 3 in 0
+        for (; c + 4 <= nch; c += 4) {
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, c * CH, a1, d1);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 4), r1, a1, d1);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 1) * CH, a2, d2);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 5), r1, a2, d2);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 2) * CH, a3, d3);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 6), r1, a3, d3);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 3) * CH, a0, d0);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 7), r1, a0, d0);
+        }
+        if (c < nch) kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, c * CH, a1, d1);
+        if (c + 1 < nch) kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 1) * CH, a2, d2);
+        if (c + 2 < nch) kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 2) * CH, a3, d3);
+#else
+        kmpc_steps2<POLY, ISO, true, true, CH>(s, sref32, k, T, 0, a0, d0);
+        kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(3), r1, a0, d0);
+        int c = 1;                                                     // chunk c sits in buffer 1, c + 1 in buffer 2, c + 2 in buffer 0
+        for (; c + 3 <= nch; c += 3) {
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, c * CH, a1, d1);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 3), r1, a1, d1);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 1) * CH, a2, d2);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 4), r1, a2, d2);
+            kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 2) * CH, a0, d0);
+            kmpc_load_chunk_adj<true, ADJ>(src, T, r0, at(c + 5), r1, a0, d0);
+        }
+        if (c < nch) kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, c * CH, a1, d1);
+        if (c + 1 < nch) kmpc_steps2<POLY, ISO, true, false, CH>(s, sref32, k, T, (c + 1) * CH, a2, d2);
+#endif
+    }
+    const int t0 = nch * CH;
+    if (t0 < T) {                                                      // an odd horizon's last step (or T = 1)
+        kmpc_load_chunk_adj<false, ADJ>(src, T, r0, t0, r1, a0, d0);
+        if (t0 == 0) kmpc_steps2<POLY, ISO, false, true, CH>(s, sref32, k, T, 0, a0, d0);
+        else kmpc_steps2<POLY, ISO, false, false, CH>(s, sref32, k, T, t0, a0, d0);
+    }
+    const f1p_f2 e0 = k.sqf[0] * s.x + sref32[0 * (T + 1) + T], e1 = k.sqf[1] * s.y + sref32[1 * (T + 1) + T];
+    const f1p_f2 e2 = k.sqf[2] * s.v + sref32[2 * (T + 1) + T], e3 = k.sqf[3] * s.yaw + sref32[3 * (T + 1) + T];
+    s.cost += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    s.cost -= k.rd[0] * s.pa * s.pa + k.rd[1] * s.pd * s.pd;           // the last step has no successor (see KmpcF32)
+    return s.cost;
+}
+
 // Refinement margin.  Measured f32 filter error against the fp64 cost (tools/f32_filter_error.py on the GPU: T = 8, 30, 60,
 // three control distributions, headings up to 14 pi): relative error <= 1.4 T u with u = 2^-24, i.e. 2.5e-6 at T = 30.  The
 // relative margin is 57 T u PER TIME STEP of the horizon (1e-4 at T = 30): 40x the measured error, 20x the half-margin the
@@ -638,12 +726,9 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     if (e >= E) return;
     const double sx = x0[4 * e], sy = x0[4 * e + 1], sv = x0[4 * e + 2], syaw = x0[4 * e + 3];
     const SrcStream ce{controls + (size_t)e * T * 2 * R, R};
-    if (!(fabs(syaw) <= 1.0e4) || !(fabs(cfg.max_steer) <= 1.0e4) || !kf.w_ok) {  // workgroup-uniform: outside the fast paths' ranges
-        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined);
-        return;
-    }
+    const bool in_range = fabs(syaw) <= 1.0e4 && fabs(cfg.max_steer) <= 1.0e4 && kf.w_ok;   // workgroup-uniform: the fast paths' ranges (outside: every rollout in fp64)
     double s0d, c0d;
-    sincos_core(syaw, &s0d, &c0d);
+    sincos_core(in_range ? syaw : 0.0, &s0d, &c0d);
     const bool poly = kf.max_steer <= 0.45f;              // polynomial tan inside its accuracy range (the reference's MAX_STEER is 0.4189)
     const bool iso = poly && kf.sq[0] == kf.sq[1] && kf.sqf[0] == kf.sqf[1];
     for (int q = tid; q < 4 * (T + 1); q += blockDim.x) {
@@ -654,52 +739,62 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
     }
     if (tid == 0) *cnt = 0;
     __syncthreads();
-    // the constants arrive converted from the host (kernel argument -> SGPRs); the three per-ego values are made scalar too,
-    // so the filter's VGPRs hold only the two rollouts' state and the control buffers
-    KmpcF32 k = kf;
-    k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
-    k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
-    k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
+    // (round 5: ONE inlined copy of the fp64 refinement -- there were three; n_eff = -1: every rollout in fp64)
+    int n_eff = -1;
+    if (in_range) {
+        // the constants arrive converted from the host (kernel argument -> SGPRs); the three per-ego values are made scalar too,
+        // so the filter's VGPRs hold only the two rollouts' state and the control buffers
+        KmpcF32 k = kf;
+        k.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)c0d)));
+        k.s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s0d)));
+        k.v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)sv)));
 
-    // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
-    float fmin_ = __builtin_huge_valf();
-    for (int r = tid; r < R; r += 2 * blockDim.x) {                    // rollouts r and r + 256 share the packed lanes
-        const int r1 = r + (int)blockDim.x < R ? r + (int)blockDim.x : r;
-        const f1p_f2 c = iso ? kmpc_rollout_cost_f32x2<true, true>(ce, sref32, k, T, r, r1)
-                             : (poly ? kmpc_rollout_cost_f32x2<true, false>(ce, sref32, k, T, r, r1) : kmpc_rollout_cost_f32x2<false, false>(ce, sref32, k, T, r, r1));
-        c32[r] = c.x;
-        if (cost32_out) cost32_out[(size_t)e * R + r] = c.x;
-        fmin_ = fminf(fmin_, c.x);                                     // NaN costs are ignored here and caught below
-        if (r1 != r) {
-            c32[r1] = c.y;
-            if (cost32_out) cost32_out[(size_t)e * R + r1] = c.y;
-            fmin_ = fminf(fmin_, c.y);
+        // ---- pass A: f32 filter -----------------------------------------------------------------------------------------
+        float fmin_ = __builtin_huge_valf();
+        const bool adj = (R & 1) == 0 && iso;                              // neighbours share the packed lanes: one 8-byte load per control (R even: rows stay 8-byte aligned)
+        for (int rb = tid; rb < (R + 1) / 2; rb += blockDim.x) {           // (otherwise: rollouts rb and rb + ceil(R / 2), 4-byte loads)
+            const int r = adj ? 2 * rb : rb;
+            const int r1 = adj ? r + 1 : (rb + (R + 1) / 2 < R ? rb + (R + 1) / 2 : r);
+            // (the reference's weights and bounds -- equal position weights, MAX_STEER 0.4189 -- with an even rollout count take the first form)
+            const f1p_f2 c = (iso && adj) ? kmpc_rollout_cost_stream<true, true, true>(ce, sref32, k, T, r, r1)
+                           : iso ? kmpc_rollout_cost_stream<true, true, false>(ce, sref32, k, T, r, r1)
+                           : (poly ? kmpc_rollout_cost_stream<true, false, false>(ce, sref32, k, T, r, r1) : kmpc_rollout_cost_stream<false, false, false>(ce, sref32, k, T, r, r1));
+            c32[r] = c.x;
+            if (cost32_out) cost32_out[(size_t)e * R + r] = c.x;
+            fmin_ = fminf(fmin_, c.x);                                     // NaN costs are ignored here and caught below
+            if (r1 != r) {
+                c32[r1] = c.y;
+                if (cost32_out) cost32_out[(size_t)e * R + r1] = c.y;
+                fmin_ = fminf(fmin_, c.y);
+            }
         }
-    }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
-    if (lane == 0) red_f[wave] = fmin_;
-    __syncthreads();
-    fmin_ = fminf(fminf(red_f[0], red_f[1]), fminf(red_f[2], red_f[3]));
-    const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
-    // ---- pass B: the near-minimum set -> list -------------------------------------------------------------------------
-    for (int r = tid; r < R; r += blockDim.x) {
-        const float c = c32[r];
-        if (!(c > thr)) {                                              // includes NaN
-            const int pos = atomicAdd(cnt, 1);
-            if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+        for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
+        if (lane == 0) red_f[wave] = fmin_;
+        __syncthreads();
+        fmin_ = fminf(fminf(red_f[0], red_f[1]), fminf(red_f[2], red_f[3]));
+        const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
+        // ---- pass B: the near-minimum set -> list -------------------------------------------------------------------------
+        for (int r = tid; r < R; r += blockDim.x) {
+            const float c = c32[r];
+            if (!(c > thr)) {                                              // includes NaN
+                const int pos = atomicAdd(cnt, 1);
+                if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+            }
         }
+        __syncthreads();
+        const int n = *cnt;
+        n_eff = (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) ? -1 : n;   // pathological inputs, degenerate ties: all rollouts in fp64
     }
-    __syncthreads();
-    const int n = *cnt;
-    if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
-        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, nullptr, true);
-    } else if (n == 1 && !best_cost) {
+    // (round 5, measured and not kept: the tail's configuration from an LDS copy -- SGPR spills 236 -> 180 but its values then occupy VGPRs:
+    // 39 VGPR spills; through a laundered pointer to the by-value argument -- the address-of forces a scratch copy: 137 VGPR spills)
+    const f1p_kmpc_cfg& s_cfg = cfg;
+    if (n_eff == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
-        kmpc_emit_wave(ce, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, nullptr);
+        kmpc_emit_wave(ce, s_cfg, sv, s_cfg.max_dsteer * s_cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, nullptr);
         if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
-        kmpc_refine_block(ref, ce, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, nullptr, true);
+        kmpc_refine_block(ref, ce, s_cfg, sx, sy, sv, syaw, e, n_eff, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, nullptr, true);
     }
 }
 
@@ -813,43 +908,43 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
 
     F1P_KPH();
     // ---- second stage (the ego's last workgroup): minimum -> near-minimum set -> fp64 refinement ------------------------
-    if (!in_range) {
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
-        return;
-    }
-    if (ga.G > 1) {
-        fmin_ = __builtin_huge_valf();
-        for (int r = tid; r < R; r += blockDim.x)
-            fmin_ = fminf(fmin_, __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
-    if (lane == 0) red_f[wave] = fmin_;
-    __syncthreads();
-    fmin_ = red_f[0];
-    for (int w = 1; w < nwaves; ++w) fmin_ = fminf(fmin_, red_f[w]);
-    const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
-    for (int r = tid; r < R; r += blockDim.x) {
-        float c;
-        if (ga.G > 1) c = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        else c = cost_out[r];
-        if (!(c > thr)) {                                              // includes NaN
-            const int pos = atomicAdd(cnt, 1);
-            if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+    // (round 5: ONE inlined copy of the refinement and one of the emission -- there were three and one; n_eff = -1: every rollout in fp64)
+    int n_eff = -1;
+    if (in_range) {
+        if (ga.G > 1) {
+            fmin_ = __builtin_huge_valf();
+            for (int r = tid; r < R; r += blockDim.x)
+                fmin_ = fminf(fmin_, __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) fmin_ = fminf(fmin_, __shfl_xor(fmin_, m, 64));
+        if (lane == 0) red_f[wave] = fmin_;
+        __syncthreads();
+        fmin_ = red_f[0];
+        for (int w = 1; w < nwaves; ++w) fmin_ = fminf(fmin_, red_f[w]);
+        const float thr = fmin_ + (fabsf(fmin_) * fminf(F1P_K4_MARGIN_REL * (float)T, 0.5f) + F1P_K4_MARGIN_ABS);
+        for (int r = tid; r < R; r += blockDim.x) {
+            float c;
+            if (ga.G > 1) c = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(cost_out + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            else c = cost_out[r];
+            if (!(c > thr)) {                                              // includes NaN
+                const int pos = atomicAdd(cnt, 1);
+                if (pos < F1P_K4_MAX_REFINE) list[pos] = r;
+            }
+        }
+        __syncthreads();
+        const int n = cnt[0];
+        n_eff = (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) ? -1 : n;   // pathological inputs, degenerate ties: all rollouts in fp64
     }
-    __syncthreads();
-    const int n = cnt[0];
     F1P_KPH();
-    if (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) {          // pathological inputs, degenerate ties: all rollouts in fp64
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, -1, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
-    } else if (n == 1 && !best_cost) {
+    const f1p_kmpc_cfg& s_cfg = cfg;
+    if (n_eff == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
-        kmpc_emit_wave(src, cfg, sv, cfg.max_dsteer * cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
+        kmpc_emit_wave(src, s_cfg, sv, s_cfg.max_dsteer * s_cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
         if (tid == 0 && n_refined) n_refined[e] = 1;
     } else {
         // the survivors in ascending rollout order: the atomic list is in arrival order, the decision (first minimum) is by index
-        kmpc_refine_block(ref, src, cfg, sx, sy, sv, syaw, e, n, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
+        kmpc_refine_block(ref, src, s_cfg, sx, sy, sv, syaw, e, n_eff, list, sref, steer, speed, best_idx, best_cost, best_seq, n_refined, warm_out, true);
     }
     F1P_KPH_OUT();
 }
