@@ -697,7 +697,7 @@ def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
     """The other ways north_star / BASELINE.md section 4 name of running the same workload, each on a context of its own (rank 0):
       host_goals     the caller's goal set [E][C][3] instead of the device sampler -- what the reference's add_sample_function plug-in returns
                      (lattice_planner.py:57-70, 113-128); BASELINE.md section 4 row 2 (0.3816 B per candidate-step)
-      cubic          cfg.generator = cubic Hermite spline candidates (north_star "clothoid / cubic-spline"); all fp64 (no f32 bracket yet)
+      cubic          cfg.generator = cubic Hermite spline candidates (north_star "clothoid / cubic-spline"), mixed schedule since round 5
       materialised   all_traj [E][C][S][4] + all_cost written to HBM, the reference's own data flow (lattice_planner.py:194-201);
                      BASELINE.md section 4 row 3 (32.38 B per candidate-step, HBM-bound) on a bounded ego count
     Each: ms per plan (HIP events on the ctx stream), steady state of a closed loop where the schedule supports it, bit-identity with the
@@ -771,12 +771,25 @@ def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
         prev = ctx.lattice_closed_loop_prev(); d_prev = ctx.to_device(prev)
         ctx.lattice_set_closed_loop(False)
         ctx.lattice_plan_dev(d_p, E, cfg_c, *b, d_prev_theta=d_prev); got = fetch(b, E)
+        ctx.lattice_profile(True); acc = np.zeros(4)
+        for _ in range(10):
+            ctx.lattice_plan_dev(d_p, E, cfg_c, *b, d_prev_theta=d_prev); acc += np.array(ctx.lattice_profile(True, read=True))
+        ctx.lattice_profile(False)
+        nq = ctx.lattice_debug_queue(E)
+        ctx.lattice_set_mode(0)
+        b2 = bufs(ctx, E)
+        ms64 = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg_c, *b2, d_prev_theta=d_prev)); ref = fetch(b2, E)
         n_or = min(128, E)
         want = oracle.lattice_plan_batch(poses[:n_or], rl, cfg_c, grid=grid, prev_theta=prev[:n_or], nthreads=nthr)
-        out["cubic"] = {"ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3),
+        out["cubic"] = {"ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3), "all_fp64_ms_per_plan": ms64,
+                        "kernels_ms": dict(zip(("k_lattice_prologue", "k_lattice_filter3", "k_lattice_refine_cubic", "k_lattice_select"), (float(v) / 10 for v in acc))),
+                        "refinement_queue_entries_per_ego": float(nq.mean()),
+                        "outputs_bit_identical_to_all_fp64": bool(all(np.array_equal(got[k], ref[k], equal_nan=(got[k].dtype != np.int32)) for k in names)),
                         "oracle": {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != got["best_idx"][:n_or]).sum()),
                                    "max_abs_dsteer": float(np.abs(want["steer"] - got["steer"][:n_or]).max())},
-                        "note": "cubic Hermite spline candidates, steady state of a closed loop (similarity term live)"}
+                        "note": "cubic Hermite spline candidates, steady state of a closed loop (similarity term live); round 5: the mixed schedule -- "
+                                "k_lattice_prologue -> k_lattice_filter3<cubic> (an f32 walk over the stations with an a-priori error bound, table-driven "
+                                "station passes) -> k_lattice_refine_cubic -> k_lattice_select<cubic>"}
     # ---- all_traj materialised (HBM-bound) ----------------------------------------------------------------------------------------------
     Em = min(E, 1024)
     with Context(rk.local_rank) as ctx:
@@ -1253,7 +1266,8 @@ def main_lattice(args):
             out.update({"host_goals_ms_per_plan": _g(variants, "host_goals", "ms_per_plan"), "host_goals_kernel_ms_filter3": _g(variants, "host_goals", "kernels_ms", "k_lattice_filter3"),
                         "host_goals_bit_identical": _g(variants, "host_goals", "outputs_bit_identical_to_all_fp64"),
                         "host_goals_oracle_mismatches": _g(variants, "host_goals", "oracle", "best_idx_mismatches"),
-                        "cubic_ms_per_plan": _g(variants, "cubic", "ms_per_plan"), "cubic_oracle_mismatches": _g(variants, "cubic", "oracle", "best_idx_mismatches"),
+                        "cubic_ms_per_plan": _g(variants, "cubic", "ms_per_plan"), "cubic_all_fp64_ms_per_plan": _g(variants, "cubic", "all_fp64_ms_per_plan"),
+                        "cubic_bit_identical": _g(variants, "cubic", "outputs_bit_identical_to_all_fp64"), "cubic_oracle_mismatches": _g(variants, "cubic", "oracle", "best_idx_mismatches"),
                         "materialised_ms_per_plan": _g(variants, "materialised", "ms_per_plan"), "materialised_hbm_frac": _g(variants, "materialised", "roofline", "frac")})
         if scene_sweep:
             out.update({"scene_sweep_worst_vs_centred": max(v["vs_centred"] for v in scene_sweep.values()),

@@ -1347,6 +1347,9 @@ __device__ __forceinline__ float wave_scan_add(float v) {          // inclusive 
     return v;
 }
 
+__device__ __forceinline__ int wave_lookup_verdict(float x, float y, bool mine, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
+                                                   const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all);
+
 template <int R>
 __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
                                                  const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
@@ -1375,7 +1378,13 @@ __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, fl
     float dx = __builtin_fmaf(cs, Ph, -(sn * Qh)), dy = __builtin_fmaf(sn, Ph, cs * Qh);
     if (!mine) { dx = 0.f; dy = 0.f; }
     const float x = wave_scan_add(dx), y = wave_scan_add(dy);
-    // the look-up of station_pass_f2's test()
+    return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+}
+
+// the look-up of station_pass_f2's test() for the wave-cooperative passes: lane = test point at (x, y) in the ego frame; the verdict of the
+// candidate by three ballots (all 64 lanes call this)
+__device__ __forceinline__ int wave_lookup_verdict(float x, float y, bool mine, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
+                                                   const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all) {
     const float edge_hi = 1.0f - edge;
     const float lxf = __builtin_fmaf(ep->txx, x, __builtin_fmaf(ep->txy, y, ep->tx0));
     const float lyf = __builtin_fmaf(ep->tyx, x, __builtin_fmaf(ep->tyy, y, ep->ty0));
@@ -1400,6 +1409,193 @@ __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, fl
     const bool any_nan = __ballot(mine & nanpos) != 0ull;
     const bool hit_sure = __ballot(mine & hitc) != 0ull && !any_nan;
     const bool unsure = never_free | (__ballot(mine & undecided) != 0ull) | any_nan;
+    return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+}
+
+// ===================================================================================================================
+// Round 5: the CUBIC generator (cfg.generator = F1P_GEN_CUBIC: parametric cubic Hermite spline from the ego pose to the goal pose, both
+// tangents of chord length, stations at equal parameter steps: cubic_setup / cubic_row in lattice_device.h, orc_cubic_row in the oracle)
+// under the mixed schedule.  It ran all fp64 at every batch size (0.43 ms per 4096-ego plan against 0.07 for clothoids).  Nothing about a
+// cubic's cost is closed-form -- the polyline length, max / mean |kappa| and the heading differences are sums over the S stations -- so the
+// f32 bracket walks the stations: the Hermite basis of every station (candidate-independent) sits in an LDS table, a station is
+// 15 fma + the curvature (one v_rsq) + the chord (one v_sqrt) + the heading (atan2f) and the running extremes the error bound needs.
+// Positions are closed-form too: the lazy station pass evaluates a test point straight from the table (no integration, no scan).
+// ===================================================================================================================
+struct CubicTab { float h10, h01, h11, pad0, d10, d01, d11, pad1, e10, e01, e11, pad2; };   // one station's basis values (fp64, rounded once)
+
+__device__ __forceinline__ CubicTab cubic_tab_row(int i, int den) {
+    const double u = (double)i / (double)den, u2 = u * u, u3 = u2 * u;
+    CubicTab t;
+    t.h10 = (float)((u3 - 2.0 * u2) + u); t.h01 = (float)(3.0 * u2 - 2.0 * u3); t.h11 = (float)(u3 - u2); t.pad0 = 0.f;
+    t.d10 = (float)((3.0 * u2 - 4.0 * u) + 1.0); t.d01 = (float)(6.0 * u - 6.0 * u2); t.d11 = (float)(3.0 * u2 - 2.0 * u); t.pad1 = 0.f;
+    t.e10 = (float)(6.0 * u - 4.0); t.e01 = (float)(6.0 - 12.0 * u); t.e11 = (float)(6.0 * u - 2.0); t.pad2 = 0.f;
+    return t;
+}
+
+struct CubBrk { float cost, lo, hi, ebound; int state; bool never_free, trusted; float cx, cy, m, maxch; };
+
+// atan2 for the cubic bracket's headings: finite arguments, not both zero (a stationary point is not trusted anyway); the device library's
+// atan2f spends half of its ~45 instructions on denormal scaling and special cases.  min / max ratio by the raw reciprocal (1.5 u), the
+// a degree-15 odd polynomial on [0, 1], two reflections, the sign of y: within 6 u of the fp64 angle (e_th carries 24 u).
+__device__ __forceinline__ float atan2_fast_f32(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float z = mn * __builtin_amdgcn_rcpf(mx), z2 = z * z;
+    // atan z = z + z^3 P(z^2), P of degree 7 fitted on [0, 1] (least squares on Chebyshev nodes): 1.5e-7 = 2.5 u evaluated in f32
+    float p = __builtin_fmaf(z2, 4.114861134e-03f, -2.092068829e-02f);
+    p = __builtin_fmaf(z2, p, 5.018902943e-02f);
+    p = __builtin_fmaf(z2, p, -8.100808412e-02f);
+    p = __builtin_fmaf(z2, p, 1.089979038e-01f);
+    p = __builtin_fmaf(z2, p, -1.426329017e-01f);
+    p = __builtin_fmaf(z2, p, 1.999914199e-01f);
+    p = __builtin_fmaf(z2, p, -3.333333135e-01f);
+    float r = __builtin_fmaf(z * z2, p, z);
+    r = ay > ax ? 1.57079637f - r : r;
+    r = x < 0.0f ? 3.14159274f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
+// One cubic candidate in f32: cost, bracket, what is known of its state without a look-up.  Error budget (u = 2^-24 = 6e-8; generous
+// constants, checked candidate by candidate against the fp64 costs by tests/test_gpu_lattice_mixed.py through the debug hook):
+//   inputs m, gx, gy, cx, cy within e_in = 8 u m;  basis values within u relative, three products + two additions per coordinate:
+//   position within e_p = 15 u m (|h10| + |h01| + |h11| <= 1.3), first derivative within e_d = 40 u m (<= 3.5), second within e_dd = 160 u m (<= 14)
+//   kappa = |xd ydd - yd xdd| / sp^1.5, sp = xd^2 + yd^2:  with v1 = |xd| + |yd| <= sqrt(2 sp), a1 = |xdd| + |ydd|
+//     |d kappa| <= (v1 e_dd + a1 e_d + 4 u v1 a1) / sp^1.5 + kappa (3 v1 e_d / sp + 10 u)
+//              <= (sqrt 2 e_dd + 4 sqrt 2 u a1max) / spmin + a1max e_d / spmin^1.5 + kmax (3 sqrt 2 e_d / sqrt spmin + 10 u)      =: e_kap
+//   polyline length: the input errors move neighbouring stations together (a chord sees them scaled by its own length), the roundings of
+//     the sums do not: |d len| <= 12 u len + 8 u m (S - 1)
+//   heading: |d theta| <= v1 e_d / sp + 20 u <= sqrt 2 e_d / sqrt spmin + 20 u + u pi (atan2_fast_f32; the f32 copy of the previous heading)  =: e_th
+//   similarity: 2 e_th sqrt(S sum) + S e_th^2 + 2 S u sum (Cauchy-Schwarz, as for the clothoid)
+// Not trusted (the fp64 arithmetic decides): a stationary point (spmin <= (0.05 m)^2), a heading within 2e-3 of +-pi (atan2's cut), a chord
+// length outside (1e-6, 1e6), anything non-finite.
+template <int R>
+__device__ __forceinline__ CubBrk bracket_cubic_f32(float gx, float gy, float gth, const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab,
+                                                    const F1P_LDS(float)* pf, bool collide_on) {
+    CubBrk o;
+    const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m);
+    const bool has_prev = ep->prev != nullptr;
+    const float m = __builtin_sqrtf(gx * gx + gy * gy);
+    const float gr = gth * F1P_INV_2PI_F;
+    const float cx = m * __builtin_amdgcn_cosf(gr), cy = m * __builtin_amdgcn_sinf(gr);
+    float len = 0.f, maxk = 0.f, sumk = 0.f, sim = 0.f, maxch = 0.f, spmin = __builtin_huge_valf(), a1max = 0.f, thmax = 0.f;
+    float xp = 0.f, yp = 0.f;
+    for (int i = 0; i < S; ++i) {
+        const F1P_LDS(CubicTab)* t = tab + i;
+        const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
+        const float xd = __builtin_fmaf(t->d10, m, __builtin_fmaf(t->d01, gx, t->d11 * cx)), yd = __builtin_fmaf(t->d01, gy, t->d11 * cy);
+        const float xdd = __builtin_fmaf(t->e10, m, __builtin_fmaf(t->e01, gx, t->e11 * cx)), ydd = __builtin_fmaf(t->e01, gy, t->e11 * cy);
+        const float sp = __builtin_fmaf(xd, xd, yd * yd);
+        const float cr = __builtin_fmaf(xd, ydd, -(yd * xdd));
+        const float rs = __builtin_amdgcn_rsqf(sp);
+        const float ak = fabsf(cr) * (rs * rs) * rs;
+        maxk = fmaxf(maxk, ak); sumk += ak;
+        spmin = fminf(spmin, sp); a1max = fmaxf(a1max, fabsf(xdd) + fabsf(ydd));
+        if (i > 0) {
+            const float dx = x - xp, dy = y - yp;
+            const float ch = __builtin_amdgcn_sqrtf(__builtin_fmaf(dx, dx, dy * dy));      // (the raw v_sqrt_f32, 1 u: the correctly rounded form is twelve instructions more)
+            len += ch; maxch = fmaxf(maxch, ch);
+        }
+        xp = x; yp = y;
+        if (has_prev && i < sim_m) {
+            const float th = atan2_fast_f32(yd, xd);
+            const float d = th - pf[i];
+            sim = __builtin_fmaf(d, d, sim);
+            thmax = fmaxf(thmax, fabsf(th));
+        }
+    }
+    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(len), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * ep->inv_S), t4 = ep->w_sim * sim;
+    o.cost = ((t1 + t2) + t3) + t4;
+    const float U = 6.0e-8f, fS = ep->fS;
+    const float e_d = 40.0f * U * m, e_dd = 160.0f * U * m, e_p = 15.0f * U * m;
+    const float isp = __builtin_amdgcn_rcpf(spmin), irs = __builtin_amdgcn_rsqf(spmin);
+    const float e_kap = (1.4143f * e_dd + 5.66f * U * a1max) * isp + a1max * e_d * (isp * irs) + maxk * (4.25f * e_d * irs + 10.0f * U);
+    const float e_len = 12.0f * U * len + 8.0f * U * m * (fS - 1.0f);
+    const float e1 = fabsf(t1) * (e_len * __builtin_amdgcn_rcpf(len) + 3.0f * U);
+    const float e2 = fabsf(ep->w_maxk) * e_kap, e3 = fabsf(ep->w_meank) * (e_kap + 2.0f * U * maxk);
+    float e4 = 0.f;
+    if (has_prev) {
+        const float e_th = 1.4143f * e_d * irs + 24.0f * U;
+        e4 = fabsf(ep->w_sim) * (2.0f * e_th * ep->sqrt_S * __builtin_sqrtf(sim) + fS * e_th * e_th + 2.0f * fS * U * sim);
+    }
+    const float sum_abs = (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4));
+    const float bound = 1.25f * ((e1 + e2) + (e3 + e4)) + 8.0f * U * sum_abs;
+    o.ebound = bound;
+    float mg = __builtin_fmaf(ep->margin_rel, sum_abs, ep->margin_abs);
+    if (!(ep->margin_rel < 0.0f)) { mg = fmaxf(mg, bound); if (!(bound == bound)) mg = __builtin_huge_valf(); }
+    o.lo = o.cost - mg; o.hi = o.cost + mg;
+    o.trusted = (m > 1e-6f) & (m < 1e6f) & (spmin > 0.0025f * (m * m)) & (thmax < 3.14159265f - 2e-3f) & (fabsf(o.cost) < 1e30f) & (len > 0.f);
+    // a clear cell at a tested station proves its R neighbours on each side free while consecutive stations are no farther apart than the
+    // spacing the clearance map was built for (distances along the polyline bound the straight-line ones)
+    o.never_free = !(maxch * 1.0001f + 2.0f * e_p <= ep->clear_ds_cap);
+    o.state = collide_on ? F1P_ST_PENDING : F1P_ST_FREE;
+    o.cx = cx; o.cy = cy; o.m = m; o.maxch = maxch;
+    return o;
+}
+
+// the cell-edge band of a cubic candidate's look-ups: its positions are closed-form (no integration error), within 15 u m of the fp64 ones
+__device__ __forceinline__ float edge_cubic(float m, const F1P_LDS(EgoParamsF2)* ep) {
+    float edge = ep->edge0 + 1.25f * (15.0f * 6.0e-8f) * m * ep->cells_per_m;
+    if (!(edge == edge)) edge = 2.0f;
+    return edge;
+}
+
+template <int R>
+__device__ __forceinline__ int cubic_test_station(int q, const PassPlan& pl, int S, bool exact_all) {   // station index of test point q (pass_plan's layout)
+    constexpr int G = 2 * R + 1;
+    if (exact_all) return q;
+    if (q == 0) return pl.first_m;
+    return q <= pl.nm ? R + G * q : S - 1;
+}
+
+// a wave takes ONE cubic candidate: lane = test point, its position straight from the basis table
+template <int R>
+__device__ __forceinline__ int station_pass_wave_cubic(float gx, float gy, float cx, float cy, float m, float edge, bool never_free,
+                                                       const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab, const F1P_LDS(unsigned char)* tile,
+                                                       unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
+    const int S = __builtin_amdgcn_readfirstlane(ep->S);
+    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
+    const bool mine = lane < pl.nt;
+    const int si = mine ? cubic_test_station<R>(lane, pl, S, exact_all) : 0;
+    const F1P_LDS(CubicTab)* t = tab + si;
+    const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
+    return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+}
+
+// ... and the lane-per-candidate form (many selected candidates in a wave): the test points one after the other
+template <int R>
+__device__ __forceinline__ int station_pass_cubic(float gx, float gy, float cx, float cy, float m, float edge, bool never_free,
+                                                  const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab, const F1P_LDS(unsigned char)* tile,
+                                                  unsigned pitch_bytes, const PassPlan& pl, bool exact_all) {
+    const int S = __builtin_amdgcn_readfirstlane(ep->S);
+    const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
+    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
+    const float edge_hi = 1.0f - edge;
+    uint32_t flags = 0u;
+    bool nan_pos = false;
+    for (int q = 0; q < pl.nt; ++q) {
+        const F1P_LDS(CubicTab)* t = tab + cubic_test_station<R>(q, pl, S, exact_all);
+        const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
+        nan_pos |= !(x == x) | !(y == y);
+        const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0)), lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
+        const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
+        const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
+        const unsigned addr = __umul24(lyc, pitch_bytes) + ((lxc >> 2) & ~7u);
+        const unsigned long long w = *reinterpret_cast<const F1P_LDS(unsigned long long)*>(tile + addr);
+        const uint32_t nc = __builtin_amdgcn_ubfe((uint32_t)w, lxc, 1u), oc = __builtin_amdgcn_ubfe((uint32_t)(w >> 32), lxc, 1u);
+        const float rx = __builtin_amdgcn_fractf(lxf), ry = __builtin_amdgcn_fractf(lyf);
+        const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
+        uint32_t fl;
+        if (!exact_all) fl = ((near ? 0u : (nc & oc)) << 1) | nc;
+        else {
+            const bool off = (lx != (int)lxc) | (ly != (int)lyc);
+            bool amb = near;
+            if (near && !off && edge < 0.5f) amb = !near_edge_neighbours_agree(tile, pitch_bytes, tile_w, tile_h, lx, ly, rx, ry, edge, edge_hi, oc);
+            fl = (amb | off) ? 1u : (oc << 1);
+        }
+        flags |= fl;
+    }
+    const bool hit_sure = (flags & 2u) != 0u && !nan_pos;
+    const bool unsure = never_free | ((flags & 1u) != 0u) | nan_pos;
     return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
 }
 
@@ -1618,7 +1814,8 @@ __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, i
 // instructions less per use).
 // HG: host-supplied goals (the caller's [E][C][3] rows instead of the prologue's goal frames) -- an instantiation of its own, so that the
 // headline kernel carries neither the pointer nor the branches (as runtime branches they cost it 12 more spilled SGPRs and 1.5 us)
-template <int CR, bool DBG = false, bool HG = false>
+// GEN: the candidate generator (F1P_GEN_CLOTHOID; F1P_GEN_CUBIC: bracket_cubic_f32 and the table-driven station passes, round 5)
+template <int CR, bool DBG = false, bool HG = false, int GEN = F1P_GEN_CLOTHOID>
 __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
@@ -1646,6 +1843,9 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     float* c_fit = c_hi + nc;
     const int nfit = nc <= (int)blockDim.x ? nc : 0;
     unsigned char* c_st = reinterpret_cast<unsigned char*>(c_fit + 6 * nfit);   // [nc] state (bit 7: can no longer turn out FREE)
+    // cubic generator: the Hermite basis of every station [S] and the f32 copy of the previous headings [S] (candidate-independent)
+    CubicTab* ctab = reinterpret_cast<CubicTab*>((reinterpret_cast<uintptr_t>(c_st + nc) + 15) & ~(uintptr_t)15);
+    float* pftab = reinterpret_cast<float*>(ctab + (GEN == F1P_GEN_CUBIC ? cfg.n_stations : 0));
     // a workgroup takes egos blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher sizes the grid: F1P_MIX_F3_EGOS_PER_WG egos each)
 #if F1P_MIX_F3_EGOS_PER_WG > 1
     for (int e = a.e0 + blockIdx.x; e < a.E; e += gridDim.x) {
@@ -1663,6 +1863,13 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     }
     if (tid >= 128 && tid < 128 + F1P_MAX_WIDTHS) wtab[tid - 128] = tid - 128 < cfg.n_width ? cfg.width[tid - 128] : 0.0;
     if (tid == 0) cnt[0] = 0;
+    if (GEN == F1P_GEN_CUBIC) {
+        const int S_ = cfg.n_stations, den_ = S_ - 1 > 1 ? S_ - 1 : 1, sim_m_ = S_ - cfg.n_shift - cfg.n_cull;
+        for (int i = tid; i < S_; i += blockDim.x) {
+            ctab[i] = cubic_tab_row(i, den_);
+            pftab[i] = (a.prev_theta && i < sim_m_) ? (float)a.prev_theta[(size_t)e * S_ + i + cfg.n_shift] : 0.f;
+        }
+    }
 #ifdef F1P_F3_PHASES
     long long fph[10]; int nfp = 0, n_rounds = 0;
 #define F1P_FPH() do { fph[nfp++] = clock64(); } while (0)
@@ -1713,17 +1920,28 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         }
         const float r2 = gx * gx + gy * gy;
         const bool r_ok = (r2 > 1e-8f) & (r2 < 1e20f) & th_ok;                  // (tiny, huge or NaN in f32: the fp64 tests decide; g1_fit rejects r <= 1e-12 itself)
-        const Fit32 f = g1_fit_f32(gx, gy, gth32);
-        o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
-        const bool trusted = r_ok & f.ok;
-        k0 = f.k0; dk = f.dk; L = f.L; ek0 = f.ek0; edk = f.edk; eL = f.eLrel;
+        bool trusted;
+        int why = -1;
+        if constexpr (GEN == F1P_GEN_CUBIC) {
+            // the six values a candidate keeps for the station pass: its goal, the end tangent, the chord length, its longest station-to-station step
+            const CubBrk b = bracket_cubic_f32<CR>(gx, gy, gth32, ep, (const F1P_LDS(CubicTab)*)ctab, (const F1P_LDS(float)*)pftab, collide_on);
+            o.cost = b.cost; o.lo = b.lo; o.hi = b.hi; o.ebound = b.ebound; o.state = F1P_ST_PENDING; o.never_free = b.never_free;
+            trusted = r_ok & b.trusted;
+            k0 = gx; dk = gy; L = b.cx; ek0 = b.cy; edk = b.m; eL = b.maxch;
+        } else {
+            const Fit32 f = g1_fit_f32(gx, gy, gth32);
+            o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
+            trusted = r_ok & f.ok;
+            k0 = f.k0; dk = f.dk; L = f.L; ek0 = f.ek0; edk = f.edk; eL = f.eLrel;
+            why = (r_ok & !f.ok) ? f.why : -1;
+        }
         // no goal: BAD (infeasible in fp64 too);  no trusted bracket: UNSURE with lo = -inf (the fp64 tests decide);  else what bracket_f2 says
         // -- without a collision check (no map, or cfg.check_collision = 0) a trusted bracket is all there is to know: FREE
         int st = trusted ? (collide_on ? (o.state | (o.never_free ? 0x80 : 0)) : F1P_ST_FREE) : F1P_ST_UNSURE;
         st = gok ? st : F1P_ST_BAD;
         lo = gok ? (trusted ? o.lo : -INF) : INF;
         hi = (gok & trusted) ? o.hi : INF;
-        dbg_code = (gok & r_ok & !f.ok) ? f.why : -1;
+        dbg_code = gok ? why : -1;
         if (DBG && (mx.dbg_cost32 || mx.dbg_bound)) { if (!(gok & trusted)) { o.cost = INF; o.ebound = 0.f; } }   // (test hooks: what the nested version reported)
         return st;
     };
@@ -1853,7 +2071,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
                     float edge = 2.0f;
                     bool nfree = look == 0 && (st & 0x80) != 0;
-                    if (mine) { edge = edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex); nfree |= !(edge < 0.8f); }
+                    if (mine) { edge = GEN == F1P_GEN_CUBIC ? edge_cubic(edk, ep) : edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex); nfree |= !(edge < 0.8f); }
                     const int nt = ex ? plan_x.nt : plan.nt;
                     bool coop = false;
 #ifndef F1P_MIX_DEBUG_END
@@ -1862,20 +2080,25 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     // checks the claims of both)
                     coop = F1P_MIX_MACRO && nt <= 64 && (__builtin_popcountll(m) <= ((look == 1 && !(thr_is_T | bound_known)) ? 2 * F1P_MIX_COOP_MAX : F1P_MIX_COOP_MAX) || (all_states && (e & 1)));
 #endif
+                    PassPlan pl;
+                    pl.nt = nt; pl.nm = ex ? plan_x.nm : plan.nm; pl.first_m = ex ? plan_x.first_m : plan.first_m;
+                    pl.tail_m = ex ? plan_x.tail_m : plan.tail_m; pl.tail_pos = ex ? plan_x.tail_pos : plan.tail_pos;
                     if (coop) {
-                        PassPlan pl;
-                        pl.nt = nt; pl.nm = ex ? plan_x.nm : plan.nm; pl.first_m = ex ? plan_x.first_m : plan.first_m;
-                        pl.tail_m = ex ? plan_x.tail_m : plan.tail_m; pl.tail_pos = ex ? plan_x.tail_pos : plan.tail_pos;
                         for (unsigned long long mm = m; mm; mm &= mm - 1) {
                             const int sl = __ffsll((long long)mm) - 1;
                             const float uk0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k0), sl)), udk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), sl));
                             const float uL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L), sl)), uedge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edge), sl));
                             const bool unf = __builtin_amdgcn_readlane(nfree ? 1 : 0, sl) != 0;
-                            const int r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex);
+                            int r;
+                            if constexpr (GEN == F1P_GEN_CUBIC) {
+                                const float ucy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ek0), sl)), um_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edk), sl));
+                                r = station_pass_wave_cubic<CR>(uk0, udk, uL, ucy, um_, uedge, unf, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, lane, pl, ex);
+                            } else r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex);
                             if (lane == sl) ns = r;
                         }
                     } else if (mine) {
-                        ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex);
+                        if constexpr (GEN == F1P_GEN_CUBIC) ns = station_pass_cubic<CR>(k0, dk, L, ek0, edk, edge, nfree, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, pl, ex);
+                        else ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex);
                         if (DBG && mx.dbg_pass) atomicAdd(&mx.dbg_pass[4 * (size_t)e + 1], 1);
                     }
                     if (DBG && mx.dbg_pass && mine) atomicAdd(&mx.dbg_pass[4 * (size_t)e + (look == 0 ? 0 : 3)], 1);
@@ -2475,7 +2698,124 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
     }
 }
 
+// The fp64 evaluation of a CUBIC queue entry (round 5): station_loop<GEN = cubic>'s arithmetic (lattice_device.h) with the stations spread
+// over the group's lanes -- every station is closed-form (cubic_row), so only the three running sums are sequential: the chord lengths,
+// |kappa| and the similarity terms are formed in parallel, left in LDS, and lanes 0 / 1 / 2 of the group add them up in station order
+// (+ 0.0 past a sum's last term: an identity, the sums start at + 0.0 and their terms are >= 0); the maximum is order-independent.
+// Cost, index and rows are therefore the all-fp64 kernel's, bit for bit.  16 lanes per entry, four entries per wave.
+template <int GS>
+__global__ __launch_bounds__(256, 2) void k_lattice_refine_cubic(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
+    constexpr int GPW = 64 / GS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gl = lane & (GS - 1), grp = lane / GS, gbase = lane & ~(GS - 1);
+    const int S = cfg.n_stations;
+    if (mx.perm_fill) {                                          // the dispatch order's slots and counters (see k_lattice_refine)
+        const int np = F1P_MIX_OREG * mx.perm_rs;
+        for (int i = (int)(blockIdx.x * blockDim.x) + tid; i < np; i += (int)(gridDim.x * blockDim.x)) mx.perm_fill[i] = 0;
+        if (blockIdx.x == 0 && tid < 2 * F1P_MIX_OREG) mx.ocnt[tid * 32u] = 0u;
+    }
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    const unsigned int ngroups_total = gridDim.x * (blockDim.x >> 6) * GPW;
+    const unsigned int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * GPW + grp;
+    const unsigned int sh = (g0 / GPW) % F1P_MIX_QSHARDS, lstride = ngroups_total / F1P_MIX_QSHARDS;
+    const unsigned int li_first = (g0 / (GPW * F1P_MIX_QSHARDS)) * GPW + g0 % GPW;
+    const unsigned int n = mx.qcount[sh * 32u];
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    const int sim_m = S - cfg.n_shift - cfg.n_cull;
+    double* px = reinterpret_cast<double*>(lds_raw) + (size_t)(wave * GPW + grp) * 5 * (size_t)S;   // [S] station x
+    double* py = px + S;                                         // [S] station y
+    double* chv = py + S;                                        // [S] chord length into the station (0 for station 0)
+    double* akv = chv + S;                                       // [S] |kappa|
+    double* simv = akv + S;                                      // [S] similarity term
+    for (unsigned int li = li_first; ; li += lstride) {
+        const bool live = li < n;
+        if (!__any(live)) break;                                 // wave-uniform exit
+        const unsigned int i = sh * mx.q_shard_cap + li;
+        RefEntry r;
+        r.ok = 0; r.e = a.e0; r.c = 0; r.gx = 0; r.gy = 0; r.gth = 0; r.cost = 0; r.k0 = 0; r.dk = 0; r.L = 0; r.pad = 0;
+        if (live) r = mx.q[i];
+        const bool work = live && r.ok != 0;                     // ok == 0: no goal -- the filter wrote cost = +inf
+        const int e = r.e;
+        const bool check_occ = collide_on && r.ok != -2;
+        EgoXform xf = {};
+        if (work && check_occ) xf = mx.xf[e];
+        const double* prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+        Cubic cq = cubic_setup(r.gx, r.gy, r.gth);
+        const bool run = work && cq.ok;
+        bool hit = false;
+        double maxk = 0.0;
+        for (int q = gl; q < S; q += GS) {
+            double x = 0.0, y = 0.0, th = 0.0, ak = 0.0;
+            if (run) cubic_row(cq, (double)q / (double)den, x, y, th, ak);
+            px[q] = x; py[q] = y; akv[q] = ak;
+            double sv = 0.0;
+            if (run && prev && q < sim_m) { const double d = th - prev[q + cfg.n_shift]; sv = d * d; }
+            simv[q] = sv;
+            maxk = __builtin_fmax(maxk, ak);
+            if (run && check_occ) {                              // k_lattice's own cell arithmetic on the ego's tile-relative transform (NaN / off-map: occupied)
+                uint32_t word = 0xffffffffu; int bit = 0;
+                const double lxf = __builtin_floor(__builtin_fma(xf.txx, x, __builtin_fma(xf.txy, y, xf.tx0)));
+                const double lyf = __builtin_floor(__builtin_fma(xf.tyx, x, __builtin_fma(xf.tyy, y, xf.ty0)));
+                const double gxf = lxf + (double)xf.tile_gx0, gyf = lyf + (double)xf.tile_gy0;
+                if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
+                    const int cgx = (int)gxf, cgy = (int)gyf;
+                    word = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
+                    bit = cgx & 31;
+                }
+                hit |= ((word >> bit) & 1u) != 0u;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int q = gl; q < S; q += GS) {                       // the chord INTO station q: the loop's `if (i > 0) len += sqrt(ddx^2 + ddy^2)`
+            double ch = 0.0;
+            if (q > 0) { const double ddx = px[q] - px[q - 1], ddy = py[q] - py[q - 1]; ch = __builtin_sqrt(ddx * ddx + ddy * ddy); }
+            chv[q] = ch;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // lanes 0 / 1 / 2 of the group: len / sumk / sim, station order, eight operands read ahead of their eight additions
+        double acc = 0.0;
+        {
+            const double* arr = gl == 0 ? chv : (gl == 1 ? akv : simv);
+            const int cnt = gl == 2 ? (sim_m > 0 ? sim_m : 0) : S;
+            int q = 0;
+            for (; q + 8 <= S; q += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = arr[q + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (q + u < cnt) ? v[u] : 0.0;
+            }
+            for (; q < S; ++q) acc += q < cnt ? arr[q] : 0.0;
+        }
+#pragma unroll
+        for (int m_ = GS / 2; m_ >= 1; m_ >>= 1) maxk = __builtin_fmax(maxk, shfl_xor_d(maxk, m_));   // (within the group: GS is a power of two, the partners stay inside it)
+        const double len = shfl_d(acc, gbase), sumk = shfl_d(acc, gbase + 1), sim = shfl_d(acc, gbase + 2);
+        const unsigned long long hm = __ballot(hit);
+        const bool any_hit = ((hm >> gbase) & (GS == 64 ? ~0ull : (1ull << (GS & 63)) - 1ull)) != 0ull;
+        double cost = __builtin_huge_val();
+        if (run) {
+            cost = 0.0;                                          // eval(): cost = 0.; cost += w_i * f_i
+            cost += cfg.w_length * (1.0 / len);
+            cost += cfg.w_max_kappa * maxk;
+            cost += cfg.w_mean_kappa * (sumk / (double)S);
+            cost += cfg.w_similarity * (prev ? sim : 0.0);
+            if (any_hit) cost = __builtin_huge_val();
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (work && gl == 0) {
+            RefEntry o = r;
+            o.cost = cost; o.k0 = r.gx; o.dk = r.gy; o.L = r.gth; o.ok = run ? 1 : 0; o.pad = 0;   // (k0, dk, L) carries the goal pose, as in k_lattice
+            mx.q[i] = o;
+        }
+    }
+}
+
 // wave per ego: select() over the refined candidates, winner re-emission, tracking (the tail of k_lattice_eval)
+template <int GEN = F1P_GEN_CLOTHOID>
 __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
@@ -2595,7 +2935,8 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     if (lane == 0 && mx.dbg_cost32 && (size_t)e * 8 + 8 <= (size_t)a.E * cfg.n_lookahead * cfg.n_width)
         for (int k = 0; k < 5; ++k) mx.dbg_cost32[(size_t)a.E * cfg.n_lookahead * cfg.n_width / 2 + (size_t)e * 8 + k] = (float)(sph[k + 1] - sph[k]);
 #else
-    if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);
+    if constexpr (GEN == F1P_GEN_CUBIC) emit_and_track<F1P_GEN_CUBIC>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);   // (k0, dk, L) = the goal pose
+    else if (have_inc) emit_and_track<F1P_GEN_CLOTHOID, true>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);
     else emit_and_track<F1P_GEN_CLOTHOID>(a, cfg, e, lane, ni, den, cl, bc, tr_x, tr_y, inc_x, inc_y, nullptr, &v_near);
 #endif
 }
@@ -2712,7 +3053,9 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // take the pair too -- they used to fall to the one-kernel fallback filter from 320 egos and to the all-fp64 kernel below
     const bool v3_likely = F1P_MIX_FILTER_V3 && !foot && (!collide || (clear_ok && (clear_r_eff == 1 || clear_r_eff == 2))) && a.tile_words + 1 <= 16;
     const int min_egos = v3_likely ? F1P_MIX_MIN_EGOS_V3 : F1P_MIX_MIN_EGOS;
-    if (ctx->lattice_mixed && (!foot || clear_ok) && !cubic && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
+    // round 5: the cubic generator takes the pair as well (device-sampled goals, up to 256 stations: its basis table lives in LDS); otherwise all fp64
+    const bool cubic_ok = !cubic || (v3_likely && !a.goals && S <= 256);
+    if (ctx->lattice_mixed && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
         (E >= min_egos || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t tile_bytes = sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
         size_t lds_f = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS) + sizeof(EgoParams) + sizeof(EgoParams32) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
@@ -2726,7 +3069,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
         // filter and the selection kernel and leave the queue counter armed)
         const bool groups16 = foot ? lds_fits(ctx, k_lattice_refine<16, true>, lds_r16 + lds_r_static) : lds_fits(ctx, k_lattice_refine<16>, lds_r16 + lds_r_static);
         const bool refine_fits = groups16 || (foot ? lds_fits(ctx, k_lattice_refine<64, true>, lds_r64 + lds_r_static) : lds_fits(ctx, k_lattice_refine<64>, lds_r64 + lds_r_static));
-        if (lds_fits(ctx, k_lattice_filter<0>, lds_f) && lds_fits(ctx, k_lattice_filter<1>, lds_f) && lds_fits(ctx, k_lattice_filter<2>, lds_f) && lds_fits(ctx, k_lattice_filter<1, true>, lds_f) && lds_fits(ctx, k_lattice_filter<2, true>, lds_f) && refine_fits && lds_fits(ctx, k_lattice_select, lds_s)) {
+        if (lds_fits(ctx, k_lattice_filter<0>, lds_f) && lds_fits(ctx, k_lattice_filter<1>, lds_f) && lds_fits(ctx, k_lattice_filter<2>, lds_f) && lds_fits(ctx, k_lattice_filter<1, true>, lds_f) && lds_fits(ctx, k_lattice_filter<2, true>, lds_f) && refine_fits && lds_fits(ctx, k_lattice_select<F1P_GEN_CLOTHOID>, lds_s)) {
             MixArgs mx;
             mx.margin_rel = F1P_MIX_MARGIN_REL; mx.margin_abs = F1P_MIX_MARGIN_ABS; mx.edge0 = F1P_MIX_EDGE0; mx.edge1 = F1P_MIX_EDGE1;
             if (ctx->dbg_margins) { mx.margin_rel = ctx->dbg_margin_rel; mx.margin_abs = ctx->dbg_margin_abs; }   // test hook (f1p_lattice_debug_margins)
@@ -2751,10 +3094,18 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             const size_t rec_stride = ego_rec_stride(cfg->n_lookahead);
             const size_t tile2_bytes = sizeof(uint32_t) * (size_t)(a.tile_rows + 1) * (a.tile_words + 1);
             size_t lds_f3 = 2 * tile2_bytes + 16 + rec_stride + sizeof(double) * F1P_MAX_WIDTHS + sizeof(float) * 24 + sizeof(int) * 4 + (size_t)n_cand * 9 + (n_cand <= F1P_MIX_FILTER_BLOCK ? (size_t)n_cand * 24 : 0) + 16;
+            if (cubic) lds_f3 += 16 + (size_t)S * (sizeof(CubicTab) + sizeof(float));   // the basis table + the previous headings
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
-            const bool v3 = F1P_MIX_FILTER_V3 && mx.n_disc == 0 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
+            const size_t lds_rc = sizeof(double) * 16 * 5 * (size_t)S;                      // k_lattice_refine_cubic: five station arrays per group
+            bool v3 = F1P_MIX_FILTER_V3 && mx.n_disc == 0 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
                             (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
                                               : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
+            if (cubic) {
+                v3 = v3 && !a.goals && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
+                     (mx.clear_r == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3)
+                                       : lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), lds_f3));
+                if (!v3) return F1P_OK;                              // (not handled: the all-fp64 kernel takes the plan)
+            }
             // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the
             // first (it waits for the first prologue): one chunk's latency-bound kernels (prologue, refinement, selection: a few waves
             // per SIMD) run beside the other's VALU-bound candidate kernel instead of after it.  Every chunk has its own queue region
@@ -2866,7 +3217,15 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     const unsigned f3_grid = mk.perm ? (unsigned)(F1P_MIX_OREG * mk.perm_rs) : (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
                     const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
                     const unsigned char* recs = (const unsigned char*)ctx->d_rec_scratch;
-                    if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
+                    if (cubic) {
+                        if (mk.clear_r == 1) {
+                            if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        } else {
+                            if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        }
+                    } else if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
                         if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL((k_lattice_filter3<2, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     } else if (mk.clear_r == 1) {
@@ -2890,7 +3249,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 if (rb > rb_max) rb = rb_max;
                 rb = rb & ~(size_t)15;
                 if (rb < 16) rb = 16;
-                if (groups16) {
+                if (cubic) hipLaunchKernelGGL(k_lattice_refine_cubic<16>, dim3((unsigned)rb), dim3(256), lds_rc, st, ak, *cfg, mk);
+                else if (groups16) {
                     if (mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine<16, true>), dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
                     else hipLaunchKernelGGL(k_lattice_refine<16>, dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
                 } else {
@@ -2899,7 +3259,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 }
                 if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_refine launch"))) break;
                 if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[3], st));
-                hipLaunchKernelGGL(k_lattice_select, dim3((Ek + 3) / 4 + (mk.perm_fill ? (Ek + 255) / 256 : 0)), dim3(256), lds_s, st, ak, *cfg, mk);
+                if (cubic) hipLaunchKernelGGL(k_lattice_select<F1P_GEN_CUBIC>, dim3((Ek + 3) / 4 + (mk.perm_fill ? (Ek + 255) / 256 : 0)), dim3(256), lds_s, st, ak, *cfg, mk);
+                else hipLaunchKernelGGL(k_lattice_select<F1P_GEN_CLOTHOID>, dim3((Ek + 3) / 4 + (mk.perm_fill ? (Ek + 255) / 256 : 0)), dim3(256), lds_s, st, ak, *cfg, mk);
                 rc = check_hip(ctx, hipGetLastError(), "k_lattice_select launch");
                 if (mk.perm_fill) ctx->order_valid = rc == F1P_OK;
             }

@@ -138,6 +138,74 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
     assert worst < 3.0e-5 / 10, worst                                              # margin_rel = 3e-5: >= 10x above the measured error
 
 
+def test_cubic_generator_under_the_mixed_schedule(ctx, scene):
+    """round 5: cubic-spline candidates take the prologue + candidate-kernel pair (bracket_cubic_f32: an f32 walk over the stations with an
+    a-priori error bound; table-driven station passes; k_lattice_refine_cubic).  The bracket's premises, measured through the debug hook --
+    bound >= |cost32 - cost64| candidate by candidate, FREE is free and HIT collides in fp64 -- and bit-identity with the all-fp64 kernel on
+    centred, wall-hugging and obstacle scenes, previous paths included; other station counts and goal grids; more than 256 stations and
+    host goals stay with the all-fp64 kernel"""
+    rl, img, origin = scene
+    res = 0.058
+    E, C, S = 768, 256, 50
+    worst = 0.0
+    img_o, _ = synth.stamp_obstacles(img, origin, res, rl, spacing=6.0, radius=0.25, lateral=0.2)
+    try:
+        for sigma, seed, prev_kind, im in ((0.3, 1, None, img), (0.8, 2, "noise", img), (0.3, 3, "winners", img), (0.4, 4, "winners", img_o)):
+            ctx.set_grid(im, res, origin, 206)
+            cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S, generator="cubic")
+            poses = synth.make_egos(rl, E, seed=seed, pos_sigma=sigma)
+            poses[0, :2] += 400.0; poses[1, 2] += np.pi
+            d_poses = ctx.to_device(poses)
+            out = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
+            d_all, d_c32, d_st, d_bd = ctx.alloc(8 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C), ctx.alloc(4 * E * C)
+            prev = None
+            if prev_kind == "noise":
+                prev = np.random.default_rng(seed).normal(0, 0.3, (E, S))
+            elif prev_kind == "winners":
+                ctx.lattice_set_mode(0)
+                prev = ctx.lattice_plan(poses, cfg)["best_traj"][:, :, 2] + (0.0 if seed == 3 else np.random.default_rng(seed).normal(0, 1e-3, (E, S)))
+            d_prev = None if prev is None else ctx.to_device(prev)
+            ctx.lattice_set_mode(0)
+            ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_all_cost=d_all, d_prev_theta=d_prev)
+            c64 = d_all.download(np.float64, (E, C))
+            want = ctx.lattice_plan(poses, cfg, prev_theta=prev)
+            ctx.lattice_set_mode(2, d_c32, d_st); ctx.lattice_debug_bound(d_bd)
+            ctx.lattice_plan_dev(d_poses, E, cfg, *out, d_prev_theta=d_prev)
+            ctx.lattice_set_mode(2); ctx.lattice_debug_bound(None)
+            got = ctx.lattice_plan(poses, cfg, prev_theta=prev); nq = ctx.lattice_debug_queue(E)
+            ctx.lattice_set_mode(1)
+            for k in NAMES:
+                np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+            assert 1.0 <= nq.mean() < 8.0                                              # the mixed schedule ran, and its queue is a few entries per ego
+            c32 = d_c32.download(np.float32, (E, C)).astype(np.float64); st = d_st.download(np.int32, (E, C))
+            bound = d_bd.download(np.float32, (E, C)).astype(np.float64)
+            fin = np.isfinite(c64)
+            assert not ((st == 0) & ~fin).any(), "a FREE candidate collides in fp64"
+            assert not ((st == 1) & fin).any(), "a HIT candidate is collision-free in fp64"
+            both = fin & (st < 3) & np.isfinite(c32)
+            err = np.abs(c32[both] - c64[both])
+            worst = max(worst, float((err / np.abs(c64[both])).max()))
+            assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())   # the a-priori bound holds, candidate by candidate
+            assert np.median(bound[both] / np.abs(c64[both])) < 1e-3 and both.mean() > 0.5          # ... without being vacuous
+            for b in out + [d_all, d_c32, d_st, d_bd, d_poses] + ([d_prev] if d_prev is not None else []):
+                b.free()
+        assert worst < 3.0e-5, worst                                                        # (measured 1.2e-5: sums over 50 stations in f32; the per-candidate bound above is what the bracket rests on)
+        ctx.set_grid(img, res, origin, 206)
+        # other shapes: few / many stations, ragged goal grids, more candidates than threads; S > 256 and host goals: all fp64 (same outputs either way)
+        for S2, nl, nw, E2 in ((2, 3, 5, 300), (7, 16, 16, 300), (120, 8, 9, 300), (50, 20, 40, 60), (300, 4, 8, 40)):
+            cfg2 = _abi.lattice_cfg(lookaheads=np.linspace(0.5, 3.2, nl), widths=np.linspace(-1.1, 1.1, nw), n_stations=S2, weights=(0.3, 0.2, 0.4, 0.1), generator="cubic")
+            p2 = synth.make_egos(rl, E2, seed=S2 + nl, pos_sigma=0.5, yaw_sigma=0.4)
+            a2 = _both(ctx, p2, cfg2)
+            _both(ctx, p2, cfg2, prev_theta=a2["best_traj"][:, :, 2] + 0.02)
+        rng = np.random.default_rng(5)
+        goals = np.stack([np.column_stack([rng.uniform(0.3, 3.0, 64), rng.uniform(-1.2, 1.2, 64), rng.uniform(-1.0, 1.0, 64)]) for _ in range(200)])
+        cfgh = _abi.lattice_cfg(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=40, weights=(0.25,) * 4, generator="cubic")
+        _both(ctx, synth.make_egos(rl, 200, seed=9), cfgh, goals=goals)
+    finally:
+        ctx.set_grid(img, res, origin, 206)
+        ctx.lattice_set_mode(1); ctx.lattice_debug_bound(None)
+
+
 def test_second_look_and_dispatch_order_on_obstacle_maps(scene):
     """round 5: discs of occupied cells on the raceline (the cheapest candidates of the egos behind one collide, the ones that skirt it meet
     cells that are not clear).  (a) the filter's claims hold with the second look in play: FREE is free and HIT collides in fp64, on every
