@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from f1tenth_planning_amd._abi import KmpcCfg, LatticeCfg  # noqa: E402  (struct layouts of include/f1p.h)
+from oracle.structs import KmpcCfg, LatticeCfg, StmpcCfg, mirror  # noqa: E402  (the oracle's OWN struct mirrors, generated from include/f1p.h)
 
 LIB = os.path.join(HERE, "liborc.so")
 ASAN_LIB = os.environ.get("F1P_ORACLE_LIB")     # the sanitizer build (make -C oracle asan), CPU test leg only
@@ -180,6 +180,7 @@ def lattice_plan_batch(poses, waypoints, cfg: LatticeCfg, grid=None, goals=None,
                        nthreads=1, cols=(0, 1, 2, 3)):
     """LatticePlanner.plan (lattice_planner.py:174-214) over poses [E,4]; waypoints rows [x, y, v, psi, ...].
     grid = (img, res, ox, oy, occupied_below) or None."""
+    cfg = mirror(cfg, LatticeCfg)                         # field by field into the header's own layout (oracle/structs.py)
     poses = _f64(poses); wp = _f64(waypoints)
     wx, wy, wv, wpsi = (_f64(wp[:, c]) for c in cols)
     E = poses.shape[0]; Cn = cfg.n_cand; S = cfg.n_stations
@@ -200,6 +201,7 @@ def lattice_plan_batch(poses, waypoints, cfg: LatticeCfg, grid=None, goals=None,
 
 
 def lattice_goals(pose, waypoints, cfg: LatticeCfg, cols=(0, 1, 2, 3)):
+    cfg = mirror(cfg, LatticeCfg)                         # field by field into the header's own layout (oracle/structs.py)
     wp = _f64(waypoints)
     wx, wy, wv, wpsi = (_f64(wp[:, c]) for c in cols)
     _, _, t, i = nearest_point(pose[:2], wp[:, [cols[0], cols[1]]])
@@ -212,12 +214,14 @@ def lattice_goals(pose, waypoints, cfg: LatticeCfg, cols=(0, 1, 2, 3)):
 
 # ---- kinematic MPC ---------------------------------------------------------------------------------------
 def update_state_kinematic(state, a, delta, cfg: KmpcCfg):
+    cfg = mirror(cfg, KmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     s = _f64(state).copy()
     lib().orc_update_state_kinematic(_p(s), C.c_double(a), C.c_double(delta), C.byref(cfg))
     return s
 
 
 def predict_motion_kinematic(x0, oa, od, cfg: KmpcCfg):
+    cfg = mirror(cfg, KmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     x0 = _f64(x0); oa = _f64(oa); od = _f64(od)
     path = np.zeros((4, cfg.horizon + 1))
     lib().orc_predict_motion_kinematic(_p(x0), _p(oa), _p(od), C.byref(cfg), _p(path))
@@ -236,6 +240,7 @@ def calc_ref_trajectory(state, cx, cy, cyaw, sp, T, dt=0.1, dl=0.03):
 
 
 def kmpc_shoot_batch(x0, ref, controls, cfg: KmpcCfg, want_all=False, nthreads=1):
+    cfg = mirror(cfg, KmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     x0 = _f64(x0); ref = _f64(ref); controls = np.ascontiguousarray(controls, dtype=np.float32)
     E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
     assert controls.shape == (E, T, 2, R) and ref.shape == (E, 4, T + 1)
@@ -268,6 +273,7 @@ def kmpc_gen_controls(seed, call, E, cfg: KmpcCfg, sigma_a, sigma_d, warm=None):
 
 def kmpc_plan_batch(x0, ref, cfg: KmpcCfg, seed, call, sigma_a, sigma_d, warm=None, nthreads=1):
     """f1p_kmpc_plan_*: generate around `warm` ([E, T, 2] f32 or None), shoot, return outputs + the next warm start"""
+    cfg = mirror(cfg, KmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     x0 = _f64(x0); ref = _f64(ref); E = x0.shape[0]; T = cfg.horizon
     w = np.zeros((E, T, 2), np.float32) if warm is None else np.ascontiguousarray(warm, np.float32).copy()
     out = dict(steer=np.zeros(E), speed=np.zeros(E), best_idx=np.zeros(E, np.int32), best_cost=np.zeros(E), best_seq=np.zeros((E, T, 2)))
@@ -305,12 +311,14 @@ def lqr_batch(states, err, waypoints, wheelbase=0.33, ts=0.01, q=(0.999, 0.0, 0.
 
 # ---- dynamic single-track model -----------------------------------------------------------
 def update_state_dynamic(state, a, delta_v, cfg):
+    cfg = mirror(cfg, StmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     s = _f64(state).copy()
     lib().orc_update_state_dynamic(_p(s), C.c_double(a), C.c_double(delta_v), C.byref(cfg))
     return s
 
 
 def predict_motion_dynamic(x0, oa, od_v, cfg):
+    cfg = mirror(cfg, StmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     x0 = _f64(x0); oa = _f64(oa); od = _f64(od_v)
     path = np.zeros((7, cfg.horizon + 1))
     lib().orc_predict_motion_dynamic(_p(x0), _p(oa), _p(od), C.byref(cfg), _p(path))
@@ -329,6 +337,7 @@ def calc_ref_trajectory_dynamic(state, cx, cy, cyaw, sp, T, dt=0.025, dl=0.03):
 
 
 def stmpc_shoot_batch(x0, ref, controls, cfg, nthreads=1):
+    cfg = mirror(cfg, StmpcCfg)                         # field by field into the header's own layout (oracle/structs.py)
     x0 = _f64(x0); ref = _f64(ref); controls = np.ascontiguousarray(controls, dtype=np.float32)
     E = x0.shape[0]; T = cfg.horizon; R = cfg.n_rollouts
     assert controls.shape == (E, T, 2, R) and ref.shape == (E, 7, T + 1)

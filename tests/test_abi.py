@@ -60,3 +60,37 @@ def test_no_gpu_means_no_context():
     from f1tenth_planning_amd.runtime import Context, F1PError
     with pytest.raises(F1PError):
         Context(0)
+
+
+def test_struct_mirrors_match_the_compiler(tmp_path):
+    """the product's ctypes structs (_abi.py) and the oracle's own mirrors (oracle/structs.py, generated from
+    include/f1p.h) both against what gcc lays out for the header: size and every field's offset.  The oracle copies incoming
+    configurations into ITS mirrors field by field, so a mistake in _abi.py cannot be shared by the checker."""
+    import subprocess
+    from oracle import structs
+    pairs = (("f1p_lattice_cfg", _abi.LatticeCfg, structs.LatticeCfg), ("f1p_kmpc_cfg", _abi.KmpcCfg, structs.KmpcCfg),
+             ("f1p_stmpc_cfg", _abi.StmpcCfg, structs.StmpcCfg), ("f1p_kmpc_sampler", _abi.KmpcSampler, structs.KmpcSampler))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "f1p.h"', 'int main(void) {']
+    for name, _, mine in pairs:
+        lines.append(f'printf("{name} %zu", sizeof({name}));')
+        for f, _ct in mine._fields_:
+            lines.append(f'printf(" {f}:%zu", offsetof({name}, {f}));')
+        lines.append('printf("\\n");')
+    lines += ['return 0; }']
+    src = tmp_path / "probe.c"; src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().split("\n")
+    for (name, prod, mine), line in zip(pairs, out):
+        toks = line.split()
+        assert toks[0] == name
+        size = int(toks[1]); offs = dict((t.split(":")[0], int(t.split(":")[1])) for t in toks[2:])
+        for cls in (prod, mine):
+            assert C.sizeof(cls) == size, (name, cls.__name__)
+            assert [f[0] for f in cls._fields_] == list(offs), (name, cls.__name__)
+            for f, _ct in cls._fields_:
+                assert getattr(cls, f).offset == offs[f], (name, cls.__name__, f)
+    # the by-name copy: a product-side struct reaches the oracle's layout unchanged
+    cfg = _abi.lattice_cfg(lookaheads=[0.7, 1.9], widths=[-0.5, 0.0, 0.5], n_stations=33, weights=(0.1, 0.2, 0.3, 0.4), n_shift=2, n_cull=1)
+    own = structs.mirror(cfg, structs.LatticeCfg)
+    assert bytes(own) == bytes(cfg) and own.n_cand == 6
