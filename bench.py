@@ -864,6 +864,224 @@ def algorithmic_ops(poses, rl, cfg, grid, prev_in, n_egos=3, stride=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def leg_host_boundary_latency(ctx, args, poses, cfg, S, steady):
+    """p50 / p95 latency of one plan() at the ctypes boundary: host poses in, host results out (H2D + kernel + D2H + sync).  Runs on every
+    rank BEFORE the timed region (it also brings the chip's clocks up, so a short --steps run is not measuring the ramp from idle).  Closed
+    loop: the similarity term is live in every one of these calls, nothing extra crosses PCIe."""
+    import copy
+    import numpy as np
+    from f1tenth_planning_amd import synth
+
+    def percentiles(fn):
+        for _ in range(20):                                  # SURVEY.md 8d: 20 warm-up + 200 timed calls
+            fn()
+        ts = []
+        for _ in range(args.latency_iters):
+            t1 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return float(np.percentile(ts, 50)), float(np.percentile(ts, 95))
+    p50, p95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
+    q50, q95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True))
+    r50, r95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=False, reuse_outputs=True))
+    h50, h95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True, traj_dtype=np.float32))
+    c50, c95 = percentiles(lambda: ctx.lattice_step(poses, cfg))
+    cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
+    ctx.lattice_set_mode(0)
+    b50, b95 = percentiles(lambda: ctx.lattice_plan(poses, cfg_bb, want_traj=True, reuse_outputs=True))
+    f50, f95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
+    ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
+    # BASELINE configs[1]: ONE ego x 512 candidates x 50 stations, the single-vehicle call
+    cfg1 = synth.bench_lattice_cfg(n_cand=512, n_stations=S)
+    ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)       # another batch shape: re-armed
+    s50, s95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True))
+    ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)
+    return {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
+            "includes": "H2D poses + kernels + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays; "
+                        "closed loop: the similarity term is live (previous headings stay on the device)",
+            "closed_loop": {"p50_ms": c50, "p95_ms": c95,
+                            "note": "f1p_lattice_step_batch: poses in, (steer, speed, status) out as ONE packed block the selection kernel writes straight "
+                                    "into page-locked host memory; previous headings and best_traj stay on the device (f1p_lattice_fetch_traj on request)"},
+            "pageable_host_arrays": {"p50_ms": q50, "p95_ms": q95},
+            "without_best_traj": {"p50_ms": r50, "p95_ms": r95},
+            "f32_best_traj": {"p50_ms": h50, "p95_ms": h95,
+                              "note": "f1p_lattice_plan_batch_f32: the same fp64 plan, best_traj rounded once to f32 on the device (3.3 MB instead of 6.6 MB down)"},
+            "all_fp64": {"p50_ms": f50, "p95_ms": f95},
+            "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"},
+            "config1_single_ego": {"p50_ms": s50, "p95_ms": s95, "workload": f"1 ego x 512 candidates x {S} stations (BASELINE configs[1]), Context.lattice_plan"}}
+
+
+def leg_other_schedules(ctx, args, cfg, d_poses, d_prev_in, E, C, S, ref):
+    """The same plan by the other schedules, every one checked bit for bit against the chain's plan (same previous path):
+      all_fp64          the plain kernel (one fp64 thread per candidate; round 1's headline kernel)
+      branch_and_bound  all fp64 with cfg.prune = 1 (station loops skipped while a cost lower bound exceeds the best so far)
+      every_station     the default schedule with f1p_lattice_set_clearance(0): every station looked up in the bitmap, single intervals
+    `ref` = (bidx, ref_cost, steer, ref_traj) of the chain's plan.  Returns (fp64, bnb, every_station)."""
+    import copy
+    import numpy as np
+    bidx, ref_cost, steer, ref_traj = ref
+    alt = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
+
+    def other(cfg_x, mode):
+        ctx.lattice_set_mode(mode)
+        for _ in range(args.warmup):
+            ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
+        ctx.sync()
+        ctx.timer_begin()
+        for _ in range(args.steps):
+            ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
+        ms = ctx.timer_end() / args.steps
+        same = bool((alt[2].download(np.int32, (E,)) == bidx).all() and
+                    np.array_equal(alt[3].download(np.float64, (E,)), ref_cost, equal_nan=True) and
+                    np.array_equal(alt[0].download(np.float64, (E,)), steer) and
+                    np.array_equal(alt[6].download(np.float64, (E, S, 4)), ref_traj))
+        return {"kernel_ms": ms, "candidate_steps_per_s_equivalent": float(E) * C * S / (ms * 1e-3), "outputs_bit_identical_to_the_timed_plan": same}
+    cfg_ex = copy.copy(cfg); cfg_ex.prune = 0
+    cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
+    every_station = None
+    fp64 = other(cfg_ex, 0)
+    fp64["note"] = "f1p_lattice_set_mode(0): every candidate-step in fp64, one thread per candidate (k_lattice)"
+    bnb = other(cfg_bb, 0)
+    bnb["note"] = "all fp64 + cfg.prune = 1: candidates sorted by a lower bound of their cost after the fit; a station loop runs only while the bound does not exceed the best cost found"
+    if not (args.all_fp64 or args.prune):
+        ctx.lattice_set_clearance(0)
+        every_station = other(cfg_ex, 1)
+        every_station["note"] = ("the default schedule with f1p_lattice_set_clearance(0): the f32 filter integrates every station interval as a piece "
+                                 "of its own and looks every station up in the bitmap (49 pieces, 50 look-ups per candidate)")
+        ctx.lattice_set_clearance(2)
+    ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
+    for b_ in alt:
+        b_.free()
+    return fp64, bnb, every_station
+
+
+def leg_kernel_profile(ctx, step, d_prev_in, n, E, C):
+    """per-kernel durations of the default schedule (HIP events between its kernels, outside the timed region), same previous path; and the
+    entries per ego the filter of that last plan handed to the fp64 refinement"""
+    import numpy as np
+    ctx.lattice_profile(True)
+    acc = np.zeros(4)
+    for _ in range(n):
+        step(d_prev_in)
+        acc += np.array(ctx.lattice_profile(True, read=True))
+    ctx.lattice_profile(False)
+    acc /= n
+    mixed_ms = {"k_lattice_prologue": float(acc[0]), "k_lattice_filter3": float(acc[1]), "k_lattice_refine": float(acc[2]), "k_lattice_select": float(acc[3])}
+    try:
+        nq = ctx.lattice_debug_queue(E)
+        pass_stat = {"mean": float(nq.mean()), "p99": float(np.percentile(nq, 99)), "max": int(nq.max()), "of": C,
+                     "note": "entries per ego handed to the fp64 refinement (scene_sweep counts the station pass itself: f1p_lattice_debug_pass)"}
+    except Exception as exc:   # noqa: BLE001 -- a statistic, not a gate
+        pass_stat = {"error": str(exc)}
+    return mixed_ms, pass_stat
+
+
+def leg_audit(ctx, step, d_prev_in, n_aud, E):
+    """runtime audit of the mixed schedule (f1p_lattice_set_audit): the timed plan again, every plan followed by the all-fp64 exhaustive
+    kernel on a moving window of 256 egos and a bit-for-bit comparison of every output; outside the timed region"""
+    ctx.lattice_audit_read(reset=True)
+    ctx.lattice_set_audit(1, min(256, E))
+    for _ in range(n_aud):
+        step(d_prev_in)
+    audit = ctx.lattice_audit_read(reset=True)
+    ctx.lattice_set_audit(0)
+    audit["note"] = ("every audited plan (similarity term live): all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs "
+                     "compared bit for bit; mismatching_egos must be 0")
+    return audit
+
+
+def lattice_valu_and_traffic(args, E, C, S, mixed_ms, kernel_ms, cand_sharded):
+    """The dominant kernel's issue-slot figures and the plan's HBM traffic, from the newest committed PMC profile of this configuration
+    (parsed at run time: no pasted constants).  Returns (dom_ms, pmc, same_cfg, valu, traffic)."""
+    dom_ms = mixed_ms["k_lattice_filter3"] if mixed_ms else kernel_ms         # the dominant kernel's own average duration
+    pmc = load_pmc({"egos": E, "cands": C, "stations": S, "workload": args.workload, "generator": args.generator,
+                    "schedule": "all_fp64" if args.all_fp64 else ("bnb" if args.prune else "mixed")})
+    same_cfg = bool(pmc and not cand_sharded)
+    valu = None
+    if same_cfg and pmc.get("SQ_INSTS_VALU") and pmc.get("waves"):
+        per_cand = pmc["SQ_INSTS_VALU"] / pmc["waves"]            # wave-instructions per wave = lane-instructions per candidate (one lane per candidate)
+        valu_tlanes = per_cand * E * C / (dom_ms * 1e-3) / 1e12
+        f32_kernel = not (args.all_fp64 or args.prune)
+        peak = VALU_PEAK_F32_GUIDE if f32_kernel else VALU_PEAK_SLOW_CLASS
+        valu = {"kernel": pmc["kernel"], "achieved": valu_tlanes, "peak": peak, "unit": "T lane-instr/s",
+                "frac": valu_tlanes / peak,
+                "peak_definition": ("MI355X_MICROARCH.md: SIMD-32, one wave64 f32 VALU instruction per 2 cycles at 2.4 GHz (157.3 TFLOP/s of FMA)" if f32_kernel else
+                                    "measured: one fp64 VALU instruction per wave per 4.3 cycles (profiles/r03_valu_issue_cycles.txt)"),
+                "arithmetic": "f64" if not f32_kernel else "f32 (the candidate kernel; prologue, refinement and selection after it are fp64 and latency-bound)",
+                "valu_instr_per_candidate": per_cand, "source": pmc["source"]}
+        if f32_kernel:
+            # the same achieved rate against what the chip measurably issues, and against the issue-cycle floor of THIS kernel's own
+            # instruction mix (transcendentals at 8.3 cycles, everything else priced at the cheapest class: a lower bound of its time)
+            valu["frac_of_measured_f32_issue_peak"] = valu_tlanes / VALU_PEAK_F32_MEASURED
+            valu["measured_f32_issue_peak"] = VALU_PEAK_F32_MEASURED
+            # instruction classes of the kernel's own stream (gfx950's per-class counters; whatever they do not name -- min / max / compare /
+            # select / bit operations / DPP moves / readlane -- is "other")
+            cls = {k: pmc[n] / pmc["waves"] for k, n in (("add_f32", "SQ_INSTS_VALU_ADD_F32"), ("mul_f32", "SQ_INSTS_VALU_MUL_F32"), ("fma_f32", "SQ_INSTS_VALU_FMA_F32"),
+                                                          ("trans_f32", "SQ_INSTS_VALU_TRANS_F32"), ("cvt", "SQ_INSTS_VALU_CVT"), ("int32", "SQ_INSTS_VALU_INT32"),
+                                                          ("add_f64", "SQ_INSTS_VALU_ADD_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"), ("fma_f64", "SQ_INSTS_VALU_FMA_F64"),
+                                                          ("trans_f64", "SQ_INSTS_VALU_TRANS_F64"), ("int64", "SQ_INSTS_VALU_INT64")) if pmc.get(n) is not None}
+            if cls:
+                cls["other"] = per_cand - sum(cls.values())
+                valu["instr_classes_per_candidate"] = cls
+            if pmc.get("SQ_INSTS_VALU_TRANS_F32") is not None:
+                trans = pmc["SQ_INSTS_VALU_TRANS_F32"] / pmc["waves"]
+                floor_cyc = (per_cand - trans) * VALU_CYC["fast"] + trans * VALU_CYC["trans"]
+                floor_ms = floor_cyc * (E * C / 64.0) / 1024.0 / 2.4e9 * 1e3
+                valu["trans_instr_per_candidate"] = trans
+                valu["issue_floor_ms_of_this_mix"] = floor_ms
+                valu["frac_of_issue_floor"] = floor_ms / dom_ms
+            # both filter kernels together (the prologue runs one wave per EGO: its instructions are spread over the ego's candidates)
+            pro = [k for k in pmc.get("all_kernels", []) if "k_lattice_prologue" in k.get("kernel", "")]
+            if pro and pro[0].get("SQ_INSTS_VALU") and pro[0].get("waves"):
+                valu["valu_instr_per_candidate_incl_prologue"] = per_cand + pro[0]["SQ_INSTS_VALU"] / pmc["waves"]
+        if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' busy clocks
+            valu["busy_frac_profiled"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+    traffic = None
+    if same_cfg:
+        # one plan = every kernel of the schedule (the filter reads the scene, k_lattice_select writes best_traj): their PMC bytes are summed
+        names = ("k_lattice_prologue", "k_lattice_filter", "k_lattice_refine", "k_lattice_select") if mixed_ms else (pmc["kernel"],)
+        tb = 0.0
+        for k in pmc.get("all_kernels", []):
+            if any(nm in k.get("kernel", "") for nm in names) and k.get("FETCH_SIZE_KiB") is not None and k.get("WRITE_SIZE_KiB") is not None:
+                tb += (k["FETCH_SIZE_KiB"] * 2 + k["WRITE_SIZE_KiB"]) * 1024    # gfx950 wide-read correction x2 (MI355X_MICROARCH.md)
+        traffic = int(tb) if tb > 0 else None
+    return dom_ms, pmc, same_cfg, valu, traffic
+
+
+def leg_cpu_baseline_and_parity(args, out, poses, rl, cfg, img, res, origin, E, C, S, world, prev_in, bidx, steer, materialised):
+    """rank 0: the oracle (`kind: "port"`, OpenMP over egos on all host threads) on a bounded sample of the same workload -- the run's parity
+    gate and its CPU baseline -- and north_star's single-core numpy baseline"""
+    import numpy as np
+    from oracle import oracle   # the checker / CPU baseline leg only
+    nthr = oracle.max_threads()
+    grid = (img, res, origin[0], origin[1], 206)
+    n_cpu = args.cpu_egos
+    if world > 1:
+        n_cpu = min(E, 256)                       # N > 1: parity gate only; the CPU baseline is an N = 1 figure
+    if n_cpu <= 0:
+        t1 = time.perf_counter()
+        oracle.lattice_plan_batch(poses[:nthr], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:nthr], nthreads=nthr)
+        per_ego = (time.perf_counter() - t1) / nthr
+        n_cpu = int(min(E, max(nthr, (12.0 / max(per_ego, 1e-6)) // nthr * nthr)))
+    t1 = time.perf_counter()
+    want = oracle.lattice_plan_batch(poses[:n_cpu], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:n_cpu], nthreads=nthr)
+    cpu_s = time.perf_counter() - t1
+    mism = int((want["best_idx"] != bidx[:n_cpu]).sum())
+    dsteer = float(np.abs(want["steer"] - steer[:n_cpu]).max())
+    out["cpu_baseline"] = None if world > 1 else {
+        "value": n_cpu * C * S / cpu_s, "unit": "candidate-trajectory-steps/s", "cores": nthr, "kind": "port",
+        "sample": f"first {n_cpu} of the {E} egos x {C} candidates x {S} stations, oracle/f1p_oracle.c "
+                  f"(fp64 C, OpenMP over egos, {nthr} threads), {cpu_s:.1f} s",
+        "note": "the oracle follows the reference's per-station X(s)/Y(s) evaluation (utils.py:289-293): every station is integrated "
+                "from 0, O(S^2) per candidate -- a faithful restatement, not a tuned CPU implementation; the GPU/CPU ratio is no credit"}
+    out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": mism, "max_abs_dsteer": dsteer,
+                     "checked_outputs": "the plan of the closed-loop chain right after the timed region (its previous path handed to the oracle)",
+                     "similarity_term_live": prev_in is not None}
+    if world == 1 and args.generator == "clothoid" and not materialised and os.path.exists(os.path.join(ROOT, "oracle", "numpy_lattice.py")):
+        out["cpu_baseline_numpy"] = numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, prev_in=prev_in)
+
+
 def main_lattice(args):
     import numpy as np
     from f1tenth_planning_amd import _abi, synth
@@ -902,50 +1120,9 @@ def main_lattice(args):
     steady = not materialised
     ctx.lattice_set_closed_loop(steady)
 
-    # p50 / p95 latency of one plan() at the ctypes boundary: host poses in, host results out (H2D + kernel + D2H + sync).
-    # Runs on every rank BEFORE the timed region (it also brings the chip's clocks up, so a short --steps run is not measuring
-    # the ramp from idle).  Closed loop: the similarity term is live in every one of these calls, nothing extra crosses PCIe.
     lat = None
     if args.latency_iters > 0 and not materialised and not cand_sharded:
-        import copy
-
-        def percentiles(fn):
-            for _ in range(20):                                  # 20 warm-up + 200 timed calls
-                fn()
-            ts = []
-            for _ in range(args.latency_iters):
-                t1 = time.perf_counter()
-                fn()
-                ts.append((time.perf_counter() - t1) * 1e3)
-            return float(np.percentile(ts, 50)), float(np.percentile(ts, 95))
-        p50, p95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
-        q50, q95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True))
-        r50, r95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=False, reuse_outputs=True))
-        h50, h95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True, traj_dtype=np.float32))
-        c50, c95 = percentiles(lambda: ctx.lattice_step(poses, cfg))
-        cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
-        ctx.lattice_set_mode(0)
-        b50, b95 = percentiles(lambda: ctx.lattice_plan(poses, cfg_bb, want_traj=True, reuse_outputs=True))
-        f50, f95 = percentiles(lambda: ctx.lattice_plan(poses, cfg, want_traj=True, reuse_outputs=True))
-        ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
-        # BASELINE configs[1]: ONE ego x 512 candidates x 50 stations, the single-vehicle call
-        cfg1 = synth.bench_lattice_cfg(n_cand=512, n_stations=S)
-        ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)       # another batch shape: re-armed
-        s50, s95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True))
-        ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)
-        lat = {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
-               "includes": "H2D poses + kernels + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays; "
-                           "closed loop: the similarity term is live (previous headings stay on the device)",
-               "closed_loop": {"p50_ms": c50, "p95_ms": c95,
-                               "note": "f1p_lattice_step_batch: poses in, (steer, speed, status) out as ONE packed block the selection kernel writes straight "
-                                       "into page-locked host memory; previous headings and best_traj stay on the device (f1p_lattice_fetch_traj on request)"},
-               "pageable_host_arrays": {"p50_ms": q50, "p95_ms": q95},
-               "without_best_traj": {"p50_ms": r50, "p95_ms": r95},
-               "f32_best_traj": {"p50_ms": h50, "p95_ms": h95,
-                                 "note": "f1p_lattice_plan_batch_f32: the same fp64 plan, best_traj rounded once to f32 on the device (3.3 MB instead of 6.6 MB down)"},
-               "all_fp64": {"p50_ms": f50, "p95_ms": f95},
-               "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"},
-               "config1_single_ego": {"p50_ms": s50, "p95_ms": s95, "workload": f"1 ego x 512 candidates x {S} stations (BASELINE configs[1]), Context.lattice_plan"}}
+        lat = leg_host_boundary_latency(ctx, args, poses, cfg, S, steady)
 
     cs = None
     if cand_sharded:
@@ -981,77 +1158,14 @@ def main_lattice(args):
         first_plan = {"ms_per_step": e1 / args.steps * 1e3, "kernel_ms": k1 / args.steps, "value": float(E) * C * S * args.steps * world / e1,
                       "note": "closed loop off, prev_theta = NULL: w_similarity multiplies 0 (rounds 1-3 timed this)"}
 
-    # The same plan by the other schedules, every one checked bit for bit against the chain's plan above (same previous path):
-    #   all_fp64          the plain kernel (one fp64 thread per candidate; round 1's headline kernel)
-    #   branch_and_bound  all fp64 with cfg.prune = 1 (station loops skipped while a cost lower bound exceeds the best so far)
-    #   every_station     the default schedule with f1p_lattice_set_clearance(0): every station looked up in the bitmap, single intervals
     bnb = fp64 = every_station = None
     if rank == 0 and not materialised and args.generator == "clothoid" and not cand_sharded and not args.only_timed:
-        import copy
-        alt = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
+        fp64, bnb, every_station = leg_other_schedules(ctx, args, cfg, d_poses, d_prev_in, E, C, S, (bidx, ref_cost, steer, ref_traj))
 
-        def other(cfg_x, mode):
-            ctx.lattice_set_mode(mode)
-            for _ in range(args.warmup):
-                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
-            ctx.sync()
-            ctx.timer_begin()
-            for _ in range(args.steps):
-                ctx.lattice_plan_dev(d_poses, E, cfg_x, *alt, d_prev_theta=d_prev_in)
-            ms = ctx.timer_end() / args.steps
-            same = bool((alt[2].download(np.int32, (E,)) == bidx).all() and
-                        np.array_equal(alt[3].download(np.float64, (E,)), ref_cost, equal_nan=True) and
-                        np.array_equal(alt[0].download(np.float64, (E,)), steer) and
-                        np.array_equal(alt[6].download(np.float64, (E, S, 4)), ref_traj))
-            return {"kernel_ms": ms, "candidate_steps_per_s_equivalent": float(E) * C * S / (ms * 1e-3), "outputs_bit_identical_to_the_timed_plan": same}
-        cfg_ex = copy.copy(cfg); cfg_ex.prune = 0
-        cfg_bb = copy.copy(cfg); cfg_bb.prune = 1
-        fp64 = other(cfg_ex, 0)
-        fp64["note"] = "f1p_lattice_set_mode(0): every candidate-step in fp64, one thread per candidate (k_lattice)"
-        bnb = other(cfg_bb, 0)
-        bnb["note"] = "all fp64 + cfg.prune = 1: candidates sorted by a lower bound of their cost after the fit; a station loop runs only while the bound does not exceed the best cost found"
-        if not (args.all_fp64 or args.prune):
-            ctx.lattice_set_clearance(0)
-            every_station = other(cfg_ex, 1)
-            every_station["note"] = ("the default schedule with f1p_lattice_set_clearance(0): the f32 filter integrates every station interval as a piece "
-                                     "of its own and looks every station up in the bitmap (49 pieces, 50 look-ups per candidate)")
-            ctx.lattice_set_clearance(2)
-        ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
-        for b in alt:
-            b.free()
-
-    # per-kernel durations of the default schedule (HIP events between its kernels, outside the timed region), same previous path
-    mixed_ms = None
+    mixed_ms = pass_stat = audit = None
     if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded or args.only_timed) and args.generator == "clothoid" and E >= 512:
-        ctx.lattice_profile(True)
-        acc = np.zeros(4)
-        for _ in range(max(10, min(args.steps, 50))):
-            step(d_prev_in)
-            acc += np.array(ctx.lattice_profile(True, read=True))
-        ctx.lattice_profile(False)
-        acc /= max(10, min(args.steps, 50))
-        mixed_ms = {"k_lattice_prologue": float(acc[0]), "k_lattice_filter3": float(acc[1]), "k_lattice_refine": float(acc[2]), "k_lattice_select": float(acc[3])}
-        # entries per ego the filter of that last plan handed to the fp64 refinement = the candidates whose collision state mattered (minus
-        # certain hits, which are dropped): what the lazy station pass looked at
-        try:
-            nq = ctx.lattice_debug_queue(E)
-            pass_stat = {"mean": float(nq.mean()), "p99": float(np.percentile(nq, 99)), "max": int(nq.max()), "of": C}
-        except Exception as exc:   # noqa: BLE001 -- a statistic, not a gate
-            pass_stat = {"error": str(exc)}
-
-    # runtime audit of the mixed schedule (f1p_lattice_set_audit): the timed plan again, every plan followed by the all-fp64 exhaustive
-    # kernel on a moving window of 256 egos and a bit-for-bit comparison of every output; outside the timed region
-    audit = None
-    if rank == 0 and not (args.all_fp64 or args.prune or materialised or cand_sharded or args.only_timed) and args.generator == "clothoid" and E >= 512:
-        ctx.lattice_audit_read(reset=True)
-        ctx.lattice_set_audit(1, min(256, E))
-        n_aud = max(20, min(args.steps, 64))
-        for _ in range(n_aud):
-            step(d_prev_in)
-        audit = ctx.lattice_audit_read(reset=True)
-        ctx.lattice_set_audit(0)
-        audit["note"] = ("every audited plan (similarity term live): all-fp64 exhaustive kernel (cfg.prune = 0) on a moving 256-ego window, all seven outputs "
-                         "compared bit for bit; mismatching_egos must be 0")
+        mixed_ms, pass_stat = leg_kernel_profile(ctx, step, d_prev_in, max(10, min(args.steps, 50)), E, C)
+        audit = leg_audit(ctx, step, d_prev_in, max(20, min(args.steps, 64)), E)
 
     # the headline workload on scenes it was NOT tuned on: wall-hugging egos, obstacles on the raceline, a moving fleet
     scene_sweep = None
@@ -1085,59 +1199,7 @@ def main_lattice(args):
         abytes = algorithmic_bytes_lattice(E, C, S, rl.shape[0], img.shape[1], img.shape[0])
         if materialised:
             abytes += E * C * S * 32 + E * C * 8      # every candidate's rows (x, y, theta, |kappa|) + its cost, written once
-        dom_ms = mixed_ms["k_lattice_filter3"] if mixed_ms else kernel_ms         # the dominant kernel's own average duration
-        pmc = load_pmc({"egos": E, "cands": C, "stations": S, "workload": args.workload, "generator": args.generator,
-                        "schedule": "all_fp64" if args.all_fp64 else ("bnb" if args.prune else "mixed")})
-        same_cfg = bool(pmc and not cand_sharded)
-        valu = None
-        if same_cfg and pmc.get("SQ_INSTS_VALU") and pmc.get("waves"):
-            per_cand = pmc["SQ_INSTS_VALU"] / pmc["waves"]            # wave-instructions per wave = lane-instructions per candidate (one lane per candidate)
-            valu_tlanes = per_cand * E * C / (dom_ms * 1e-3) / 1e12
-            f32_kernel = not (args.all_fp64 or args.prune)
-            peak = VALU_PEAK_F32_GUIDE if f32_kernel else VALU_PEAK_SLOW_CLASS
-            valu = {"kernel": pmc["kernel"], "achieved": valu_tlanes, "peak": peak, "unit": "T lane-instr/s",
-                    "frac": valu_tlanes / peak,
-                    "peak_definition": ("MI355X_MICROARCH.md: SIMD-32, one wave64 f32 VALU instruction per 2 cycles at 2.4 GHz (157.3 TFLOP/s of FMA)" if f32_kernel else
-                                        "measured: one fp64 VALU instruction per wave per 4.3 cycles (profiles/r03_valu_issue_cycles.txt)"),
-                    "arithmetic": "f64" if not f32_kernel else "f32 (the candidate kernel; prologue, refinement and selection after it are fp64 and latency-bound)",
-                    "valu_instr_per_candidate": per_cand, "source": pmc["source"]}
-            if f32_kernel:
-                # the same achieved rate against what the chip measurably issues, and against the issue-cycle floor of THIS kernel's own
-                # instruction mix (transcendentals at 8.3 cycles, everything else priced at the cheapest class: a lower bound of its time)
-                valu["frac_of_measured_f32_issue_peak"] = valu_tlanes / VALU_PEAK_F32_MEASURED
-                valu["measured_f32_issue_peak"] = VALU_PEAK_F32_MEASURED
-                # instruction classes of the kernel's own stream (gfx950's per-class counters; whatever they do not name -- min / max / compare /
-                # select / bit operations / DPP moves / readlane -- is "other")
-                cls = {k: pmc[n] / pmc["waves"] for k, n in (("add_f32", "SQ_INSTS_VALU_ADD_F32"), ("mul_f32", "SQ_INSTS_VALU_MUL_F32"), ("fma_f32", "SQ_INSTS_VALU_FMA_F32"),
-                                                              ("trans_f32", "SQ_INSTS_VALU_TRANS_F32"), ("cvt", "SQ_INSTS_VALU_CVT"), ("int32", "SQ_INSTS_VALU_INT32"),
-                                                              ("add_f64", "SQ_INSTS_VALU_ADD_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"), ("fma_f64", "SQ_INSTS_VALU_FMA_F64"),
-                                                              ("trans_f64", "SQ_INSTS_VALU_TRANS_F64"), ("int64", "SQ_INSTS_VALU_INT64")) if pmc.get(n) is not None}
-                if cls:
-                    cls["other"] = per_cand - sum(cls.values())
-                    valu["instr_classes_per_candidate"] = cls
-                if pmc.get("SQ_INSTS_VALU_TRANS_F32") is not None:
-                    trans = pmc["SQ_INSTS_VALU_TRANS_F32"] / pmc["waves"]
-                    floor_cyc = (per_cand - trans) * VALU_CYC["fast"] + trans * VALU_CYC["trans"]
-                    floor_ms = floor_cyc * (E * C / 64.0) / 1024.0 / 2.4e9 * 1e3
-                    valu["trans_instr_per_candidate"] = trans
-                    valu["issue_floor_ms_of_this_mix"] = floor_ms
-                    valu["frac_of_issue_floor"] = floor_ms / dom_ms
-                # both filter kernels together (the prologue runs one wave per EGO: its instructions are spread over the ego's candidates)
-                pro = [k for k in pmc.get("all_kernels", []) if "k_lattice_prologue" in k.get("kernel", "")]
-                if pro and pro[0].get("SQ_INSTS_VALU") and pro[0].get("waves"):
-                    valu["valu_instr_per_candidate_incl_prologue"] = per_cand + pro[0]["SQ_INSTS_VALU"] / pmc["waves"]
-            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
-                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' busy clocks
-                valu["busy_frac_profiled"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pmc["GRBM_GUI_ACTIVE"] / 8.0)
-        traffic = None
-        if same_cfg:
-            # one plan = every kernel of the schedule (the filter reads the scene, k_lattice_select writes best_traj): their PMC bytes are summed
-            names = ("k_lattice_prologue", "k_lattice_filter", "k_lattice_refine", "k_lattice_select") if mixed_ms else (pmc["kernel"],)
-            tb = 0.0
-            for k in pmc.get("all_kernels", []):
-                if any(nm in k.get("kernel", "") for nm in names) and k.get("FETCH_SIZE_KiB") is not None and k.get("WRITE_SIZE_KiB") is not None:
-                    tb += (k["FETCH_SIZE_KiB"] * 2 + k["WRITE_SIZE_KiB"]) * 1024    # gfx950 wide-read correction x2 (MI355X_MICROARCH.md)
-            traffic = int(tb) if tb > 0 else None
+        dom_ms, pmc, same_cfg, valu, traffic = lattice_valu_and_traffic(args, E, C, S, mixed_ms, kernel_ms, cand_sharded)
         achieved_gbs = abytes / (kernel_ms * 1e-3) / 1e9              # the plan's algorithmic bytes over the plan's kernel time
         pcie_value = (float(E) * C * S / (lat["p50_ms"] * 1e-3)) if lat else None
         default_sched = not (args.all_fp64 or args.prune or materialised or args.generator != "clothoid")
@@ -1277,33 +1339,7 @@ def main_lattice(args):
             for nm, v in scene_sweep.items():
                 out["scene_" + nm + "_ms_per_plan"] = v["ms_per_plan"]
         if not args.no_cpu_baseline and not cand_sharded:
-            from oracle import oracle   # the checker / CPU baseline leg only
-            nthr = oracle.max_threads()
-            grid = (img, res, origin[0], origin[1], 206)
-            n_cpu = args.cpu_egos
-            if world > 1:
-                n_cpu = min(E, 256)                       # N > 1: parity gate only; the CPU baseline is an N = 1 figure
-            if n_cpu <= 0:
-                t1 = time.perf_counter()
-                oracle.lattice_plan_batch(poses[:nthr], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:nthr], nthreads=nthr)
-                per_ego = (time.perf_counter() - t1) / nthr
-                n_cpu = int(min(E, max(nthr, (12.0 / max(per_ego, 1e-6)) // nthr * nthr)))
-            t1 = time.perf_counter()
-            want = oracle.lattice_plan_batch(poses[:n_cpu], rl, cfg, grid=grid, prev_theta=None if prev_in is None else prev_in[:n_cpu], nthreads=nthr)
-            cpu_s = time.perf_counter() - t1
-            mism = int((want["best_idx"] != bidx[:n_cpu]).sum())
-            dsteer = float(np.abs(want["steer"] - steer[:n_cpu]).max())
-            out["cpu_baseline"] = None if world > 1 else {
-                "value": n_cpu * C * S / cpu_s, "unit": "candidate-trajectory-steps/s", "cores": nthr, "kind": "port",
-                "sample": f"first {n_cpu} of the {E} egos x {C} candidates x {S} stations, oracle/f1p_oracle.c "
-                          f"(fp64 C, OpenMP over egos, {nthr} threads), {cpu_s:.1f} s",
-                "note": "the oracle follows the reference's per-station X(s)/Y(s) evaluation (utils.py:289-293): every station is integrated "
-                        "from 0, O(S^2) per candidate -- a faithful restatement, not a tuned CPU implementation; the GPU/CPU ratio is no credit"}
-            out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": mism, "max_abs_dsteer": dsteer,
-                             "checked_outputs": "the plan of the closed-loop chain right after the timed region (its previous path handed to the oracle)",
-                             "similarity_term_live": prev_in is not None}
-            if world == 1 and args.generator == "clothoid" and not materialised and os.path.exists(os.path.join(ROOT, "oracle", "numpy_lattice.py")):
-                out["cpu_baseline_numpy"] = numpy_baseline(poses, rl, cfg, grid, C, S, bidx, steer, prev_in=prev_in)
+            leg_cpu_baseline_and_parity(args, out, poses, rl, cfg, img, res, origin, E, C, S, world, prev_in, bidx, steer, materialised)
         if rk.rccl_note:
             out["rccl_init"] = rk.rccl_note
         print(json.dumps(out), flush=True)

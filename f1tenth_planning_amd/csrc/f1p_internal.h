@@ -60,6 +60,9 @@ struct f1p_ctx {
     bool st_q_dirty = true;
 
     // in-kernel control generation of the shooting MPC (f1p_kmpc_plan_*): the warm start lives here, on the device
+    f1p_kmpc_cfg* d_kmpc_cfg = nullptr; // device copy of the last shooting configuration (the kernels' fp64 tails read it with scalar loads)
+    f1p_kmpc_cfg h_kmpc_cfg;            // ... and its host shadow (compared per launch, source of the copy)
+    bool kmpc_cfg_valid = false;
     float* d_kmpc_warm = nullptr;      // [E][T][2] f32: previous plan's applied winner shifted by one step
     int kmpc_warm_E = 0, kmpc_warm_T = 0;
     bool kmpc_warm_valid = false;

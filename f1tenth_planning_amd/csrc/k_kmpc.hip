@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
                                                           double* __restrict__ steer, double* __restrict__ speed,
                                                           int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
                                                           double* __restrict__ best_seq, float* __restrict__ cost32_out,
-                                                          int32_t* __restrict__ n_refined) {
+                                                          int32_t* __restrict__ n_refined, const f1p_kmpc_cfg* __restrict__ dcfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* sref32 = reinterpret_cast<float*>(lds_raw);                // [4][T+1] relative to the ego state, f32
@@ -786,9 +786,12 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_FILTER) void k_kmpc_shoot_mixed(c
         const int n = *cnt;
         n_eff = (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) ? -1 : n;   // pathological inputs, degenerate ties: all rollouts in fp64
     }
-    // (round 5, measured and not kept: the tail's configuration from an LDS copy -- SGPR spills 236 -> 180 but its values then occupy VGPRs:
-    // 39 VGPR spills; through a laundered pointer to the by-value argument -- the address-of forces a scratch copy: 137 VGPR spills)
-    const f1p_kmpc_cfg& s_cfg = cfg;
+    // round 5: the fp64 tail reads the configuration from a DEVICE copy (f1p_ctx::d_kmpc_cfg, refreshed by the launcher when the caller's
+    // struct changes) -- uniform, read-only: scalar loads where a field is used.  As a by-value argument its ~30 doubles were loaded at
+    // the kernel's entry and sat in scalar registers across the filter, spilled into VGPR lanes around it.  (Measured and not kept: an
+    // LDS copy -- its values then occupy VGPRs, 39 VGPR spills; a laundered pointer to the by-value argument -- the address-of forces a
+    // scratch copy, 137 VGPR spills.)
+    const f1p_kmpc_cfg& s_cfg = *dcfg;
     if (n_eff == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
         kmpc_emit_wave(ce, s_cfg, sv, s_cfg.max_dsteer * s_cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, nullptr);
@@ -826,7 +829,8 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
                                                        f1p_kmpc_cfg cfg, KmpcF32 kf, KmpcGenArgs ga,
                                                        double* __restrict__ steer, double* __restrict__ speed,
                                                        int32_t* __restrict__ best_idx, double* __restrict__ best_cost,
-                                                       double* __restrict__ best_seq, int32_t* __restrict__ n_refined) {
+                                                       double* __restrict__ best_seq, int32_t* __restrict__ n_refined,
+                                                       const f1p_kmpc_cfg* __restrict__ dcfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int T = cfg.horizon, R = cfg.n_rollouts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     float* sref32 = reinterpret_cast<float*>(lds_raw);                // [4][T+1] relative to the ego state, f32
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(256, F1P_K4_WAVES_GEN) void k_kmpc_plan_gen(const d
         n_eff = (n > F1P_K4_MAX_REFINE || n < 1 || !isfinite(fmin_)) ? -1 : n;   // pathological inputs, degenerate ties: all rollouts in fp64
     }
     F1P_KPH();
-    const f1p_kmpc_cfg& s_cfg = cfg;
+    const f1p_kmpc_cfg& s_cfg = *dcfg;                               // (the device copy: see k_kmpc_shoot_mixed)
     if (n_eff == 1 && !best_cost) {
         // a single survivor needs no fp64 cost unless it is asked for
         kmpc_emit_wave(src, s_cfg, sv, s_cfg.max_dsteer * s_cfg.dt, e, list[0], 0.0, steer, speed, best_idx, nullptr, best_seq, warm_out);
@@ -1123,6 +1127,21 @@ __global__ void k_argmin_reduce(const uint64_t* __restrict__ recs, int N, int E,
 
 static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg);
 
+// the device copy of the configuration the shooting kernels' fp64 tails read (stream-ordered: a changed struct is copied behind the launches
+// that still read the old one)
+static int ensure_kmpc_cfg(f1p_ctx* ctx, const f1p_kmpc_cfg* cfg) {
+    if (!ctx->d_kmpc_cfg) {
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_cfg, sizeof(f1p_kmpc_cfg)));
+        ctx->kmpc_cfg_valid = false;
+    }
+    if (!ctx->kmpc_cfg_valid || __builtin_memcmp(&ctx->h_kmpc_cfg, cfg, sizeof(f1p_kmpc_cfg)) != 0) {
+        ctx->h_kmpc_cfg = *cfg;                                   // (the copy's source must outlive the call: the context's own shadow)
+        F1P_HIP(ctx, hipMemcpyAsync(ctx->d_kmpc_cfg, &ctx->h_kmpc_cfg, sizeof(f1p_kmpc_cfg), hipMemcpyHostToDevice, ctx->stream));
+        ctx->kmpc_cfg_valid = true;
+    }
+    return F1P_OK;
+}
+
 int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, const float* d_controls, int E,
                       const f1p_kmpc_cfg* cfg, double* d_steer, double* d_speed, int32_t* d_best_idx,
                       double* d_best_cost, double* d_best_seq) {
@@ -1132,8 +1151,9 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
         const KmpcF32 kf = make_kf(cfg);
         const size_t lds = sizeof(float) * (4 * T1 + (size_t)cfg->n_rollouts + 4) + sizeof(int) * (F1P_K4_MAX_REFINE + 1) + 8 +
                            sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
+        if (const int rc = ensure_kmpc_cfg(ctx, cfg)) return rc;
         hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, kf,
-                           d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref);
+                           d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref, ctx->d_kmpc_cfg);
         return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot_mixed launch");
     }
     const size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
@@ -1222,8 +1242,9 @@ int launch_kmpc_plan_gen(f1p_ctx* ctx, const double* d_x0, const double* d_ref, 
     if (ga.G == 1) lds += sizeof(float) * R;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > (size_t)ctx->prop.sharedMemPerBlock) return set_error(ctx, F1P_EINVAL, "horizon / n_rollouts need more LDS than a workgroup has: use fewer rollouts per plan");
+    if (const int rc = ensure_kmpc_cfg(ctx, cfg)) return rc;
     hipLaunchKernelGGL(k_kmpc_plan_gen, dim3((unsigned)((size_t)E * ga.G)), dim3(block), lds, ctx->stream, d_x0, d_ref, E, *cfg, make_kf(cfg), ga,
-                       d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_nref);
+                       d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_nref, ctx->d_kmpc_cfg);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_plan_gen launch");
 }
 
