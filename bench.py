@@ -698,6 +698,7 @@ def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
       host_goals     the caller's goal set [E][C][3] instead of the device sampler -- what the reference's add_sample_function plug-in returns
                      (lattice_planner.py:57-70, 113-128); BASELINE.md section 4 row 2 (0.3816 B per candidate-step)
       cubic          cfg.generator = cubic Hermite spline candidates (north_star "clothoid / cubic-spline"), mixed schedule since round 5
+      footprint      f1p_set_footprint: the vehicle rectangle covered by three discs along the heading, every station tested at their centres
       materialised   all_traj [E][C][S][4] + all_cost written to HBM, the reference's own data flow (lattice_planner.py:194-201);
                      BASELINE.md section 4 row 3 (32.38 B per candidate-step, HBM-bound) on a bounded ego count
     Each: ms per plan (HIP events on the ctx stream), steady state of a closed loop where the schedule supports it, bit-identity with the
@@ -790,6 +791,45 @@ def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
                         "note": "cubic Hermite spline candidates, steady state of a closed loop (similarity term live); round 5: the mixed schedule -- "
                                 "k_lattice_prologue -> k_lattice_filter3<cubic> (an f32 walk over the stations with an a-priori error bound, table-driven "
                                 "station passes) -> k_lattice_refine_cubic -> k_lattice_select<cubic>"}
+    # ---- oriented footprint ----------------------------------------------------------------------------------------------------------------
+    n_d, flen, fwid, foff = 3, 0.58, 0.31, 0.145             # the reference's vehicle (kinematic_mpc.py:60-61) covered by three discs, pose near the rear axle
+    f_offsets = [foff - 0.5 * flen + (k + 0.5) * flen / n_d for k in range(n_d)]
+    f_radius = float(np.hypot(0.5 * flen / n_d, 0.5 * fwid))
+    with Context(rk.local_rank) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, res, origin, 206)
+        ctx.set_footprint(f_offsets, f_radius)
+        ctx.lattice_set_closed_loop(True)
+        d_p, b = ctx.to_device(poses), bufs(ctx, E)
+        ms = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg, *b))
+        prev = ctx.lattice_closed_loop_prev(); d_prev = ctx.to_device(prev)
+        ctx.lattice_set_closed_loop(False)
+        ctx.lattice_plan_dev(d_p, E, cfg, *b, d_prev_theta=d_prev); got = fetch(b, E)
+        ctx.lattice_profile(True); acc = np.zeros(4)
+        for _ in range(10):
+            ctx.lattice_plan_dev(d_p, E, cfg, *b, d_prev_theta=d_prev); acc += np.array(ctx.lattice_profile(True, read=True))
+        ctx.lattice_profile(False)
+        nq = ctx.lattice_debug_queue(E)
+        ctx.lattice_set_mode(0)
+        b2 = bufs(ctx, E)
+        ms64 = timed(ctx, lambda: ctx.lattice_plan_dev(d_p, E, cfg, *b2, d_prev_theta=d_prev)); ref = fetch(b2, E)
+        n_or = min(256, E)
+        dil = oracle.inflate_image(img, res, 206, f_radius, nthreads=nthr)
+        oracle.set_footprint(f_offsets)
+        try:
+            want = oracle.lattice_plan_batch(poses[:n_or], rl, cfg, grid=(dil, res, origin[0], origin[1], 206), prev_theta=prev[:n_or], nthreads=nthr)
+        finally:
+            oracle.set_footprint(())
+        out["footprint"] = {"ms_per_plan": ms, "nominal_candidate_steps_per_s": float(E) * C * S / (ms * 1e-3), "all_fp64_ms_per_plan": ms64,
+                            "discs": {"offsets_m": f_offsets, "radius_m": f_radius},
+                            "kernels_ms": dict(zip(("k_lattice_prologue", "k_lattice_filter3", "k_lattice_refine", "k_lattice_select"), (float(v) / 10 for v in acc))),
+                            "refinement_queue_entries_per_ego": float(nq.mean()),
+                            "outputs_bit_identical_to_all_fp64": bool(all(np.array_equal(got[k], ref[k], equal_nan=(got[k].dtype != np.int32)) for k in names)),
+                            "oracle": {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != got["best_idx"][:n_or]).sum()),
+                                       "max_abs_dsteer": float(np.abs(want["steer"] - got["steer"][:n_or]).max())},
+                            "note": "f1p_set_footprint: every station tested at three disc centres along its heading against the disc-dilated bitmap (the "
+                                    "reference's collision check is a stub: utils/utils.py:297-301; build-defined glue), steady state of a closed loop; since "
+                                    "round 5 on k_lattice_prologue -> k_lattice_filter3<FOOT> -> k_lattice_refine<FOOT> -> k_lattice_select (was: the one-kernel "
+                                    "fallback filter)"}
     # ---- all_traj materialised (HBM-bound) ----------------------------------------------------------------------------------------------
     Em = min(E, 1024)
     with Context(rk.local_rank) as ctx:
@@ -1330,6 +1370,8 @@ def main_lattice(args):
                         "host_goals_oracle_mismatches": _g(variants, "host_goals", "oracle", "best_idx_mismatches"),
                         "cubic_ms_per_plan": _g(variants, "cubic", "ms_per_plan"), "cubic_all_fp64_ms_per_plan": _g(variants, "cubic", "all_fp64_ms_per_plan"),
                         "cubic_bit_identical": _g(variants, "cubic", "outputs_bit_identical_to_all_fp64"), "cubic_oracle_mismatches": _g(variants, "cubic", "oracle", "best_idx_mismatches"),
+                        "footprint_ms_per_plan": _g(variants, "footprint", "ms_per_plan"), "footprint_all_fp64_ms_per_plan": _g(variants, "footprint", "all_fp64_ms_per_plan"),
+                        "footprint_bit_identical": _g(variants, "footprint", "outputs_bit_identical_to_all_fp64"), "footprint_oracle_mismatches": _g(variants, "footprint", "oracle", "best_idx_mismatches"),
                         "materialised_ms_per_plan": _g(variants, "materialised", "ms_per_plan"), "materialised_hbm_frac": _g(variants, "materialised", "roofline", "frac")})
         if scene_sweep:
             out.update({"scene_sweep_worst_vs_centred": max(v["vs_centred"] for v in scene_sweep.values()),

@@ -172,6 +172,7 @@ struct MixArgs {
     float clear_ds_cap;           // ... for candidates whose station spacing is <= this [m]
     int n_disc;                   // oriented footprint under the mixed schedule (clearance mode only): discs along the heading, 0 = station point
     double disc_off[4];           // their longitudinal offsets [m] (f1p_set_footprint)
+    float disc_off_f[4], disc_omax_f;   // ... rounded for the candidate kernel, and max |offset|
     double sim_s2, sim_s3, sim_s4; // sum_{j < sim_m} j^2, j^3, j^4 (exact integers; host): the candidate side of the closed-form similarity term
     float margin_rel, margin_abs; // |cost64 - cost32| <= margin_rel * (sum of |terms|) + margin_abs
     float edge0, edge1;           // a station is "near a cell boundary" within edge0 + edge1 * L cells
@@ -1030,6 +1031,11 @@ struct EgoParamsF2 {
 // refinement queue are the ones the every-candidate loop produced, so the queue -- and every output -- is unchanged.
 struct Brk32 { float cost, lo, hi, ebound; int state; bool never_free; };
 
+// oriented footprint (f1p_set_footprint) in the candidate kernel: nd discs along the heading at longitudinal offsets o[d] [m], omax = max |o|
+// (wave-uniform: kernel arguments).  nd = 0: the station point itself
+struct FootF { int nd; float o[4]; float omax; __device__ FootF() : nd(0), o{0.f, 0.f, 0.f, 0.f}, omax(0.f) {} };
+
+
 // The band around a cell edge inside which a look-up of THIS candidate decides nothing: farther than the f32 POSITION error -- the
 // calibrated band (edge0 + edge1 L: 5-10x the measured end-point error, tools/mixed_endpoint_error.py) or, when larger, the candidate's
 // a-priori bound (LABNOTES.md 5c):
@@ -1042,7 +1048,7 @@ struct Brk32 { float cost, lo, hi, ebound; int state; bool never_free; };
 // Only the candidates that take the station pass need it (round 4: it used to be formed for all 256).
 template <int R>
 __device__ __forceinline__ float edge_f2(float k0, float dk, float L, float ek0, float edk, float eLrel, const F1P_LDS(EgoParamsF2)* ep, bool exact_all,
-                                         float* e_pos_out = nullptr) {
+                                         float* e_pos_out = nullptr, float omax = 0.0f) {
     constexpr int G = 2 * R + 1;
     const bool macro = F1P_MIX_MACRO && !exact_all && G > 1;
     const float gm = macro ? (float)G : 1.0f;
@@ -1058,15 +1064,17 @@ __device__ __forceinline__ float edge_f2(float k0, float dk, float L, float ek0,
     // neglected terms are 2 z^3/5040 and b^2 z/14 in P, b z^2/84 and 2 b^3/42 in Q -- per unit of arc length (a piece is 2 hp long):
     const float abp = fabsf(bp);
     const float r_series = zm * zm * zm * (1.0f / 5040.0f) + bp * bp * zm * (1.0f / 28.0f) + abp * zm * zm * (1.0f / 168.0f) + abp * bp * bp * (1.0f / 42.0f);
-    const float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
+    // (oriented footprint: a disc centre sits omax from the station along the f32 heading -- its error e_th, the heading polynomial's and v_sin / v_cos's)
+    float e_pos = L * (e_th + (2.1f + 4.0f * TH + ep->fS) * U + r_series);
+    if (omax > 0.0f) e_pos += omax * (e_th + (4.1f + 4.0f * TH) * U);
     if (e_pos_out) *e_pos_out = e_pos;
     float edge = fmaxf(__builtin_fmaf(ep->edge1, L, ep->edge0), 1.25f * e_pos * ep->cells_per_m + ep->edge0);
     if (!(edge == edge)) edge = 2.0f;                                      // NaN: nothing is "away from an edge"
     return edge;
 }
 
-template <int R>
-__device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, double sim_s2, double sim_s3, double sim_s4) {
+template <int R, bool FOOT = false>
+__device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, double sim_s2, double sim_s3, double sim_s4, float omax = 0.0f) {
     Brk32 o;
     const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
     const float k0 = f.k0, dk = f.dk, L = f.L;
@@ -1085,7 +1093,9 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     const float gm = macro ? (float)G : 1.0f;                                // intervals per integrated piece
     const float hp = gm * h, bp = (gm * gm) * b;                             // the piece's half-length and quadratic phase coefficient
     const bool untrusted = !(kmax * hp <= 0.4f) || !(fabsf(bp) <= 0.05f);    // outside the one-piece series' range the positions decide nothing
-    bool unsure = untrusted || !(ds <= ep->clear_ds_cap);                    // ... nor beyond the spacing the clearance map was built for (NaN: unsure)
+    // ... nor beyond the spacing the clearance map was built for (NaN: unsure).  Oriented footprint: between stations a disc centre moves by at
+    // most ds (1 + |o| kappa_max) -- the station's own step plus the rotation of its offset
+    bool unsure = untrusted || !((FOOT ? ds * __builtin_fmaf(omax, kmax, 1.0f) : ds) <= ep->clear_ds_cap);
     // (the cell-edge band of the look-ups -- and with it the a-priori POSITION bound -- is formed by edge_f2 for the candidates that take the
     // station pass: nothing in the bracket needs it)
 #ifdef F1P_MIX_DEBUG_END
@@ -1189,9 +1199,10 @@ __device__ __forceinline__ bool near_edge_neighbours_agree(const F1P_LDS(unsigne
 // LDS tile.  Runs for the few candidates per ego that k_lattice_filter3's rounds select.  (Look-ups straight from global memory -- no
 // tile -- were measured: ~1 000 cycles per dependent look-up, 14.7 k cycles per pass, and 50 of them for an ego that tests every
 // station: the kernel's tail grew to 54 us.)
-template <int R>
+template <int R, bool FOOT = false>
 __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
-                                               const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, float& xe, float& ye, bool exact_all) {
+                                               const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, float& xe, float& ye, bool exact_all,
+                                               const FootF& ft = FootF()) {
     const int S = __builtin_amdgcn_readfirstlane(ep->S);
     const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
     // exact_all (wave-uniform): every station against the real bitmap, single intervals -- an ego that stands in a cell that is not clear
@@ -1234,9 +1245,9 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
     //   normal mode:  bit 0 (undecided) = not clear;  bit 1 (certain hit) = not clear & occupied & away from every cell edge
     //   exact_all:    every station is tested against the bitmap: bit 0 = near a cell edge or off the tile, bit 1 = occupied & not near
     const float edge_hi = 1.0f - edge;
-    auto test = [&]() {                                                      // the station at (x, y)
-        const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0));
-        const float lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
+    auto test_point = [&](float qx, float qy) {                              // one point of the station
+        const float lxf = __builtin_fmaf(txx, qx, __builtin_fmaf(txy, qy, tx0));
+        const float lyf = __builtin_fmaf(tyx, qx, __builtin_fmaf(tyy, qy, ty0));
         const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
         // clamped onto the guard column (index tile_w) / guard row (index tile_h)
         const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
@@ -1255,6 +1266,18 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
         }
         flags |= fl;
     };
+    // the station at (x, y), station index us (interval units).  Oriented footprint: its disc centres (x, y) + o_d (cos theta, sin theta),
+    // heading [rev] = us (alpha + beta us)
+    auto test = [&](float us) {
+        if constexpr (!FOOT) { (void)us; test_point(x, y); }
+        else {
+            const float ths = us * __builtin_fmaf(beta, us, alpha);
+            const float sns = __builtin_amdgcn_sinf(ths), css = __builtin_amdgcn_cosf(ths);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < ft.nd) test_point(__builtin_fmaf(ft.o[d], css, x), __builtin_fmaf(ft.o[d], sns, y));
+        }
+    };
     int base = 0;
     float ub = 0.5f;                                                         // u of interval `base`
     if (!macro) {
@@ -1262,7 +1285,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
         for (; base + G < S; base += G, ub += (float)G) {                    // whole groups with a station after them
 #pragma unroll
             for (int j = 0; j < G; ++j) {
-                if (exact_all || j == R) test();
+                if (exact_all || j == R) test(ub + ((float)j - 0.5f));
                 step(ub + (float)j);
             }
             // round 5: an ego inside a wall (every candidate occupied at station 0) or behind one ran all S stations of this chain on every
@@ -1273,7 +1296,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
         if (!all_hit) {                                                      // tail of <= G stations: one test covers it
             const int t = base + R < S - 1 ? base + R : S - 1;
             for (int i = base; i < S; ++i, ub += 1.0f) {
-                if (exact_all || i == t) test();
+                if (exact_all || i == t) test(ub - 0.5f);
                 if (i + 1 < S) step(ub);
             }
         }
@@ -1284,7 +1307,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
 #pragma unroll
             for (int j = 0; j < R; ++j) { step(ub); ub += 1.0f; }            // single intervals up to the first tested station
             pos = R;
-            test();
+            test((float)R);
             set_piece((float)G);
             float um = (float)R + 0.5f * (float)G;                           // midpoint of the piece [pos, pos + G]
             // (round 4: pieces run while the NEXT tested station pos + G exists -- the last of them used to be five single intervals of
@@ -1292,7 +1315,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
             for (base = G; base + R <= S - 1; base += G, um += (float)G) {
                 step(um);
                 pos += G;
-                test();
+                test((float)pos);
             }
             set_piece(1.0f);
             ub = (float)pos + 0.5f;
@@ -1301,7 +1324,7 @@ __device__ __forceinline__ int station_pass_f2(float k0, float dk, float L, floa
         // covers R stations on both sides); what lies beyond is within R of the LAST station (pos + G > S - 1), which is tested then.
         const int t = pos > 0 ? (S - 1 > pos + R ? S - 1 : -1) : (R < S - 1 ? R : S - 1);
         for (int i = pos; i < S; ++i, ub += 1.0f) {
-            if (i == t) test();
+            if (i == t) test(ub - 0.5f);
             if (i + 1 < S) step(ub);
         }
     }
@@ -1347,12 +1370,51 @@ __device__ __forceinline__ float wave_scan_add(float v) {          // inclusive 
     return v;
 }
 
-__device__ __forceinline__ int wave_lookup_verdict(float x, float y, bool mine, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
-                                                   const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all);
+// the look-up of station_pass_f2's test() for the wave-cooperative passes: lane = test point at (x, y) in the ego frame.  lane_lookup_flags:
+// what the point says (bit 0: nothing, bit 1: inside an occupied cell for certain, bit 2: the position is NaN); all 64 lanes call it (the
+// neighbour look-ups sit behind a wave-uniform branch).  wave_verdict: the candidate's state from the lanes' flags by three ballots.
+__device__ __forceinline__ uint32_t lane_lookup_flags(float x, float y, bool mine, float edge, const F1P_LDS(EgoParamsF2)* ep,
+                                                      const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all) {
+    const float edge_hi = 1.0f - edge;
+    const float lxf = __builtin_fmaf(ep->txx, x, __builtin_fmaf(ep->txy, y, ep->tx0));
+    const float lyf = __builtin_fmaf(ep->tyx, x, __builtin_fmaf(ep->tyy, y, ep->ty0));
+    const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
+    const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
+    const unsigned addr = __umul24(lyc, pitch_bytes) + ((lxc >> 2) & ~7u);
+    const unsigned long long w = *reinterpret_cast<const F1P_LDS(unsigned long long)*>(tile + addr);   // low: clearance word, high: bitmap word
+    const uint32_t nc = __builtin_amdgcn_ubfe((uint32_t)w, lxc, 1u), oc = __builtin_amdgcn_ubfe((uint32_t)(w >> 32), lxc, 1u);
+    const float rx = __builtin_amdgcn_fractf(lxf), ry = __builtin_amdgcn_fractf(lyf);
+    const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
+    bool undecided, hitc;
+    if (!exact_all) { undecided = nc != 0u; hitc = !near && (nc & oc) != 0u; }
+    else {
+        const bool off = (lx != (int)lxc) | (ly != (int)lyc);
+        bool amb = near;                                            // the fp64 position may lie in another cell than the f32 one
+        if (edge < 0.5f && __ballot(mine & near & !off) != 0ull) {    // (wave-uniform branch: most passes have no station within the band of a cell edge)
+            if (near & !off) amb = !near_edge_neighbours_agree(tile, pitch_bytes, tile_w, tile_h, lx, ly, rx, ry, edge, edge_hi, oc);
+        }
+        undecided = amb | off; hitc = !undecided && oc != 0u;
+    }
+    const bool nanpos = !(x == x) | !(y == y);                     // a NaN position converts to cell 0: nothing was decided
+    return (undecided ? 1u : 0u) | (hitc ? 2u : 0u) | (nanpos ? 4u : 0u);
+}
 
-template <int R>
+__device__ __forceinline__ int wave_verdict(uint32_t fl, bool mine, bool never_free) {
+    const bool any_nan = __ballot(mine & ((fl & 4u) != 0u)) != 0ull;
+    const bool hit_sure = __ballot(mine & ((fl & 2u) != 0u)) != 0ull && !any_nan;
+    const bool unsure = never_free | (__ballot(mine & ((fl & 1u) != 0u)) != 0ull) | any_nan;
+    return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
+}
+
+__device__ __forceinline__ int wave_lookup_verdict(float x, float y, bool mine, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
+                                                   const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all) {
+    return wave_verdict(lane_lookup_flags(x, y, mine, edge, ep, tile, pitch_bytes, tile_w, tile_h, exact_all), mine, never_free);
+}
+
+template <int R, bool FOOT = false>
 __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
-                                                 const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
+                                                 const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all,
+                                                 const FootF& ft = FootF()) {
     constexpr int G = 2 * R + 1;
     const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
     const float ds = L * ep->inv_den, h = 0.5f * ds;
@@ -1378,38 +1440,19 @@ __device__ __forceinline__ int station_pass_wave(float k0, float dk, float L, fl
     float dx = __builtin_fmaf(cs, Ph, -(sn * Qh)), dy = __builtin_fmaf(sn, Ph, cs * Qh);
     if (!mine) { dx = 0.f; dy = 0.f; }
     const float x = wave_scan_add(dx), y = wave_scan_add(dy);
-    return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
-}
-
-// the look-up of station_pass_f2's test() for the wave-cooperative passes: lane = test point at (x, y) in the ego frame; the verdict of the
-// candidate by three ballots (all 64 lanes call this)
-__device__ __forceinline__ int wave_lookup_verdict(float x, float y, bool mine, float edge, bool never_free, const F1P_LDS(EgoParamsF2)* ep,
-                                                   const F1P_LDS(unsigned char)* tile, unsigned pitch_bytes, unsigned tile_w, unsigned tile_h, bool exact_all) {
-    const float edge_hi = 1.0f - edge;
-    const float lxf = __builtin_fmaf(ep->txx, x, __builtin_fmaf(ep->txy, y, ep->tx0));
-    const float lyf = __builtin_fmaf(ep->tyx, x, __builtin_fmaf(ep->tyy, y, ep->ty0));
-    const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
-    const unsigned lxc = min((unsigned)lx, tile_w), lyc = min((unsigned)ly, tile_h);
-    const unsigned addr = __umul24(lyc, pitch_bytes) + ((lxc >> 2) & ~7u);
-    const unsigned long long w = *reinterpret_cast<const F1P_LDS(unsigned long long)*>(tile + addr);   // low: clearance word, high: bitmap word
-    const uint32_t nc = __builtin_amdgcn_ubfe((uint32_t)w, lxc, 1u), oc = __builtin_amdgcn_ubfe((uint32_t)(w >> 32), lxc, 1u);
-    const float rx = __builtin_amdgcn_fractf(lxf), ry = __builtin_amdgcn_fractf(lyf);
-    const bool near = (fminf(rx, ry) < edge) | (fmaxf(rx, ry) > edge_hi);
-    bool undecided, hitc;
-    if (!exact_all) { undecided = nc != 0u; hitc = !near && (nc & oc) != 0u; }
+    if constexpr (!FOOT) return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
     else {
-        const bool off = (lx != (int)lxc) | (ly != (int)lyc);
-        bool amb = near;                                            // the fp64 position may lie in another cell than the f32 one
-        if (edge < 0.5f && __ballot(mine & near & !off) != 0ull) {    // (wave-uniform branch: most passes have no station within the band of a cell edge)
-            if (near & !off) amb = !near_edge_neighbours_agree(tile, pitch_bytes, tile_w, tile_h, lx, ly, rx, ry, edge, edge_hi, oc);
-        }
-        undecided = amb | off; hitc = !undecided && oc != 0u;
+        // oriented footprint: the disc centres (x, y) + o_d (cos theta, sin theta) of the tested station, theta its heading -- the piece ends at
+        // station u = um + fm / 2 (interval units), heading [rev] = u (alpha + beta u)
+        const float us = exact_all ? (float)lane : __builtin_fmaf(0.5f, fm, um);   // (every station: lane 0 is station 0 with an empty piece, um = -1/2)
+        const float ths = us * __builtin_fmaf(beta, us, alpha);
+        const float sns = __builtin_amdgcn_sinf(ths), css = __builtin_amdgcn_cosf(ths);
+        uint32_t fl = 0u;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < ft.nd) fl |= lane_lookup_flags(__builtin_fmaf(ft.o[d], css, x), __builtin_fmaf(ft.o[d], sns, y), mine, edge, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+        return wave_verdict(fl, mine, never_free);
     }
-    const bool nanpos = !(x == x) | !(y == y);                     // a NaN position converts to cell 0: nothing was decided
-    const bool any_nan = __ballot(mine & nanpos) != 0ull;
-    const bool hit_sure = __ballot(mine & hitc) != 0ull && !any_nan;
-    const bool unsure = never_free | (__ballot(mine & undecided) != 0ull) | any_nan;
-    return hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
 }
 
 // ===================================================================================================================
@@ -1714,6 +1757,21 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     __builtin_amdgcn_wave_barrier();
     F1P_PPH();
     sn_t = shfl_d(sn_t, 0); cs_t = shfl_d(cs_t, 0);
+    // oriented footprint: the ego "stands in a cell that is not clear" when any of its disc centres (station 0: o_d along the heading) does
+    bool disc_not_clear = false;
+    if (mx.n_disc > 0 && mx.clear_bits) {                       // (wave-uniform)
+        bool ncl = false;
+        if (lane < mx.n_disc) {
+            const double o = (lane == 0 ? mx.disc_off[0] : lane == 1 ? mx.disc_off[1] : lane == 2 ? mx.disc_off[2] : mx.disc_off[3]) * a.grid.inv_res;
+            const int lx0 = cvt_flr_i32_f32((float)__builtin_fma(cs_t, o, txo)), ly0 = cvt_flr_i32_f32((float)__builtin_fma(sn_t, o, tyo));
+            ncl = true;                                          // outside the window or off the map: not clear
+            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
+                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) ncl = ((mx.clear_bits[(size_t)gy * a.grid.wwords + gw] >> (lx0 & 31)) & 1u) != 0u;
+            }
+        }
+        disc_not_clear = __ballot(ncl) != 0ull;
+    }
     if (a.prev_theta) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { pm0 += shfl_xor_d(pm0, m); pm1 += shfl_xor_d(pm1, m); pm2 += shfl_xor_d(pm2, m); }   // (requested early, consumed here: off the chain)
@@ -1775,7 +1833,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
         p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = tile_gx0; p.tile_gy0 = tile_gy0;
         p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
-        p.exact_all = own_bit < 0 ? 1 : (int)((own_word >> own_bit) & 1u);
+        p.exact_all = (own_bit < 0 || disc_not_clear) ? 1 : (int)((own_word >> own_bit) & 1u);
         *reinterpret_cast<EgoRecHdr*>(rec) = h;
     }
     F1P_PPH();
@@ -1815,7 +1873,7 @@ __device__ __forceinline__ bool candidate_goal_rec(const f1p_lattice_cfg& cfg, i
 // HG: host-supplied goals (the caller's [E][C][3] rows instead of the prologue's goal frames) -- an instantiation of its own, so that the
 // headline kernel carries neither the pointer nor the branches (as runtime branches they cost it 12 more spilled SGPRs and 1.5 us)
 // GEN: the candidate generator (F1P_GEN_CLOTHOID; F1P_GEN_CUBIC: bracket_cubic_f32 and the table-driven station passes, round 5)
-template <int CR, bool DBG = false, bool HG = false, int GEN = F1P_GEN_CLOTHOID>
+template <int CR, bool DBG = false, bool HG = false, int GEN = F1P_GEN_CLOTHOID, bool FOOT = false>
 __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, const unsigned char* __restrict__ recs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
@@ -1893,6 +1951,10 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     auto cand_of = [&](int cb) { return cb + ((blockDim.x == 256 && cb + 256 <= c1) ? (int)(__umul24((unsigned)ptid, 29u) & 255u) : ptid); };   // (formed where needed: no register held for it)
     const bool all_states = DBG && mx.dbg_state != nullptr;             // test hook: every candidate's collision state is wanted
     const bool collide_on = cfg.check_collision && a.has_grid;
+    // oriented footprint (round 5, last step: it used to take the one-kernel fallback filter): its own instantiation -- the disc loops cost the
+    // point-footprint kernel nothing
+    FootF ft;
+    if constexpr (FOOT) { ft.nd = mx.n_disc; ft.omax = mx.disc_omax_f; for (int d = 0; d < 4; ++d) ft.o[d] = mx.disc_off_f[d]; }
 
     const float INF = __builtin_huge_valf();
 
@@ -1930,7 +1992,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
             k0 = gx; dk = gy; L = b.cx; ek0 = b.cy; edk = b.m; eL = b.maxch;
         } else {
             const Fit32 f = g1_fit_f32(gx, gy, gth32);
-            o = bracket_f2<CR>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4);
+            o = bracket_f2<CR, FOOT>(f, ep, mx.sim_s2, mx.sim_s3, mx.sim_s4, ft.omax);
             trusted = r_ok & f.ok;
             k0 = f.k0; dk = f.dk; L = f.L; ek0 = f.ek0; edk = f.edk; eL = f.eLrel;
             why = (r_ok & !f.ok) ? f.why : -1;
@@ -2071,7 +2133,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
                     float edge = 2.0f;
                     bool nfree = look == 0 && (st & 0x80) != 0;
-                    if (mine) { edge = GEN == F1P_GEN_CUBIC ? edge_cubic(edk, ep) : edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex); nfree |= !(edge < 0.8f); }
+                    if (mine) { edge = GEN == F1P_GEN_CUBIC ? edge_cubic(edk, ep) : edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex, nullptr, ft.omax); nfree |= !(edge < 0.8f); }
                     const int nt = ex ? plan_x.nt : plan.nt;
                     bool coop = false;
 #ifndef F1P_MIX_DEBUG_END
@@ -2093,12 +2155,12 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                             if constexpr (GEN == F1P_GEN_CUBIC) {
                                 const float ucy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ek0), sl)), um_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edk), sl));
                                 r = station_pass_wave_cubic<CR>(uk0, udk, uL, ucy, um_, uedge, unf, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, lane, pl, ex);
-                            } else r = station_pass_wave<CR>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex);
+                            } else r = station_pass_wave<CR, FOOT>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex, ft);
                             if (lane == sl) ns = r;
                         }
                     } else if (mine) {
                         if constexpr (GEN == F1P_GEN_CUBIC) ns = station_pass_cubic<CR>(k0, dk, L, ek0, edk, edge, nfree, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, pl, ex);
-                        else ns = station_pass_f2<CR>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex);
+                        else ns = station_pass_f2<CR, FOOT>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex, ft);
                         if (DBG && mx.dbg_pass) atomicAdd(&mx.dbg_pass[4 * (size_t)e + 1], 1);
                     }
                     if (DBG && mx.dbg_pass && mine) atomicAdd(&mx.dbg_pass[4 * (size_t)e + (look == 0 ? 0 : 3)], 1);
@@ -3051,10 +3113,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // (the plans that will take the prologue + candidate-kernel pair -- decided for good below -- switch to the mixed schedule from one ego)
     // round 5: host-supplied goals and plans WITHOUT a collision check (no map set: the reference's own default, utils/utils.py:297-301 is a stub)
     // take the pair too -- they used to fall to the one-kernel fallback filter from 320 egos and to the all-fp64 kernel below
-    const bool v3_likely = F1P_MIX_FILTER_V3 && !foot && (!collide || (clear_ok && (clear_r_eff == 1 || clear_r_eff == 2))) && a.tile_words + 1 <= 16;
+    const bool v3_likely = F1P_MIX_FILTER_V3 && (!collide || (clear_ok && (clear_r_eff == 1 || clear_r_eff == 2))) && a.tile_words + 1 <= 16;
     const int min_egos = v3_likely ? F1P_MIX_MIN_EGOS_V3 : F1P_MIX_MIN_EGOS;
     // round 5: the cubic generator takes the pair as well (device-sampled goals, up to 256 stations: its basis table lives in LDS); otherwise all fp64
-    const bool cubic_ok = !cubic || (v3_likely && !a.goals && S <= 256);
+    const bool cubic_ok = !cubic || (v3_likely && !foot && !a.goals && S <= 256);
     if (ctx->lattice_mixed && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
         (E >= min_egos || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t tile_bytes = sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
@@ -3082,10 +3144,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             // clearance mode of the filter's occupancy test (device-sampled goals: the station spacing is bounded by the configuration)
             mx.clear_bits = nullptr; mx.clear_r = 0; mx.clear_ds_cap = 0.f;
             mx.n_disc = 0;
-            for (int d = 0; d < 4; ++d) mx.disc_off[d] = 0.0;
+            for (int d = 0; d < 4; ++d) { mx.disc_off[d] = 0.0; mx.disc_off_f[d] = 0.f; }
+            mx.disc_omax_f = 0.f;
             if (clear_ok && ensure_clear_map(ctx, clear_dist) == F1P_OK) {
                 mx.clear_bits = ctx->d_bits_clear; mx.clear_r = clear_r_eff; mx.clear_ds_cap = (float)clear_ds_cap;
-                if (foot) { mx.n_disc = ctx->n_disc; for (int d = 0; d < 4; ++d) mx.disc_off[d] = ctx->disc_off[d]; }
+                if (foot) {
+                    mx.n_disc = ctx->n_disc;
+                    for (int d = 0; d < 4; ++d) { mx.disc_off[d] = ctx->disc_off[d]; mx.disc_off_f[d] = (float)ctx->disc_off[d]; if (d < mx.n_disc) mx.disc_omax_f = fmaxf(mx.disc_omax_f, fabsf(mx.disc_off_f[d]) * 1.000001f); }
+                }
             }
             const bool prof = ctx->lattice_profile && ctx->ev_prof[0];
             const dim3 fb(F1P_MIX_FILTER_BLOCK);
@@ -3097,9 +3163,12 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             if (cubic) lds_f3 += 16 + (size_t)S * (sizeof(CubicTab) + sizeof(float));   // the basis table + the previous headings
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const size_t lds_rc = sizeof(double) * 16 * 5 * (size_t)S;                      // k_lattice_refine_cubic: five station arrays per group
-            bool v3 = F1P_MIX_FILTER_V3 && mx.n_disc == 0 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
+            bool v3 = F1P_MIX_FILTER_V3 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
                             (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
                                               : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
+            if (mx.n_disc > 0)                                       // oriented footprint: its own instantiations (hooks included)
+                v3 = v3 && (mx.clear_r == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3)
+                                             : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), lds_f3));
             if (cubic) {
                 v3 = v3 && !a.goals && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
                      (mx.clear_r == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3)
@@ -3224,6 +3293,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         } else {
                             if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        }
+                    } else if (mk.n_disc > 0) {                                 // (oriented footprint: one instantiation per clearance mode and goal source, hooks included)
+                        if (ak.goals) {
+                            if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        } else {
+                            if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         }
                     } else if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
                         if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
