@@ -572,7 +572,7 @@ def leg_kmpc_c4(rk, args, steps):
     return out
 
 
-def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True, device=0):
+def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True, device=0, clearance=None):
     """the headline workload (E x C x S, steady state of a closed loop, default schedule) on scenes it was NOT tuned on.
       centred       today's bench scene (sigma 0.3 m around the raceline, nothing inside the corridor)
       wall_hugging  sigma 0.9 m of a 1.1 m half-width corridor: many egos next to (or inside) a wall
@@ -608,6 +608,8 @@ def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes
             ctx.set_waypoints(rl); ctx.set_grid(im, res, origin, 206)
             ctx.lattice_set_closed_loop(True)
             ctx.lattice_set_order(order)
+            if clearance is not None:
+                ctx.lattice_set_clearance(clearance)      # (A/B: tools/scene_sweep.py --clearance)
             pose_sets = [pose_of(k) for k in range(n_plans)] if moving else [pose_of(0)]
             d_pose = [ctx.to_device(p) for p in pose_sets]
             outs = [ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4)]
@@ -853,10 +855,10 @@ def filter_shape(S, r):
     (bracket_f2: nothing there looks at positions); the station pass -- positions and occupancy look-ups -- runs only for the candidates whose
     bracket reaches below the best collision-free one (station_pass_wave; pass_plan is mirrored here): in the clearance mode r the tested
     stations are r, r + G, r + 2 G, ... (G = 2 r + 1) and the last station when the tested ones do not cover it, each reached by ONE
-    integrated piece.  r = 0 (every_station, k_lattice_filter): every interval a piece of its own, every station looked up, every candidate."""
+    integrated piece.  r = 0 (every_station: no clearance map): every interval a piece of its own, every station looked up -- for the same lazy set."""
     if r <= 0:
         return {"pieces_integrated_per_candidate": S - 1, "stations_looked_up_per_candidate": S, "clearance_r": 0,
-                "station_pass": "every candidate"}
+                "station_pass": "lazy, as with a clearance map; every look is the every-station one"}
     G = 2 * r + 1
     if G < S:
         nm = (S - 1 - r) // G
@@ -955,7 +957,7 @@ def leg_other_schedules(ctx, args, cfg, d_poses, d_prev_in, E, C, S, ref):
     """The same plan by the other schedules, every one checked bit for bit against the chain's plan (same previous path):
       all_fp64          the plain kernel (one fp64 thread per candidate; round 1's headline kernel)
       branch_and_bound  all fp64 with cfg.prune = 1 (station loops skipped while a cost lower bound exceeds the best so far)
-      every_station     the default schedule with f1p_lattice_set_clearance(0): every station looked up in the bitmap, single intervals
+      every_station     the default schedule with f1p_lattice_set_clearance(0): no clearance map, every station of a looked-at candidate tested on the bitmap
     `ref` = (bidx, ref_cost, steer, ref_traj) of the chain's plan.  Returns (fp64, bnb, every_station)."""
     import copy
     import numpy as np
@@ -986,8 +988,9 @@ def leg_other_schedules(ctx, args, cfg, d_poses, d_prev_in, E, C, S, ref):
     if not (args.all_fp64 or args.prune):
         ctx.lattice_set_clearance(0)
         every_station = other(cfg_ex, 1)
-        every_station["note"] = ("the default schedule with f1p_lattice_set_clearance(0): the f32 filter integrates every station interval as a piece "
-                                 "of its own and looks every station up in the bitmap (49 pieces, 50 look-ups per candidate)")
+        every_station["note"] = ("the default schedule with f1p_lattice_set_clearance(0) -- no clearance map: every look of the lazy station pass is the "
+                                 "every-station one (49 single-interval pieces, 50 look-ups on the real bitmap for each candidate that can still win).  Until the end "
+                                 "of round 5 this ran the one-kernel fallback filter, every station of EVERY candidate (0.137 ms); that kernel is gone")
         ctx.lattice_set_clearance(2)
     ctx.lattice_set_mode(0 if (args.all_fp64 or args.prune) else 1)
     for b_ in alt:
@@ -1080,7 +1083,7 @@ def lattice_valu_and_traffic(args, E, C, S, mixed_ms, kernel_ms, cand_sharded):
     traffic = None
     if same_cfg:
         # one plan = every kernel of the schedule (the filter reads the scene, k_lattice_select writes best_traj): their PMC bytes are summed
-        names = ("k_lattice_prologue", "k_lattice_filter", "k_lattice_refine", "k_lattice_select") if mixed_ms else (pmc["kernel"],)
+        names = ("k_lattice_prologue", "k_lattice_filter3", "k_lattice_refine", "k_lattice_select") if mixed_ms else (pmc["kernel"],)
         tb = 0.0
         for k in pmc.get("all_kernels", []):
             if any(nm in k.get("kernel", "") for nm in names) and k.get("FETCH_SIZE_KiB") is not None and k.get("WRITE_SIZE_KiB") is not None:
@@ -1303,7 +1306,8 @@ def main_lattice(args):
                                        else f"egos sharded over {world} GPU(s), no collective")},
             "value_definition": "E*C*S*steps*n_gpus / wall time of the K timed STEADY-STATE plans, inputs resident in HBM (kernel-only figure).  E*C*S is the "
                                 "workload's NOMINAL size (BASELINE's unit): the default schedule does not evaluate every candidate-step literally (filter_shape); "
-                                "every_station and all_fp64 are the schedules that do, timed beside it with bit-identical outputs.  "
+                                "all_fp64 is the schedule that does (every station of every candidate), timed beside it with bit-identical outputs; every_station is the default "
+                                "schedule without its clearance map.  "
                                 "The SURVEY 8d host-boundary figure (H2D + kernels + D2H + sync per plan) is pcie_inclusive_value / plan_latency_host_boundary",
             "per_gpu_value": value / (1 if cand_sharded else world),
             "steady_state": steady_state,

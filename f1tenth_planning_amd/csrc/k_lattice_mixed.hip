@@ -1,33 +1,35 @@
-// k_lattice_mixed.hip -- the mixed-precision schedule of the lattice planner (the default: F1P_MIX_MIN_EGOS_V3 / F1P_MIX_MIN_EGOS): an f32 filter that knows its own
+// k_lattice_mixed.hip -- the mixed-precision schedule of the lattice planner (the default at every batch size): an f32 filter that knows its own
 // error decides what CANNOT win, the unchanged fp64 arithmetic decides among the rest; every output is bit-identical to k_lattice
 // (k_lattice.hip).  Kernels: k_lattice_prologue (fp64, wave per ego) -> k_lattice_filter3 (f32, thread per candidate) -> k_lattice_refine
-// (fp64, 16 lanes per queue entry) -> k_lattice_select (fp64, wave per ego); k_lattice_filter is the one-kernel fallback filter for host
-// goals, the every-station occupancy rule without a clearance map and the oriented footprint.  Replaces LatticePlanner.plan
+// (fp64, 16 lanes per queue entry) -> k_lattice_select (fp64, wave per ego).  Since the end of round 5 this is the ONLY filter: device- and
+// host-supplied goals, clothoid and cubic candidates, point and oriented footprint, with or without a clearance map (the one-kernel
+// k_lattice_filter of rounds 2-4 is gone; LABNOTES.md 5a keeps its story).  Replaces LatticePlanner.plan
 // (planning/lattice_planner/lattice_planner.py:174-214) together with k_lattice.hip; shared device code in lattice_device.h.
 #include "lattice_device.h"
 
 namespace f1p {
 
 // ===================================================================================================================
-// Mixed-precision schedule (f1p_lattice_set_mode(ctx, 1), the default from F1P_MIX_MIN_EGOS_V3 / F1P_MIX_MIN_EGOS egos): an f32 FILTER over every
-// candidate-trajectory-step, the DECISION in fp64 -- the pattern of k_kmpc_shoot_mixed applied to the lattice planner.
+// Mixed-precision schedule (f1p_lattice_set_mode(ctx, 1), the default): an f32 FILTER over every candidate, the DECISION in fp64 -- the
+// pattern of k_kmpc_shoot_mixed applied to the lattice planner.
 //
-//   k_lattice_filter  (workgroup per ego)   nearest segment, look-ahead centres, occupancy tile and goals exactly as k_lattice
-//       (fp64: they decide indices).  Then per candidate IN F32: G1 fit (16-node Gauss-Legendre with hardware sin / cos, degree-5
-//       Taylor model of the residual), all S stations (midpoint-frame series, hardware sin / cos of the midpoint heading), the
-//       occupancy test against the LDS tile, the cost.  Alongside the cost every candidate gets a STATE:
-//         FREE    no station within `edge` cells of a cell boundary, none occupied          -> certainly collision-free in fp64
+//   k_lattice_prologue (wave per ego)   nearest segment, look-ahead centres, goal frames exactly as k_lattice (fp64: they decide indices);
+//       one record per ego for the candidate kernel.
+//   k_lattice_filter3  (workgroup per ego, thread per candidate, f32)   G1 fit (16-node Gauss-Legendre with hardware sin / cos, degree-5
+//       Taylor model of the residual), the four cost terms in closed form with the interval [lo, hi] = cost32 -+ margin that contains the
+//       fp64 cost; then, LAZILY for the candidates that can still win, the station positions (midpoint-frame series, hardware sin / cos)
+//       and the occupancy look-ups against the ego's LDS tile.  Every candidate ends in a STATE:
+//         FREE    no tested station within `edge` cells of a cell boundary, none occupied   -> certainly collision-free in fp64
 //         HIT     a station well inside an occupied cell                                     -> certainly +inf in fp64
 //         UNSURE  a station near a cell boundary / off the tile, or an f32 result that cannot be trusted (goal direction near
 //                 the +-pi seam of the fit's normalisation, phase excursion beyond the 16-node rule, model root outside its
 //                 trust radius, |kappa| ds beyond the one-piece series)                      -> only fp64 can tell
 //         BAD     no goal / degenerate goal (the fp64 tests themselves)                      -> certainly infeasible
-//       and the interval [lo, hi] = cost32 -+ margin that contains its fp64 cost.  With T = min hi over the FREE candidates (an
-//       upper bound of the ego's final minimum), a candidate needs fp64 only if it is FREE or UNSURE and lo <= T: typically the
-//       f32 winner plus the UNSURE candidates ranked above it.  Those (ego, candidate, goal) triples are appended to a global
-//       queue (one atomicAdd per ego).
-//   k_lattice_refine  (thread per queue entry, all lanes busy)   the UNCHANGED fp64 arithmetic of k_lattice for that candidate:
-//       g1_fit + station_loop + cost -- so every refined cost is bit-identical to the exhaustive kernel's.
+//       (PENDING / PENDING2: not looked at -- its lo lies above T).  With T = min hi over the FREE candidates (an upper bound of the ego's
+//       final minimum), a candidate needs fp64 only if it is FREE or UNSURE and lo <= T: typically the f32 winner plus the UNSURE
+//       candidates ranked above it.  Those (ego, candidate, goal) triples are appended to a global queue (one atomicAdd per ego).
+//   k_lattice_refine  (16 lanes per queue entry)   the UNCHANGED fp64 arithmetic of k_lattice for that candidate: g1_fit + station_loop +
+//       cost -- so every refined cost is bit-identical to the exhaustive kernel's.
 //   k_lattice_select  (wave per ego)   argmin over the ego's refined candidates (np.argmin rules), winner re-emission, tracking.
 //
 // Exactness: the final minimum is attained by a candidate whose fp64 cost is <= T, hence whose lo <= T (margin >= the f32 error,
@@ -38,12 +40,9 @@ namespace f1p {
 // k_lattice (tests: all fuzz seeds, the 4096-ego bench batch, collisions, similarity term, NaN inputs, host goals, shards).
 // ===================================================================================================================
 #ifndef F1P_MIX_MIN_EGOS_V3
-#define F1P_MIX_MIN_EGOS_V3 1  // ... and for the plans that take k_lattice_prologue + k_lattice_filter3 (device-sampled goals, clearance mode, point footprint): measured,
+#define F1P_MIX_MIN_EGOS_V3 1  // egos from which the mixed schedule is the default: measured,
                                // round 4 (the lazy station pass; tools/time_modes_vs_egos.py, all fp64 / mixed): 1 ego 0.0399 / 0.0279 ms, 8: 0.041 / 0.032, 64: 0.048 / 0.040,
                                // 256: 0.050 / 0.037, 512: 0.063 / 0.041, 2048: 0.132 / 0.052 -- the mixed schedule wins at every batch size
-#endif
-#ifndef F1P_MIX_MIN_EGOS
-#define F1P_MIX_MIN_EGOS 320   // (the one-kernel fallback filter: host goals, r = 0, oriented footprint) measured crossover (tools/time_modes_vs_egos.py, round 3): 1 ego 0.0397 (all fp64) / 0.0398 (mixed), 64: 0.048 / 0.054, 256: 0.0502 / 0.0507, 512: 0.064 / 0.053, 1024: 0.077 / 0.060, 2048: 0.132 / 0.073 ms (round 2: 512)
 #endif
 // filter tolerances (calibrated by tests/test_gpu_lattice_mixed.py through the debug hook):
 #ifndef F1P_MIX_MARGIN_REL
@@ -72,9 +71,6 @@ namespace f1p {
 #endif
 #ifndef F1P_MIX_FIT_UNROLL
 #define F1P_MIX_FIT_UNROLL 2
-#endif
-#ifndef F1P_MIX_FILTER_V3
-#define F1P_MIX_FILTER_V3 1          // prologue + candidate kernel (k_lattice_prologue, k_lattice_filter3) where it applies; 0: the one-kernel k_lattice_filter everywhere (A/B builds)
 #endif
 #ifndef F1P_MIX_COOP_MAX
 #define F1P_MIX_COOP_MAX 4           // selected candidates per wave up to which the station pass runs wave-cooperatively (station_pass_wave), one after the other
@@ -143,7 +139,7 @@ __constant__ float c_gl16_wuf[16][6] = {
     {3.112676197e-02f, -8.386952385e-04f, 2.259822926e-05f, -6.088981340e-07f, 1.640645970e-08f, -4.420639591e-10f},
     {1.357622971e-02f, -7.156638159e-05f, 3.772584204e-07f, -1.988697942e-09f, 1.048331671e-11f, -5.526225325e-14f}};
 
-struct RefEntry {                 // one fp64 re-evaluation: written by k_lattice_filter, completed by k_lattice_refine
+struct RefEntry {                 // one fp64 re-evaluation: written by k_lattice_filter3, completed by k_lattice_refine
     int32_t e, c;
     double gx, gy, gth;           // the candidate's goal in the ego frame (fp64, from candidate_goal)
     double cost, k0, dk, L;       // results
@@ -276,254 +272,6 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     f.ek0 = iL * (e_A + 4.0f * U * (fabsf(delta) + fabsf(A))) + fabsf(f.k0) * f.eLrel;
     f.edk = 2.0f * (iL * iL) * e_A + fabsf(f.dk) * (2.0f * f.eLrel + 4.0f * U);
     return f;
-}
-
-// workgroup-uniform f32 parameters of the filter's station loop (LDS)
-struct EgoParams32 {
-    float txx, txy, tx0, tyx, tyy, ty0;
-    float w_len, w_maxk, w_meank, w_sim;
-    float margin_rel, margin_abs, edge0, edge1;
-    const double* prev;
-    int tile_w, tile_h, tile_words, S, den, sim_m, n_shift, collide;
-    int clear_r;                  // > 0: the LDS tile holds the CLEARANCE map (MixArgs::clear_bits)
-    float clear_ds_cap;
-    int n_disc;                   // oriented footprint: disc centres (x, y) + o_d (cos theta, sin theta) are tested instead of the station point
-    float disc_off[4], disc_omax;
-};
-
-struct Filt32 { float cost, lo, hi; int state; float xe, ye; float ebound; };
-
-__device__ __forceinline__ int cvt_i32_sat_f32(float v) {
-    int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-
-// all S stations of one clothoid in f32: rows of sample_traj, occupancy against the LDS tile, cost terms
-__device__ __forceinline__ Filt32 station_loop_f32(const Fit32& f, const F1P_LDS(EgoParams32)* ep, const F1P_LDS(uint32_t)* tile) {
-    Filt32 o;
-    // workgroup-uniform integers through readfirstlane: an LDS read lands in a VGPR, and a loop counter compared against a VGPR
-    // bound becomes vector code (v_add / v_cmp per station) under the 64-VGPR budget of this kernel
-    const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m), n_shift = __builtin_amdgcn_readfirstlane(ep->n_shift);
-    const int tile_w = __builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = __builtin_amdgcn_readfirstlane(ep->tile_h), tile_words = __builtin_amdgcn_readfirstlane(ep->tile_words);
-    const bool collide = __builtin_amdgcn_readfirstlane(ep->collide) != 0;
-    const double* prev = ep->prev;
-    const float k0 = f.k0, dk = f.dk, L = f.L;
-    const float ds = L * __builtin_amdgcn_rcpf((float)ep->den), h = 0.5f * ds;
-    const float b = 0.5f * dk * h * h;                                       // quadratic phase coefficient of a piece on [-1, 1]
-    const float kend = __builtin_fmaf(dk, L, k0);
-    const float kmax = fmaxf(fabsf(k0), fabsf(kend));
-    const bool untrusted = !(kmax * h <= 0.4f) || !(fabsf(b) <= 0.05f);      // the one-piece series needs a small phase excursion: outside it the positions decide NOTHING
-    bool unsure = untrusted;
-    const float k0r = k0 * F1P_INV_2PI_F, hdkr = 0.5f * dk * F1P_INV_2PI_F;
-    const float edge = __builtin_fmaf(ep->edge1, L, ep->edge0), edge_hi = 1.0f - edge;
-    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
-    const float b2 = b * b, q0 = 2.0f * b;
-    float x = 0.f, y = 0.f, sim = 0.f;
-    uint32_t hit = 0u;                                                       // occupied-cell bits of the stations away from every cell edge
-    for (int i = 0; i < S; ++i) {
-        const float s = (float)i * ds;
-        if (prev && i < sim_m) {
-            const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
-            const float dd = th - (float)prev[i + n_shift];
-            sim = __builtin_fmaf(dd, dd, sim);
-        }
-        if (collide) {
-            const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0));
-            const float lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
-            const float fx = __builtin_floorf(lxf), fy = __builtin_floorf(lyf);
-            const float rx = lxf - fx, ry = lyf - fy;
-            const bool near = (rx < edge) | (rx > edge_hi) | (ry < edge) | (ry > edge_hi);
-            const int lx = cvt_i32_sat_f32(fx), ly = cvt_i32_sat_f32(fy);     // saturating: huge values land outside the tile (NaN: after the loop)
-            const bool inside = ((unsigned)lx < (unsigned)tile_w) & ((unsigned)ly < (unsigned)tile_h);
-            uint32_t occ = 0u;
-            if (inside) {                                                      // byte address in three instructions; v_bfe_u32 masks its offset to 5 bits itself
-                const unsigned addr = __umul24((unsigned)ly, (unsigned)tile_words * 4u) + (((unsigned)lx >> 3) & ~3u);
-                occ = __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(reinterpret_cast<const F1P_LDS(unsigned char)*>(tile) + addr), (unsigned)lx, 1u);
-            }
-            unsure |= near | !inside;                                          // off the tile: the fp64 path reads the global bitmap
-            hit |= near ? 0u : occ;
-        }
-        if (i + 1 < S) {
-            const float sm = s + h;
-            const float a = __builtin_fmaf(dk, sm, k0) * h;
-            const float thr = sm * __builtin_fmaf(hdkr, sm, k0r);              // midpoint heading in revolutions
-            const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
-            const float z = a * a;
-            // int_{-1}^{1} cos / sin (a t + b t^2) dt = P, Q:  P = 2 (1 - z/6 + z^2/120 - b^2/10),  Q = 2 b (1/3 - z/10)
-            const float P = __builtin_fmaf(z, __builtin_fmaf(z, (1.0f / 60.0f), (-1.0f / 3.0f)), __builtin_fmaf(b2, -0.2f, 2.0f));
-            const float Q = q0 * __builtin_fmaf(z, -0.1f, (1.0f / 3.0f));
-            x = __builtin_fmaf(h, __builtin_fmaf(cs, P, -(sn * Q)), x);
-            y = __builtin_fmaf(h, __builtin_fmaf(sn, P, cs * Q), y);
-        }
-    }
-    bool hit_sure = hit != 0u && !untrusted;                                   // (a HIT claimed from untrusted positions pruned free candidates: fuzz seed 378, 2 stations)
-    if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }            // a NaN anywhere in the rows is sticky in x / y: nothing was decided
-    // sum_i |k0 + g i|, g = dk ds, in closed form: kappa is linear in the station index, so the sum splits into at most two
-    // arithmetic series at the sign change (a station within rounding of kappa = 0 on the wrong side changes the sum by < 2 |kappa_i|)
-    float sumk;
-    {
-        const float g = dk * ds, fS = (float)S, kl = __builtin_fmaf(g, fS - 1.0f, k0);
-        if (!(k0 * kl < 0.0f)) {
-            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
-        } else {
-            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));      // last station on kappa_0's side of zero
-            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
-            const float n1 = is + 1.0f, n2 = fS - n1;
-            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
-        }
-    }
-    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (float)(S - 1) * ds, k0)));
-    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * __builtin_amdgcn_rcpf((float)S)), t4 = ep->w_sim * sim;
-    o.cost = ((t1 + t2) + t3) + t4;
-    const float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
-    o.lo = o.cost - m; o.hi = o.cost + m;
-    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
-    o.xe = x; o.ye = y;
-    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
-    return o;
-}
-
-// The same with the CLEARANCE map (LABNOTES.md 5a): `tile` (LDS offset 0) holds, per cell, "the centre of an occupied or off-map cell
-// lies within R ds_cap + (sqrt 2 + 1) cells of this cell's centre"; the real bitmap's tile follows at byte offset `occ_off`.
-// Only stations R, 3R + 1, 5R + 2, ... (and one in the tail) are looked up.  A clear cell proves the R stations before and
-// after it free in fp64: they are within R ds <= R ds_cap of the tested one along the curve, and the + 1 cell absorbs the f32
-// position error of the tested station (<< 1 cell), so no boundary band is needed.  A tested station in a cell that is not clear
-// is looked up in the real bitmap: occupied and away from every cell edge -> HIT (a station of the candidate itself), anything
-// else -> UNSURE, and fp64 decides on the real bitmap.  The loop is unrolled by the group of 2R + 1 stations: one branch per
-// group, no per-station bookkeeping.
-template <int R, bool FOOT>
-__device__ __forceinline__ Filt32 station_loop_f32_clear(const Fit32& f, const F1P_LDS(EgoParams32)* ep, const F1P_LDS(uint32_t)* tile, unsigned occ_off) {
-    Filt32 o;
-    const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m), n_shift = __builtin_amdgcn_readfirstlane(ep->n_shift);
-    const int tile_w = __builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = __builtin_amdgcn_readfirstlane(ep->tile_h), tile_words = __builtin_amdgcn_readfirstlane(ep->tile_words);
-    const double* prev = ep->prev;
-    const float k0 = f.k0, dk = f.dk, L = f.L;
-    const float ds = L * __builtin_amdgcn_rcpf((float)ep->den), h = 0.5f * ds;
-    const float b = 0.5f * dk * h * h;
-    const float kend = __builtin_fmaf(dk, L, k0);
-    const float kmax = fmaxf(fabsf(k0), fabsf(kend));
-    const bool untrusted = !(kmax * h <= 0.4f) || !(fabsf(b) <= 0.05f);      // outside the one-piece series' range the positions decide nothing
-    // oriented footprint: the tested points are the disc centres (x, y) + o_d (cos theta, sin theta).  Between stations a centre
-    // moves by at most ds (1 + |o_d| kappa_max) -- the station's own step plus the rotation of the offset -- so that is the spacing
-    // the clearance map has to cover
-    const int nd = FOOT ? __builtin_amdgcn_readfirstlane(ep->n_disc) : 0;
-    const float ds_eff = nd > 0 ? ds * __builtin_fmaf(ep->disc_omax, kmax, 1.0f) : ds;
-    bool unsure = untrusted || !(ds_eff <= ep->clear_ds_cap);                // ... and the spacing the map was built for (NaN: unsure)
-    const float k0r = k0 * F1P_INV_2PI_F, hdkr = 0.5f * dk * F1P_INV_2PI_F;
-    const float edge = __builtin_fmaf(ep->edge1, L, ep->edge0), edge_hi = 1.0f - edge;
-    const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
-    const float b2 = b * b, q0 = 2.0f * b;
-    float x = 0.f, y = 0.f, sim = 0.f;
-    uint32_t flags = 0u;                                                     // bit 0: a tested station decided nothing; bit 1: a tested station is inside an occupied cell
-    auto step = [&](int i, float sm) {                                       // station i -> i + 1 through the midpoint arc length sm (and station i's similarity term)
-        if (prev && i < sim_m) {
-            const float s = (float)i * ds;
-            const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
-            const float dd = th - (float)prev[i + n_shift];
-            sim = __builtin_fmaf(dd, dd, sim);
-        }
-        const float a = __builtin_fmaf(dk, sm, k0) * h;
-        const float thr = sm * __builtin_fmaf(hdkr, sm, k0r);
-        const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
-        const float z = a * a;
-        const float P = __builtin_fmaf(z, __builtin_fmaf(z, (1.0f / 60.0f), (-1.0f / 3.0f)), __builtin_fmaf(b2, -0.2f, 2.0f));
-        const float Q = q0 * __builtin_fmaf(z, -0.1f, (1.0f / 3.0f));
-        x = __builtin_fmaf(h, __builtin_fmaf(cs, P, -(sn * Q)), x);
-        y = __builtin_fmaf(h, __builtin_fmaf(sn, P, cs * Q), y);
-    };
-    // An ego that itself stands in a cell that is not clear (next to a wall, or inside one) would leave every candidate undecided:
-    // its workgroup tests every station against the real bitmap instead (workgroup-uniform, so no divergence) -- the plain loop's rule.
-    bool exact_all;
-    {
-        uint32_t c = 0u;
-        for (int d = 0; d < (nd > 0 ? nd : 1); ++d) {                        // station 0: heading 0, the centres sit at (o_d, 0) in the ego frame
-            const float o = nd > 0 ? ep->disc_off[d] : 0.0f;
-            const int lx0 = cvt_i32_sat_f32(__builtin_floorf(__builtin_fmaf(txx, o, tx0))), ly0 = cvt_i32_sat_f32(__builtin_floorf(__builtin_fmaf(tyx, o, ty0)));
-            uint32_t cd = 1u;
-            if (((unsigned)lx0 < (unsigned)tile_w) & ((unsigned)ly0 < (unsigned)tile_h)) cd = (tile[ly0 * tile_words + (lx0 >> 5)] >> (lx0 & 31)) & 1u;
-            c |= cd;
-        }
-        exact_all = __builtin_amdgcn_readfirstlane((int)c) != 0;
-    }
-    auto test_point = [&](float qx, float qy) {                              // one point of the station
-        const float lxf = __builtin_fmaf(txx, qx, __builtin_fmaf(txy, qy, tx0));
-        const float lyf = __builtin_fmaf(tyx, qx, __builtin_fmaf(tyy, qy, ty0));
-        const float fx = __builtin_floorf(lxf), fy = __builtin_floorf(lyf);
-        const int lx = cvt_i32_sat_f32(fx), ly = cvt_i32_sat_f32(fy);
-        const bool inside = ((unsigned)lx < (unsigned)tile_w) & ((unsigned)ly < (unsigned)tile_h);
-        uint32_t fl = 1u;                                                     // off the tile: undecided
-        if (inside) {
-            const unsigned addr = __umul24((unsigned)ly, (unsigned)tile_words * 4u) + (((unsigned)lx >> 3) & ~3u);
-            const F1P_LDS(unsigned char)* base = reinterpret_cast<const F1P_LDS(unsigned char)*>(tile);
-            fl = exact_all ? 1u : __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(base + addr), (unsigned)lx, 1u);
-            if (fl) {                                                         // not clear (rare), or every station is tested: the real bitmap, with the boundary band
-                const uint32_t occ = __builtin_amdgcn_ubfe(*reinterpret_cast<const F1P_LDS(uint32_t)*>(base + addr + occ_off), (unsigned)lx, 1u);
-                const float rx = lxf - fx, ry = lyf - fy;
-                const bool near = (rx < edge) | (rx > edge_hi) | (ry < edge) | (ry > edge_hi);
-                // the station itself is decided unless it is near a cell edge; its neighbours only when every station is tested
-                fl = ((!exact_all | near) ? 1u : 0u) | ((occ && !near) ? 2u : 0u);
-            }
-        }
-        flags |= fl;
-    };
-    auto test = [&](int i) {                                                 // station i at (x, y)
-        if (nd == 0) { test_point(x, y); return; }
-        const float s = (float)i * ds;
-        const float thr = s * __builtin_fmaf(hdkr, s, k0r);                  // heading in revolutions
-        const float sn = __builtin_amdgcn_sinf(thr), cs = __builtin_amdgcn_cosf(thr);
-        for (int d = 0; d < nd; ++d) {
-            const float o = ep->disc_off[d];
-            test_point(__builtin_fmaf(o, cs, x), __builtin_fmaf(o, sn, y));
-        }
-    };
-    constexpr int G = 2 * R + 1;
-    int base = 0;
-    float fb = 0.0f;                                                         // (float)base, kept as a float counter
-    for (; base + G < S; base += G, fb += (float)G) {                        // whole groups with a station after them: unconditional steps
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            if (exact_all || j == R) test(base + j);
-            step(base + j, __builtin_fmaf(fb, ds, ((float)j + 0.5f) * ds));  // midpoint of interval base + j: one fma (the offsets are loop constants)
-        }
-    }
-    {                                                                        // tail of <= G stations: one test covers it
-        const int t = base + R < S - 1 ? base + R : S - 1;
-        for (int i = base; i < S; ++i) {
-            if (exact_all || i == t) test(i);
-            if (i + 1 < S) step(i, __builtin_fmaf((float)i, ds, h));
-            else if (prev && i < sim_m) {                                     // the last station's similarity term
-                const float s = (float)i * ds;
-                const float th = s * __builtin_fmaf(0.5f * dk, s, k0);
-                const float dd = th - (float)prev[i + n_shift];
-                sim = __builtin_fmaf(dd, dd, sim);
-            }
-        }
-    }
-    bool hit_sure = (flags & 2u) != 0u && !untrusted;
-    unsure |= (flags & 1u) != 0u;
-    if (!(x == x) || !(y == y)) { hit_sure = false; unsure = true; }
-    float sumk;
-    {
-        const float g = dk * ds, fS = (float)S, kl = __builtin_fmaf(g, fS - 1.0f, k0);
-        if (!(k0 * kl < 0.0f)) {
-            sumk = fS * fabsf(__builtin_fmaf(0.5f * g, fS - 1.0f, k0));
-        } else {
-            float is = __builtin_floorf(-k0 * __builtin_amdgcn_rcpf(g));
-            is = fminf(fmaxf(is, 0.0f), fS - 2.0f);
-            const float n1 = is + 1.0f, n2 = fS - n1;
-            sumk = n1 * fabsf(__builtin_fmaf(0.5f * g, is, k0)) + n2 * fabsf(__builtin_fmaf(0.5f * g, is + fS, k0));
-        }
-    }
-    const float maxk = fmaxf(fabsf(k0), fabsf(__builtin_fmaf(dk, (float)(S - 1) * ds, k0)));
-    const float t1 = ep->w_len * __builtin_amdgcn_rcpf(L), t2 = ep->w_maxk * maxk, t3 = ep->w_meank * (sumk * __builtin_amdgcn_rcpf((float)S)), t4 = ep->w_sim * sim;
-    o.cost = ((t1 + t2) + t3) + t4;
-    const float m = __builtin_fmaf(ep->margin_rel, (fabsf(t1) + fabsf(t2)) + (fabsf(t3) + fabsf(t4)), ep->margin_abs);
-    o.lo = o.cost - m; o.hi = o.cost + m;
-    o.state = hit_sure ? F1P_ST_HIT : (unsure ? F1P_ST_UNSURE : F1P_ST_FREE);
-    o.xe = x; o.ye = y;
-    if (!(o.cost == o.cost) || !(fabsf(o.cost) < 1e30f)) { o.state = hit_sure ? F1P_ST_HIT : F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); o.hi = __builtin_huge_valf(); }
-    return o;
 }
 
 __device__ __forceinline__ int wave_scan_add_i32(int v) {          // inclusive sum over the 64 lanes (all active)
@@ -742,231 +490,6 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
 #undef F1P_LAT
 }
 
-// CR = MixArgs::clear_r (0: every station against the bitmap; 1, 2: clearance mode): one instantiation per station loop, so each keeps the 64-VGPR budget
-// FOOT: oriented footprint (clearance mode only) -- its own instantiations, so the point-test kernels keep their register budget
-// (round 3: 6 waves per SIMD -- 80 registers, no spills.  Since the headline configuration moved to k_lattice_prologue +
-// k_lattice_filter3 this kernel serves host goals, the r = 0 occupancy rule and the oriented footprint)
-template <int CR, bool FOOT = false>
-__global__ __launch_bounds__(256, 6) void k_lattice_filter(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    // the occupancy tile sits at LDS offset 0: its address arithmetic in the station loop then needs no base register
-    // clearance mode (MixArgs::clear_r > 0): the clearance map's tile first, the real bitmap's tile after it
-    uint32_t* tile = reinterpret_cast<uint32_t*>(lds_raw);       // [tile_rows][tile_words]
-    const unsigned tile_bytes = (unsigned)a.tile_rows * (unsigned)a.tile_words * 4u;
-    uint32_t* tile_occ = reinterpret_cast<uint32_t*>(lds_raw + tile_bytes);   // [tile_rows][tile_words], clearance mode only
-    double* red_d = reinterpret_cast<double*>(lds_raw + (((size_t)tile_bytes * 2 + 15) & ~(size_t)15));   // [4]
-    double* cen_x = red_d + 4;                                   // [64]
-    double* cen_y = cen_x + F1P_MAX_LOOKAHEADS;
-    double* cen_psi = cen_y + F1P_MAX_LOOKAHEADS;
-    EgoParams* egp = reinterpret_cast<EgoParams*>(cen_psi + F1P_MAX_LOOKAHEADS);   // candidate_goal reads the pose from here
-    EgoParams32* ep32 = reinterpret_cast<EgoParams32*>(egp + 1);
-    int* red_i = reinterpret_cast<int*>(ep32 + 1);               // [4]
-    int* cen_ok = red_i + 4;                                     // [64]
-    float* red_f = reinterpret_cast<float*>(cen_ok + F1P_MAX_LOOKAHEADS);   // [4]
-    int* cnt = reinterpret_cast<int*>(red_f + 4);                // [2]: refine count, queue base
-    int* lk_first = cnt + 2;                                     // [4][16] wave_lookahead_centres scratch per wave
-    int* lk_pairs = lk_first + 64;                               // [4][64]
-    const int e = blockIdx.x;
-    if (e >= a.E) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int C = cfg.n_lookahead * cfg.n_width, S = cfg.n_stations;
-    const int c0 = cfg.cand_begin, c1 = cfg.cand_count > 0 ? cfg.cand_begin + cfg.cand_count : C;
-    const int nc = c1 - c0;
-    float* c_lo = reinterpret_cast<float*>(lk_pairs + 256);      // [nc] per-candidate lower bound of the fp64 cost
-    unsigned char* c_st = reinterpret_cast<unsigned char*>(c_lo + nc);          // [nc] state
-    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
-    // -DF1P_MIX_PHASES: shader-clock stamps at the phase boundaries, written to the debug cost buffer (tools/mixed_phases.py)
-#ifdef F1P_MIX_PHASES
-    long long tph[8]; int nph = 0;
-#define F1P_PH() do { __syncthreads(); tph[nph++] = clock64(); } while (0)
-#else
-#define F1P_PH() do {} while (0)
-#endif
-    F1P_PH();
-
-    // ---- 3 first: the occupancy tile and the per-ego constants depend on the pose only -- their global loads and the sincos of
-    // the heading are in flight while the nearest-segment and look-ahead chains run
-    const bool collide_on = cfg.check_collision && a.has_grid;
-    int tile_gx0 = 0, tile_gy0 = 0;
-    if (collide_on) {
-        const double fx = __builtin_floor((px - a.grid.ox) * a.grid.inv_res);
-        const double fy = __builtin_floor((py - a.grid.oy) * a.grid.inv_res);
-        const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
-        const int half = a.tile_rows / 2;
-        tile_gx0 = ((egx - half) >> 5) << 5;
-        tile_gy0 = egy - half;
-        const int nwords = a.tile_rows * a.tile_words;
-        const uint32_t* __restrict__ tile_src = CR > 0 ? mx.clear_bits : a.grid.bits;
-        for (int q = tid; q < nwords; q += blockDim.x) {
-            const int r = q / a.tile_words, j = q - r * a.tile_words;
-            const int gy = tile_gy0 + r, gw = (tile_gx0 >> 5) + j;
-            uint32_t v = 0xffffffffu;
-            uint32_t vo = 0xffffffffu;
-            if (gy >= 0 && gy < a.grid.h && gw >= 0 && gw < a.grid.wwords) {
-                v = tile_src[(size_t)gy * a.grid.wwords + gw];
-                if (CR > 0) vo = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
-            }
-            tile[q] = v;
-            if (CR > 0) tile_occ[q] = vo;
-        }
-    }
-    const int den = S - 1 > 1 ? S - 1 : 1;
-    if (tid == (blockDim.x > 64 ? 64 : 0)) {
-        double sn_t, cs_t;
-        sincos(theta, &sn_t, &cs_t);
-        EgoParams q;
-        q.txx = cs_t * a.grid.inv_res; q.txy = -sn_t * a.grid.inv_res; q.tx0 = (px - a.grid.ox) * a.grid.inv_res - (double)tile_gx0;
-        q.tyx = sn_t * a.grid.inv_res; q.tyy = cs_t * a.grid.inv_res; q.ty0 = (py - a.grid.oy) * a.grid.inv_res - (double)tile_gy0;
-        q.tile_w = 0; q.tile_h = 0; q.tile_gx0 = 0; q.tile_gy0 = 0; q.grid_w = 0; q.grid_h = 0;
-        q.px = px; q.py = py; q.theta = theta; q.ct = cs_t; q.st = sn_t;
-        q.prev = nullptr; q.bits = nullptr;
-        q.tile_words = 0; q.wwords = 0; q.S = S; q.den = den; q.sim_m = 0; q.n_shift = 0; q.collide = 0; q.tile_rows_i = 0;
-        *egp = q;
-        EgoParams32 p;
-        p.txx = (float)q.txx; p.txy = (float)q.txy; p.tx0 = (float)q.tx0; p.tyx = (float)q.tyx; p.tyy = (float)q.tyy; p.ty0 = (float)q.ty0;
-        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
-        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
-        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;       // metres of position error per metre of arc -> cells
-        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
-        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_words = a.tile_words;
-        p.S = S; p.den = den; p.sim_m = S - cfg.n_shift - cfg.n_cull; p.n_shift = cfg.n_shift; p.collide = collide_on ? 1 : 0;
-        p.clear_r = mx.clear_r; p.clear_ds_cap = mx.clear_ds_cap;
-        p.n_disc = 0; p.disc_omax = 0.f;
-        for (int d = 0; d < 4; ++d) p.disc_off[d] = 0.f;
-        if constexpr (FOOT) {
-            p.n_disc = mx.n_disc;
-            for (int d = 0; d < 4; ++d) { p.disc_off[d] = (float)mx.disc_off[d]; if (d < p.n_disc) p.disc_omax = fmaxf(p.disc_omax, fabsf(p.disc_off[d])); }
-        }
-        *ep32 = p;
-        cnt[0] = 0;
-    }
-    // ---- 1-3: identical to k_lattice (fp64: these decide indices) ----------------------------------------------------------
-    double nd; int ni;
-    nearest_scan_boxed(px, py, a.wx, a.wy, a.wbox, a.n, tid, blockDim.x, nd, ni);
-    block_argmin(nd, ni, red_d, red_i);
-    const SegProj ns = seg_project(px, py, a.wx[ni], a.wy[ni], a.wx[ni + 1], a.wy[ni + 1]);
-    F1P_PH();
-    if (!a.goals) {
-#if F1P_MIX_LOOKAHEAD_PAIRS
-        wave_lookahead_centres(px, py, cfg, a.wx, a.wy, a.wpsi, a.n, (double)ni + ns.t, wave, nwaves, cen_x, cen_y, cen_psi, cen_ok,
-                               lk_first + 16 * wave, lk_pairs + 64 * wave, nd, nullptr, a.wbox);
-#else
-        for (int l = wave; l < cfg.n_lookahead; l += nwaves) {
-            const Intersect it = wave_intersect(px, py, cfg.lookahead[l], a.wx, a.wy, a.n, (double)ni + ns.t, true);
-            if (lane == 0) {
-                cen_ok[l] = it.found ? 1 : 0;
-                if (it.found) {
-                    const int r = it.i < 0 ? it.i + a.n : it.i;
-                    cen_x[l] = a.wx[r]; cen_y[l] = a.wy[r]; cen_psi[l] = a.wpsi[r];
-                }
-            }
-        }
-#endif
-    }
-    __syncthreads();
-    F1P_PH();
-    // the refinement kernel's cell arithmetic uses the same fp64 transform: handed over through global memory (one lane per field,
-    // from the LDS copy -- a struct built in the setup thread's registers costs this 64-VGPR kernel a scratch spill)
-    if (collide_on && tid >= 32 && tid < 40) {
-        const int k = tid - 32;
-        const EgoParams* q = egp;
-        if (k < 6) {
-            const double v = k == 0 ? q->txx : (k == 1 ? q->txy : (k == 2 ? q->tx0 : (k == 3 ? q->tyx : (k == 4 ? q->tyy : q->ty0))));
-            reinterpret_cast<double*>(&mx.xf[e])[k] = v;
-        } else if (k == 6) {
-            mx.xf[e].tile_gx0 = tile_gx0; mx.xf[e].tile_gy0 = tile_gy0;
-        }
-    }
-
-    // ---- 4. every candidate in f32: state + [lo, hi] ---------------------------------------------------------------------------
-    float t_min = __builtin_huge_valf();                          // min hi over this thread's FREE candidates
-    for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
-        if (c >= c1) continue;
-        double gx = 0.0, gy = 0.0, gth = 0.0;
-        const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
-        Filt32 o;
-        int dbg_code = -1;
-        o.cost = __builtin_huge_valf(); o.lo = __builtin_huge_valf(); o.hi = __builtin_huge_valf(); o.state = F1P_ST_BAD;
-        if (gok) {
-            const double r2 = gx * gx + gy * gy;
-            if (r2 > 1e-20 && r2 < 1e20) {
-                const Fit32 f = g1_fit_f32((float)gx, (float)gy, (float)gth);
-                if (f.ok) {
-                    if constexpr (CR > 0) {
-                        if (collide_on) o = station_loop_f32_clear<CR, FOOT>(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile, tile_bytes);
-                        else o = station_loop_f32(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile);
-                    } else {
-                        o = station_loop_f32(f, (const F1P_LDS(EgoParams32)*)ep32, (const F1P_LDS(uint32_t)*)tile);
-                    }
-                }
-                else { o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf(); dbg_code = f.why; }
-            } else if (r2 >= 1e-26) {                                   // tiny or huge but not the fp64 fit's "degenerate" (r <= 1e-12): fp64 decides
-                o.state = F1P_ST_UNSURE; o.lo = -__builtin_huge_valf();
-            }                                                           // r < 1e-13 (or NaN): g1_fit rejects it -> BAD
-        }
-        c_lo[c - c0] = o.lo;
-        c_st[c - c0] = (unsigned char)o.state;
-        if (o.state == F1P_ST_FREE) t_min = fminf(t_min, o.hi);
-#ifdef F1P_MIX_DEBUG_END
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = (o.state != F1P_ST_BAD && dbg_code < 0) ? __builtin_sqrtf(((float)gx - o.xe) * ((float)gx - o.xe) + ((float)gy - o.ye) * ((float)gy - o.ye)) : 0.0f;
-#else
-        if (mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
-#endif
-        if (mx.dbg_state) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : (o.state == F1P_ST_UNSURE && o.lo == -__builtin_huge_valf() ? 5 : o.state);
-    }
-    F1P_PH();
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) t_min = fminf(t_min, __shfl_xor(t_min, m, 64));
-    if (lane == 0) red_f[wave] = t_min;
-    __syncthreads();
-    t_min = red_f[0];
-    for (int w = 1; w < nwaves; ++w) t_min = fminf(t_min, red_f[w]);
-
-    // ---- 5. the candidates only fp64 can rank: count, reserve queue space, write the entries --------------------------------------
-    const bool none_free = !(t_min < __builtin_huge_valf());
-    int mine = 0;
-    for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
-        if (c >= c1) continue;
-        const int st = c_st[c - c0];
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
-        mine += (need | (none_free & (c == c0))) ? 1 : 0;
-    }
-    int pos = 0;
-    if (mine) pos = atomicAdd(&cnt[0], mine);
-    __syncthreads();
-    if (tid == 0) {
-        const int n = cnt[0];
-        const unsigned int sh = (unsigned int)e % F1P_MIX_QSHARDS;
-        const unsigned int base = sh * mx.q_shard_cap + atomicAdd(&mx.qcount[sh * 32u], (unsigned int)n);
-        cnt[1] = (int)base;
-        mx.ego_base[e] = (int)base; mx.ego_n[e] = n; mx.ego_ni[e] = ni;
-    }
-    __syncthreads();
-    const int base = cnt[1];
-    for (int cb = c0; cb < c1; cb += blockDim.x) {
-        const int c = cb + tid;
-        if (c >= c1) continue;
-        const int st = c_st[c - c0];
-        const bool need = ((st == F1P_ST_FREE) | (st == F1P_ST_UNSURE) | (st == F1P_ST_PENDING2)) & !(c_lo[c - c0] > t_min);
-        if (need | (none_free & (c == c0))) {
-            double gx = 0.0, gy = 0.0, gth = 0.0;
-            const bool gok = candidate_goal(a, cfg, e, c, C, egp, cen_x, cen_y, cen_psi, cen_ok, gx, gy, gth);
-            RefEntry r;
-            r.e = e; r.c = c; r.gx = gx; r.gy = gy; r.gth = gth;
-            // ok: 0 = no goal (infeasible), -1 = evaluate, -2 = evaluate, certainly collision-free (the occupancy test is skipped)
-            r.cost = __builtin_huge_val(); r.k0 = 0.0; r.dk = 0.0; r.L = 0.0; r.ok = gok ? (st == F1P_ST_FREE ? -2 : -1) : 0; r.pad = 0;
-            mx.q[base + pos] = r;
-            ++pos;
-        }
-    }
-    F1P_PH();
-#ifdef F1P_MIX_PHASES
-    if (tid == 0 && mx.dbg_cost32) for (int k = 0; k + 1 < nph; ++k) mx.dbg_cost32[(size_t)e * C + k] = (float)(tph[k + 1] - tph[k]);
-#endif
-}
-
 // ===================================================================================================================
 // Round 3: k_lattice_filter2 -- the f32 filter rebuilt around the MEASURED issue costs of gfx950
 // (tools/microbench/issue_cycles.hip, profiles/r03_valu_issue_cycles.txt; cycles per wave64 instruction per SIMD):
@@ -987,10 +510,9 @@ __global__ __launch_bounds__(256, 6) void k_lattice_filter(LatticeArgs a, f1p_la
 //     indices are clamped onto them with v_min_u32 (negative and huge values included: v_cvt_flr_i32_f32 saturates), so the common
 //     case is 13 instructions and one LDS read without a branch; "not clear" -- rare -- enters the exact test on the real bitmap.
 //   * similarity term in its own loop (no pointer test per station).
-// Exactness is argued exactly as for k_lattice_filter: the kernel only decides what CANNOT win or is certainly blocked; its error
-// bounds are the same constants, re-measured for this arithmetic (tests/test_gpu_lattice_mixed.py, tools/mixed_calibrate.py).
-// Scope: device-sampled goals, clearance mode (R = 1, 2), point footprint -- the configuration of the headline; everything else
-// (host goals, R = 0, oriented footprint) keeps k_lattice_filter.
+// Exactness as argued at the top of this file: the kernel only decides what CANNOT win or is certainly blocked; its error bounds are
+// measured for this arithmetic (tests/test_gpu_lattice_mixed.py, tools/mixed_calibrate.py).
+// Scope (end of round 5): every plan of the mixed schedule.
 // ===================================================================================================================
 // one per look-ahead row, ego frame.  Centre and normal stay fp64: a goal next to the ego is the DIFFERENCE of the two (centre +
 // w normal ~ 0), and in f32 the cancellation costs the fit up to 1e-5 of relative cost error (measured); two fp64 fma and two
@@ -1095,7 +617,8 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
     const bool untrusted = !(kmax * hp <= 0.4f) || !(fabsf(bp) <= 0.05f);    // outside the one-piece series' range the positions decide nothing
     // ... nor beyond the spacing the clearance map was built for (NaN: unsure).  Oriented footprint: between stations a disc centre moves by at
     // most ds (1 + |o| kappa_max) -- the station's own step plus the rotation of its offset
-    bool unsure = untrusted || !((FOOT ? ds * __builtin_fmaf(omax, kmax, 1.0f) : ds) <= ep->clear_ds_cap);
+    // (an ego whose first look is the every-station one -- exact_all: it stands in a cell that is not clear, or the plan has no clearance map -- has no spacing to respect)
+    bool unsure = untrusted || (!exact_all && !((FOOT ? ds * __builtin_fmaf(omax, kmax, 1.0f) : ds) <= ep->clear_ds_cap));
     // (the cell-edge band of the look-ups -- and with it the a-priori POSITION bound -- is formed by edge_f2 for the candidates that take the
     // station pass: nothing in the bracket needs it)
 #ifdef F1P_MIX_DEBUG_END
@@ -2035,7 +1558,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     // ---- the tiles for the station pass: requested now, behind the candidates' arithmetic; the first reduction's barrier publishes them
     {
         const int tile_gx0 = __builtin_amdgcn_readfirstlane(ep->tile_gx0), tile_gy0 = __builtin_amdgcn_readfirstlane(ep->tile_gy0);
-        const int lsh = pitch <= 8 ? 3 : 4, lw = 1 << lsh;
+        const int lsh = pitch <= 8 ? 3 : (pitch <= 16 ? 4 : 5), lw = 1 << lsh;      // (the launcher admits up to 32 words per row)
         const int j = tid & (lw - 1);
         const int gw = (tile_gx0 >> 5) + j;
         const bool col_ok = j < a.tile_words && gw >= 0 && gw < a.grid.wwords;
@@ -2045,7 +1568,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                 const bool guard = j >= a.tile_words || r >= a.tile_rows;
                 uint32_t v = 0xffffffffu, vo = guard ? 0u : 0xffffffffu;   // guard: (not clear, not occupied) = undecided; off the map: occupied
                 if (col_ok && r < a.tile_rows && gy >= 0 && gy < a.grid.h) {
-                    v = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];
+                    if (mx.clear_bits) v = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];   // (no clearance map -- f1p_lattice_set_clearance(0), a coarse grid: nothing is "clear", every look is the every-station one)
                     vo = a.grid.bits[(size_t)gy * a.grid.wwords + gw];
                 }
                 reinterpret_cast<uint2*>(tile)[r * pitch + j] = make_uint2(v, vo);   // clearance word | bitmap word, side by side
@@ -3081,7 +2604,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     double *d_steer = a.steer, *d_speed = a.speed, *d_best_cost = a.best_cost, *d_best_traj = a.best_traj;
     int32_t *d_best_idx = a.best_idx, *d_status = a.status, *d_near_idx = a.near_idx;
     float* d_best_traj32 = a.best_traj32;
-    // ---- mixed-precision schedule: f32 filter over every candidate-step, fp64 decision (see k_lattice_filter) -----------------
+    // ---- mixed-precision schedule: f32 filter over every candidate, fp64 decision (see the top of this file) -----------------
     auto fin = [](double v) { return v == v && v < HUGE_VAL && v > -HUGE_VAL; };
     const bool weights_finite = fin(cfg->w_length) && fin(cfg->w_max_kappa) && fin(cfg->w_mean_kappa) && fin(cfg->w_similarity);
     // (an oriented footprint runs here only in the filter's clearance mode: decided below, before anything is launched)
@@ -3113,16 +2636,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // (the plans that will take the prologue + candidate-kernel pair -- decided for good below -- switch to the mixed schedule from one ego)
     // round 5: host-supplied goals and plans WITHOUT a collision check (no map set: the reference's own default, utils/utils.py:297-301 is a stub)
     // take the pair too -- they used to fall to the one-kernel fallback filter from 320 egos and to the all-fp64 kernel below
-    const bool v3_likely = F1P_MIX_FILTER_V3 && (!collide || (clear_ok && (clear_r_eff == 1 || clear_r_eff == 2))) && a.tile_words + 1 <= 16;
-    const int min_egos = v3_likely ? F1P_MIX_MIN_EGOS_V3 : F1P_MIX_MIN_EGOS;
-    // round 5: the cubic generator takes the pair as well (device-sampled goals, up to 256 stations: its basis table lives in LDS); otherwise all fp64
-    const bool cubic_ok = !cubic || (v3_likely && !foot && !a.goals && S <= 256);
-    if (ctx->lattice_mixed && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
-        (E >= min_egos || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
-        const size_t tile_bytes = sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
-        size_t lds_f = sizeof(double) * (4 + 3 * F1P_MAX_LOOKAHEADS) + sizeof(EgoParams) + sizeof(EgoParams32) + sizeof(int) * (4 + F1P_MAX_LOOKAHEADS) +
-                       sizeof(float) * 4 + sizeof(int) * (2 + 64 + 256) + (size_t)n_cand * 5 + 16 + 2 * tile_bytes;
-        lds_f = (lds_f + 15) & ~(size_t)15;
+    // ... and, last step of round 5, the oriented footprint, plans without a clearance map (f1p_lattice_set_clearance(0), a grid too coarse for
+    // one: every look is then the every-station one) and occupancy windows up to 32 words wide: the one-kernel fallback filter is gone, what the
+    // pair cannot take (a window or station table beyond LDS) runs all fp64
+    const bool tile_ok = a.tile_words + 1 <= 32;
+    // the cubic generator: device-sampled goals, point footprint, a clearance map, up to 256 stations (its basis table lives in LDS); otherwise all fp64
+    const bool cubic_ok = !cubic || (!foot && !a.goals && S <= 256 && (!collide || clear_ok));
+    if (ctx->lattice_mixed && tile_ok && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
+        (E >= F1P_MIX_MIN_EGOS_V3 || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t lds_r16 = sizeof(double) * 16 * (64 + 4 * (size_t)S), lds_r64 = sizeof(double) * 4 * (64 + 4 * (size_t)S);
         const size_t lds_r_static = 1024;                          // k_lattice_refine's static tables (s_gl_wu, s_gl_x) count against the same limit
         const size_t lds_s = sizeof(double) * 16 * (size_t)S;
@@ -3131,7 +2652,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
         // filter and the selection kernel and leave the queue counter armed)
         const bool groups16 = foot ? lds_fits(ctx, k_lattice_refine<16, true>, lds_r16 + lds_r_static) : lds_fits(ctx, k_lattice_refine<16>, lds_r16 + lds_r_static);
         const bool refine_fits = groups16 || (foot ? lds_fits(ctx, k_lattice_refine<64, true>, lds_r64 + lds_r_static) : lds_fits(ctx, k_lattice_refine<64>, lds_r64 + lds_r_static));
-        if (lds_fits(ctx, k_lattice_filter<0>, lds_f) && lds_fits(ctx, k_lattice_filter<1>, lds_f) && lds_fits(ctx, k_lattice_filter<2>, lds_f) && lds_fits(ctx, k_lattice_filter<1, true>, lds_f) && lds_fits(ctx, k_lattice_filter<2, true>, lds_f) && refine_fits && lds_fits(ctx, k_lattice_select<F1P_GEN_CLOTHOID>, lds_s)) {
+        if (refine_fits && lds_fits(ctx, k_lattice_select<F1P_GEN_CLOTHOID>, lds_s)) {
             MixArgs mx;
             mx.margin_rel = F1P_MIX_MARGIN_REL; mx.margin_abs = F1P_MIX_MARGIN_ABS; mx.edge0 = F1P_MIX_EDGE0; mx.edge1 = F1P_MIX_EDGE1;
             if (ctx->dbg_margins) { mx.margin_rel = ctx->dbg_margin_rel; mx.margin_abs = ctx->dbg_margin_abs; }   // test hook (f1p_lattice_debug_margins)
@@ -3163,25 +2684,26 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             if (cubic) lds_f3 += 16 + (size_t)S * (sizeof(CubicTab) + sizeof(float));   // the basis table + the previous headings
             lds_f3 = (lds_f3 + 15) & ~(size_t)15;
             const size_t lds_rc = sizeof(double) * 16 * 5 * (size_t)S;                      // k_lattice_refine_cubic: five station arrays per group
-            bool v3 = F1P_MIX_FILTER_V3 && (!collide || mx.clear_r == 1 || mx.clear_r == 2) && a.tile_words + 1 <= 16 &&
-                            (mx.clear_r == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
+            // (clearance 0 -- no map -- runs the r = 1 instantiations: every look of theirs is the every-station one then)
+            const int cr = mx.clear_r == 2 ? 2 : 1;
+            bool v3 =       (cr == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
                                               : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
             if (mx.n_disc > 0)                                       // oriented footprint: its own instantiations (hooks included)
-                v3 = v3 && (mx.clear_r == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3)
+                v3 = v3 && (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3)
                                              : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), lds_f3));
             if (cubic) {
                 v3 = v3 && !a.goals && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
-                     (mx.clear_r == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3)
+                     (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3)
                                        : lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), lds_f3));
-                if (!v3) return F1P_OK;                              // (not handled: the all-fp64 kernel takes the plan)
             }
+            if (!v3) return F1P_OK;                                  // (not handled: the all-fp64 kernel takes the plan)
             // ---- pipeline: the batch in chunks of egos, chunk k on internal stream k % 2, the second stream one stage behind the
             // first (it waits for the first prologue): one chunk's latency-bound kernels (prologue, refinement, selection: a few waves
             // per SIMD) run beside the other's VALU-bound candidate kernel instead of after it.  Every chunk has its own queue region
             // and counters; per-ego arrays are indexed by the absolute ego.  The caller's stream is joined at both ends, so the
             // call keeps its in-order semantics.  Per-kernel profiling (f1p_lattice_profile) runs unpipelined.
             int nch = 1;
-            if (v3 && !prof) nch = ctx->lattice_chunks > 0 ? ctx->lattice_chunks : (E >= F1P_PIPE_MIN_EGOS ? F1P_PIPE_CHUNKS : 1);
+            if (!prof) nch = ctx->lattice_chunks > 0 ? ctx->lattice_chunks : (E >= F1P_PIPE_MIN_EGOS ? F1P_PIPE_CHUNKS : 1);
             if (nch > 8) nch = 8;
             int ce = ((E + nch - 1) / nch + 3) & ~3;                  // egos per chunk: the prologue / selection kernels take four egos per workgroup
             if (ce < 4) ce = 4;
@@ -3223,7 +2745,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             if (fresh || ctx->mix_q_dirty) F1P_HIP(ctx, hipMemsetAsync(mx.qcount, 0, qc_bytes, ctx->stream));
             ctx->mix_q_dirty_prev = ctx->mix_q_dirty;                // (the dispatch order's counters share the fate of the queue's)
             ctx->mix_q_dirty = true;                                 // until the selection kernels of THIS plan are enqueued
-            if (v3) {
+            {
                 const size_t need_rec = rec_stride * (size_t)E;
                 if (need_rec > ctx->rec_scratch_bytes) {
                     F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -3235,7 +2757,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             }
             // dispatch order of the candidate kernel (MixArgs::perm): one unpipelined chunk of a batch large enough to queue
             mx.perm = nullptr; mx.perm_fill = nullptr; mx.ocnt = nullptr; mx.heavy = nullptr; mx.perm_rs = 0;
-            if (v3 && nch == 1 && E >= F1P_MIX_ORDER_MIN_EGOS && F1P_MIX_F3_EGOS_PER_WG == 1 && ctx->lattice_order) {
+            if (nch == 1 && E >= F1P_MIX_ORDER_MIN_EGOS && F1P_MIX_F3_EGOS_PER_WG == 1 && ctx->lattice_order) {
                 const int rs = (E + F1P_MIX_OREG - 1) / F1P_MIX_OREG;
                 const size_t perm_bytes = (sizeof(int32_t) * (size_t)F1P_MIX_OREG * rs + 255) & ~(size_t)255, ocnt_bytes = sizeof(unsigned int) * 64 * F1P_MIX_OREG;
                 const size_t need_o = perm_bytes + ocnt_bytes + (size_t)E;
@@ -3262,7 +2784,6 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 for (int j = 0; j < 2; ++j) if (!ctx->ev_pipe[j]) F1P_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pipe[j], hipEventDisableTiming));
             }
             if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[0], ctx->stream));
-            if (prof && !v3) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[1], ctx->stream));   // no separate prologue kernel: an empty interval
             const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
             int rc = F1P_OK;
             for (int k = 0; k < nch && rc == F1P_OK; ++k) {
@@ -3274,7 +2795,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 mk.qcount = mx.qcount + (size_t)k * 32 * F1P_MIX_QSHARDS;
                 mk.q = mx.q + (size_t)k * region;
                 if (mx.inc) mk.inc = mx.inc + (size_t)k * (inc_bytes / sizeof(double));
-                if (v3) {
+                {
                     ak.pose_copy = d_pose_copy;
                     hipLaunchKernelGGL(k_lattice_prologue, dim3((Ek + 3) / 4), dim3(256), 0, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
                     if (d_pose_copy) { ak.poses = d_pose_copy; ak.pose_copy = nullptr; }      // the kernels behind the prologue read HBM
@@ -3287,7 +2808,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
                     const unsigned char* recs = (const unsigned char*)ctx->d_rec_scratch;
                     if (cubic) {
-                        if (mk.clear_r == 1) {
+                        if (cr == 1) {
                             if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         } else {
@@ -3296,16 +2817,16 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         }
                     } else if (mk.n_disc > 0) {                                 // (oriented footprint: one instantiation per clearance mode and goal source, hooks included)
                         if (ak.goals) {
-                            if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         } else {
-                            if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         }
                     } else if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
-                        if (mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL((k_lattice_filter3<2, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
-                    } else if (mk.clear_r == 1) {
+                    } else if (cr == 1) {
                         if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     } else {
@@ -3313,12 +2834,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         else hipLaunchKernelGGL(k_lattice_filter3<2>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     }
                 }
-                else if (mk.n_disc > 0 && mk.clear_r == 1) hipLaunchKernelGGL((k_lattice_filter<1, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
-                else if (mk.n_disc > 0 && mk.clear_r == 2) hipLaunchKernelGGL((k_lattice_filter<2, true>), dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
-                else if (mk.clear_r == 1) hipLaunchKernelGGL(k_lattice_filter<1>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
-                else if (mk.clear_r == 2) hipLaunchKernelGGL(k_lattice_filter<2>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
-                else hipLaunchKernelGGL(k_lattice_filter<0>, dim3(Ek), fb, lds_f, st, ak, *cfg, mk);
-                if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_filter launch"))) break;
+                if ((rc = check_hip(ctx, hipGetLastError(), "k_lattice_filter3 launch"))) break;
                 if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[2], st));
                 size_t rb = (region + 3) / 4;                            // grid-stride over the queue: a few entries per ego in the usual case
                 rb = (rb + 15) & ~(size_t)15;                            // groups (4 or 16 per workgroup) a multiple of the shard count

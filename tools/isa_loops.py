@@ -2,7 +2,7 @@
 """Static look at one kernel's gfx950 listing (hipcc -S --cuda-device-only): per basic block the VALU / SALU / readlane+writelane
 (SGPR spill traffic) / scratch counts, with the loop back-edges marked -- to see whether spills sit inside hot loops.
 
-    python tools/isa_loops.py /tmp/k_lattice.s k_lattice_filter [--min 20]
+    python tools/isa_loops.py /tmp/k_lattice.s k_lattice_filter3 [--min 20]
 """
 import re
 import sys

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Shader-clock breakdown of one queue entry's path through k_lattice_refine (needs the -DF1P_MIX_PHASES build, see mixed_phases.py)."""
+"""Shader-clock breakdown of one queue entry's path through k_lattice_refine (needs the -DF1P_MIX_PHASES build:
+   make -C f1tenth_planning_amd/csrc LIB=libf1p_phases.so OBJDIR=build_x EXTRA=-DF1P_MIX_PHASES;  F1P_LIBRARY=.../libf1p_phases.so)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--scenes", default="")
     ap.add_argument("--ego-order", action="store_true", help="f1p_lattice_set_order(0): the candidate kernel's workgroups in ego order (A/B)")
+    ap.add_argument("--clearance", type=int, default=None, help="f1p_lattice_set_clearance(r): 0 = no clearance map (A/B)")
     ap.add_argument("--lib", default="", help="another build of libf1p.so (A/B runs)")
     a = ap.parse_args()
     if a.lib:
@@ -28,7 +29,7 @@ def main():
     rl = synth.make_raceline(seed=0)
     img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
     cfg = synth.bench_lattice_cfg(n_cand=a.cands, n_stations=a.stations)
-    out = bench.leg_scene_sweep(rl, img, 0.058, origin, cfg, a.egos, a.cands, a.stations, a.steps, scenes=[s for s in a.scenes.split(",") if s] or None, order=not a.ego_order)
+    out = bench.leg_scene_sweep(rl, img, 0.058, origin, cfg, a.egos, a.cands, a.stations, a.steps, scenes=[s for s in a.scenes.split(",") if s] or None, order=not a.ego_order, clearance=a.clearance)
     for name, r in out.items():
         km = r["kernels_ms"]
         print(f"{name:18s} {r['ms_per_plan']*1e3:7.1f} us/plan (x{r.get('vs_centred', 1.0):.2f})  pro {km['k_lattice_prologue']*1e3:5.1f} f3 {km['k_lattice_filter3']*1e3:5.1f} "

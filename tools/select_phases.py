@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Shader-clock breakdown of one ego's wave in k_lattice_select (needs the -DF1P_MIX_PHASES build, see mixed_phases.py)."""
+"""Shader-clock breakdown of one ego's wave in k_lattice_select (needs the -DF1P_MIX_PHASES build, see refine_phases.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
