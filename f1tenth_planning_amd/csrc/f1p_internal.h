@@ -75,7 +75,7 @@ struct f1p_ctx {
     char* d_bb_scratch = nullptr;
     size_t bb_scratch_bytes = 0;
 
-    // mixed-precision lattice schedule (f32 filter + fp64 decision): 0 = off, 1 = from F1P_MIX_MIN_EGOS egos (default), 2 = always
+    // mixed-precision lattice schedule (f32 filter + fp64 decision): 0 = off, 1 = from F1P_MIX_MIN_EGOS_V3 egos (default: one), 2 = always
     int lattice_mixed = 1;
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;

@@ -207,8 +207,9 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius);
  * configured with f1p_inflate_grid (one exact dilation by the sum of the two radii) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
  * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the grid with the caller's inflation alone.  Needs the grid;
- * f1p_set_grid clears it.  Plans with a footprint run the all-fp64 exhaustive kernel, or -- from 320 egos, with device-sampled goals --
- * the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0); outputs are bit-identical either way. */
+ * f1p_set_grid clears it.  Plans with a footprint run the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0;
+ * round 5: the same prologue + candidate kernel pair as point-footprint plans, at every batch size), the all-fp64 exhaustive kernel
+ * otherwise; outputs are bit-identical either way. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
 
 /* ------------------------------------------------------------------------------------------------
@@ -316,9 +317,9 @@ int f1p_lattice_step_batch(f1p_ctx* ctx, const double* poses, int32_t E, const f
 int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S);
 
 /* Evaluation schedule of f1p_lattice_plan_* (clothoid generator, winner-only outputs).
- *   mixed = 1 (default): plans with device-sampled goals and a point footprint in the clearance mode (the usual case) at every batch
- *   size, other plans from 320 egos, run an f32 filter over the candidates (fit, cost bracket; stations, occupancy,
- *     cost) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
+ *   mixed = 1 (default): every plan shape at every batch size (device- or host-supplied goals, clothoid or cubic candidates, point or
+ *     oriented footprint, with or without a map; round 5) runs an f32 filter over the candidates (fit, cost bracket; lazily: stations,
+ *     occupancy) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
  *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
  *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;
  *   mixed = 2: the same for any batch size;  mixed = 0: all fp64 (with cfg.prune: branch and bound).
@@ -331,13 +332,13 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
  * one to finish merges the partial winners, re-emits and tracks: no second launch); n > 0 forces n slices (tests, A/B runs). */
 int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups);
 
-/* Occupancy test of the f32 filter (mixed schedule, device-sampled goals).  stations_each_side = r > 0 (default 2; a smaller r is taken when the clearance zone of r would not fit the ego's tile): the filter
+/* Occupancy test of the f32 filter (mixed schedule).  stations_each_side = r > 0 (default 2; a smaller r is taken when the clearance zone of r would not fit the ego's tile): the filter
  * looks up one station in 2 r + 1 in a CLEARANCE map of the active bitmap (cells whose centre is within
  * r * ds_cap + (sqrt 2 + 1) cells of an occupied or off-map cell, ds_cap = 1.2 * hypot(max look-ahead, max width) / (S - 1);
  * built on the device at the first plan and whenever the bitmap changes): a tested station in a clear cell proves the r
  * stations before and after it collision-free, anything else is decided by the fp64 kernels on the real bitmap, so every
- * output stays bit-identical.  r = 0: every station against the bitmap itself with a boundary band (the first version).
- * Range 0..2. */
+ * output stays bit-identical.  r = 0: no clearance map -- every station of a looked-at candidate against the bitmap itself with a
+ * boundary band.  Range 0..2. */
 int f1p_lattice_set_clearance(f1p_ctx* ctx, int32_t stations_each_side);
 
 /* Runtime audit of the mixed-precision schedule.  every_n > 0: every every_n-th f1p_lattice_plan_* call that runs the mixed

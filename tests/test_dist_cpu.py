@@ -180,3 +180,36 @@ def test_bench_ranks_agree_on_the_communicator():
     hung = _run_rccl_case("hang", 3)
     assert not hung[0]["ok"] and not hung[1]["ok"] and hung[1]["hung"] and not hung[0]["hung"]
     assert "did not return" in hung[1]["note"]
+
+
+TIMING_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["F1P_ROOT"])
+import bench
+rank = int(os.environ["RANK"])
+rk = bench.Ranks()
+rk.init()
+rk.barrier()
+ms = 1.5 + 2.0 * rank                          # this rank's time for the K timed steps
+print("RESULT " + json.dumps(dict(rank=rank, world=rk.world, max=rk.max(ms), per_rank=rk.gather(ms), eq=rk.all_equal_int(7), ne=rk.all_equal_int(rank))), flush=True)
+rk.barrier()
+'''
+
+
+def test_bench_timing_is_the_max_over_ranks_and_every_rank_is_reported():
+    """bench.py's contract for --gpus N: the step time is the MAX over ranks, and (VERDICT r4 #7) the JSON line carries every rank's own
+    time (per_rank_ms_per_step = min / max / all) so a straggler is visible.  World size 2 over gloo, no GPU."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), F1P_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-c", TIMING_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        d = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:]); res[d["rank"]] = d
+    for r in range(2):
+        assert res[r]["world"] == 2 and res[r]["max"] == 3.5 and res[r]["per_rank"] == [1.5, 3.5]
+        assert res[r]["eq"] is True and res[r]["ne"] is False

@@ -43,3 +43,27 @@ run("host goals", lambda c: None, cfg, d_goals=True)
 run("cubic generator", lambda c: None, cfg_c)
 run("oriented footprint (3 discs)", lambda c: c.set_footprint(offs, rad), cfg)
 run("no clearance map", lambda c: c.lattice_set_clearance(0), cfg)
+
+
+def run_mat(name, setup, cfg_, Em=1024):
+    """all_traj [E][C][S][4] + all_cost materialised (k_lattice<STAGING>, all fp64, HBM-bound)"""
+    with Context(0) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        setup(ctx)
+        d_p = ctx.to_device(poses[:Em])
+        b = [ctx.alloc(8 * Em), ctx.alloc(8 * Em), ctx.alloc(4 * Em), ctx.alloc(8 * Em), ctx.alloc(4 * Em), ctx.alloc(4 * Em), ctx.alloc(8 * Em * S * 4)]
+        d_ac, d_at = ctx.alloc(8 * Em * C), ctx.alloc(8 * Em * C * S * 4)
+        for _ in range(5):
+            ctx.lattice_plan_dev(d_p, Em, cfg_, *b, d_all_cost=d_ac, d_all_traj=d_at)
+        ctx.sync(); ctx.timer_begin()
+        for _ in range(50):
+            ctx.lattice_plan_dev(d_p, Em, cfg_, *b, d_all_cost=d_ac, d_all_traj=d_at)
+        ms = ctx.timer_end() / 50
+        print(f"{name:44s} {ms:.4f} ms per plan ({Em * C * S * 32 / ms / 1e6:.0f} GB/s of rows)")
+
+
+if "--materialised" in sys.argv:
+    run_mat("materialised, clothoid", lambda c: None, cfg)
+    run_mat("materialised, cubic", lambda c: None, cfg_c)
+    run_mat("materialised, clothoid + footprint", lambda c: c.set_footprint(offs, rad), cfg)
+    run_mat("materialised, cubic + footprint", lambda c: c.set_footprint(offs, rad), cfg_c)
