@@ -63,7 +63,7 @@ __device__ __forceinline__ bool split_merge(const LatticeArgs& a, int e, int g, 
 
 // FOOT = oriented footprint (f1p_set_footprint): further instantiations, so the point-test kernels keep their register budget.
 template <bool STAGING, int GEN, bool PRUNE = false, bool FOOT = false>
-__global__ __launch_bounds__(256, (STAGING && (GEN != F1P_GEN_CLOTHOID || FOOT)) ? F1P_K3_WAVES_STAGE2 : ((STAGING || FOOT) ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES)) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
+__global__ __launch_bounds__(256, (STAGING && GEN != F1P_GEN_CLOTHOID && !FOOT) ? F1P_K3_WAVES_STAGE2 : ((STAGING || FOOT) ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES)) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
     double* red_d = reinterpret_cast<double*>(lds_raw);          // [4]

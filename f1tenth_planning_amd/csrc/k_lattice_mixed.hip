@@ -91,6 +91,20 @@ namespace f1p {
 #ifndef F1P_MIX_ROUNDS
 #define F1P_MIX_ROUNDS 10            // rounds of the station pass (what is still undecided below T after the last one goes to fp64)
 #endif
+#ifndef F1P_F3_CONTRACT
+#define F1P_F3_CONTRACT 1            // fused multiply-adds in the f32 filter arithmetic (the translation unit is compiled with -ffp-contract=off for the fp64 code
+                                     // that has to match the exhaustive kernel bit for bit; nothing in the f32 filter has to match anything -- its error bounds count one
+                                     // rounding per operation, a fused multiply-add has fewer).  Same box, two runs each: candidate kernel 37.55 -> 36.95 us with events
+#endif
+#if F1P_F3_CONTRACT
+#define F1P_F32_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define F1P_F32_CONTRACT
+#endif
+#ifndef F1P_F3_FAST_ATAN
+#define F1P_F3_FAST_ATAN 1           // atan2_fast_f32 (6 u absolute, ~17 instructions) for the chord direction of the f32 fit instead of atan2f (~45): with the
+                                     // contraction 37.55 -> 36.6 us, plan 73.95 -> 72.85 us (0: atan2f, A/B builds)
+#endif
 #ifndef F1P_MIX_F3_EGOS_PER_WG
 #define F1P_MIX_F3_EGOS_PER_WG 1     // egos a k_lattice_filter3 workgroup evaluates one after the other (grid = egos / this)
 #endif
@@ -196,7 +210,9 @@ struct Fit32 { float k0, dk, L; bool ok; int why; float ek0, edk, eLrel; };
 
 // Clothoid.G1Hermite(0,0,0,x,y,theta) in f32: the structure of g1_fit (published guess, one quadrature pass, degree-5 Taylor
 // model) with 16 nodes and the hardware sin / cos (v_sin_f32 / v_cos_f32 take revolutions).  ok = false: do not trust it.
+__device__ __forceinline__ float atan2_fast_f32(float y, float x);
 __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
+    F1P_F32_CONTRACT
     // Round 4: ONE straight line of arithmetic, the tests collected as flags.  A wave runs every step anyway as soon as one of its 64
     // candidates passes a test, so the early returns saved nothing -- but each of them made the compiler materialise the default of every
     // result on its path (~120 v_mov_b32 and ~25 exec-mask branches per candidate, a tenth of the candidate kernel's issue time).  A
@@ -204,7 +220,7 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     Fit32 f;
     const float r = __builtin_sqrtf(x1 * x1 + y1 * y1);
     const bool c40 = (r > 1e-6f) & (r < 1e6f);
-    const float phi = atan2f(y1, x1);
+    const float phi = F1P_F3_FAST_ATAN ? atan2_fast_f32(y1, x1) : atan2f(y1, x1);
     const float PI_F = 3.14159265358979f;
     const float phi0 = -phi;                                                  // |phi| <= pi already
     float phi1 = th1 - phi;
@@ -265,7 +281,8 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     //   L = r / c0, k0 = (delta - A) / L, dk = 2 A / L^2: first-order propagation, reciprocal 1.53 u
     const float U = 6.0e-8f;
     const float Pm = fabsf(A0) + fabsf(delta - A0) + fabsf(phi0);
-    const float e_m = (24.0f + 4.0f * Pm) * U, e_g = 1.6f * e_m;
+    // (atan2_fast_f32: the chord direction within 6 u absolute -- phi0 moves by it, delta does not; |dg / dphi0| = |int cos| <= 1)
+    const float e_m = (24.0f + 4.0f * Pm) * U, e_g = 1.6f * e_m + (F1P_F3_FAST_ATAN ? 6.0f * U : 0.0f);
     const float e_A = e_g * __builtin_amdgcn_rcpf(fabsf(dv_last)) + 4.0f * U * (fabsf(A) + fabsf(delta) + Pm);   // + the rounding of phi0, phi1, delta themselves
     const float e_c0 = e_g + e_A * (1.0f / 6.0f);
     f.eLrel = e_c0 * __builtin_amdgcn_rcpf(c0) + 4.0f * U;
@@ -571,6 +588,7 @@ struct FootF { int nd; float o[4]; float omax; __device__ FootF() : nd(0), o{0.f
 template <int R>
 __device__ __forceinline__ float edge_f2(float k0, float dk, float L, float ek0, float edk, float eLrel, const F1P_LDS(EgoParamsF2)* ep, bool exact_all,
                                          float* e_pos_out = nullptr, float omax = 0.0f) {
+    F1P_F32_CONTRACT
     constexpr int G = 2 * R + 1;
     const bool macro = F1P_MIX_MACRO && !exact_all && G > 1;
     const float gm = macro ? (float)G : 1.0f;
@@ -597,6 +615,7 @@ __device__ __forceinline__ float edge_f2(float k0, float dk, float L, float ek0,
 
 template <int R, bool FOOT = false>
 __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoParamsF2)* ep, double sim_s2, double sim_s3, double sim_s4, float omax = 0.0f) {
+    F1P_F32_CONTRACT
     Brk32 o;
     const bool exact_all = __builtin_amdgcn_readfirstlane(ep->exact_all) != 0;
     const float k0 = f.k0, dk = f.dk, L = f.L;
@@ -1485,6 +1504,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 
     auto bracket_of = [&](int c, float& k0, float& dk, float& L, float& ek0, float& edk, float& eL, float& lo, float& hi, float& gx, float& gy, Brk32& o, int& dbg_code) -> int {
         // (straight-line, like g1_fit_f32: a candidate without a goal or with an untrusted fit runs through on garbage and is overruled at the end)
+        F1P_F32_CONTRACT
         bool gok, th_ok = true;
         float gth32;
         if (HG) {
@@ -2689,8 +2709,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             bool v3 =       (cr == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
                                               : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
             if (mx.n_disc > 0)                                       // oriented footprint: its own instantiations (hooks included)
-                v3 = v3 && (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3)
-                                             : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), lds_f3));
+                v3 = v3 && (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3) &&
+                                                   lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CLOTHOID, true>), lds_f3)
+                                             : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), lds_f3) &&
+                                                   lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CLOTHOID, true>), lds_f3));
             if (cubic) {
                 v3 = v3 && !a.goals && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
                      (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3)
@@ -2819,9 +2841,12 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                         if (ak.goals) {
                             if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
-                        } else {
+                        } else if (dbg) {
                             if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        } else {                                                // (device goals without hooks: the instantiation without spills)
+                            if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, false, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<2, false, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         }
                     } else if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
                         if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);

@@ -131,7 +131,7 @@ def test_filter_bracket_and_states_hold_against_fp64(ctx, scene):
         # round 3: every candidate's bracket is at least its own A-PRIORI error bound (LABNOTES.md 5c) -- and the bound holds, candidate by
         # candidate (measured: >= 140x above the actual error; it is a worst-case first-order bound)
         assert (bound[both] >= err).all(), float((err / np.maximum(bound[both], 1e-300)).max())
-        assert np.median(bound[both] / np.abs(c64[both])) < 1e-3                   # ... without being vacuous
+        assert np.median(bound[both] / np.abs(c64[both])) < 1.2e-3                 # ... without being vacuous (round 5: + 6 u for atan2_fast_f32's chord direction, 0.9e-3 -> 1.04e-3)
         assert ((st == 2) | (st >= 4)).mean() < 0.35                               # the uncertain share stays small (r = 2 clearance, round 3: ~0.27; with round 5's second look far less)
         for b in out + [d_all, d_c32, d_st, d_bd, d_poses] + ([prev] if prev is not None else []):
             b.free()

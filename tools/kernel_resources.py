@@ -25,7 +25,8 @@ CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
 #   k_lattice / g1      the out-of-line fp64 fit's 8-byte frame
 #   k_lattice_filter3<CR, true>   the TEST-HOOK instantiation of the candidate kernel (debug pointers + their stores: never the production launch)
 BUDGET = {"ILb1E": 160, "k_kmpc_plan_gen": 32, "k_kmpc_shoot_mixed": 0, "k_clothoid_g1": 8, "9k_latticeILb0E": 8,
-          "k_lattice_filter3ILi1ELb1E": 16, "k_lattice_filter3ILi2ELb1E": 16}
+          "k_lattice_filter3ILi1ELb1E": 24, "k_lattice_filter3ILi2ELb1E": 24,
+          "k_lattice_filter3ILi1ELb0ELb0ELi0ELb1E": 8, "k_lattice_filter3ILi2ELb0ELb0ELi0ELb1E": 8}   # (the instantiations WITH test hooks; the production ones: 0)
 # The headline kernels (k_lattice_prologue, k_lattice_filter3 without test hooks) carry NO scratch and no VGPR spills;
 # `make resources` is part of __graft_entry__.build().
 
