@@ -1265,7 +1265,10 @@ def main_lattice(args):
                                 "the algorithm removed as much as how fast the rest runs -- the issue-slot figure is roofline.frac")
         hbm = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                "algorithmic_bytes_per_launch": abytes, "bytes_per_candidate_step": abytes / (E * C * S),
-               "note": "0.14 B per candidate-step: the planning kernels are not memory-bound; the HBM fraction is tiny and reported as such"}
+               "note": ("the reference's all_traj data flow: every candidate's rows written once (32.3 B per candidate-step); the kernel also carries the full fp64 "
+                        "evaluation; the store-only ceiling of this chip is 4.1-4.4 TB/s (tools/microbench/stream.hip), 3.9-4.0 for this kernel's 128-byte chunks"
+                        if materialised else
+                        "0.14 B per candidate-step: the planning kernels are not memory-bound; the HBM fraction is tiny and reported as such")}
         kernels_name = ("k_lattice_prologue + k_lattice_filter3 + k_lattice_refine + k_lattice_select (one plan; the dominant kernel is k_lattice_filter3)"
                         if mixed_ms else (pmc["kernel"] if pmc else "k_lattice"))
         if valu and not materialised:
