@@ -18,3 +18,9 @@ with Context(0) as ctx:
         pct(lambda: ctx.lattice_plan(poses, cfg, reuse_outputs=True)),
         pct(lambda: ctx.lattice_plan(poses, cfg, reuse_outputs=True, traj_dtype=np.float32)),
         pct(lambda: ctx.lattice_plan(poses, cfg, reuse_outputs=True, want_traj=False))))
+    # a single vehicle (BASELINE configs[1]) and one closed-loop control step of the batch
+    cfg1 = synth.bench_lattice_cfg(n_cand=512, n_stations=50)
+    one = pct(lambda: ctx.lattice_plan(poses[:1], cfg1, reuse_outputs=True))
+    ctx.lattice_set_closed_loop(True)
+    step = pct(lambda: ctx.lattice_step(poses, cfg))
+    print("single ego x 512 candidates %.4f   closed-loop step (4096 egos) %.4f" % (one, step))
