@@ -142,8 +142,8 @@ def test_cubic_generator_under_the_mixed_schedule(ctx, scene):
     """round 5: cubic-spline candidates take the prologue + candidate-kernel pair (bracket_cubic_f32: an f32 walk over the stations with an
     a-priori error bound; table-driven station passes; k_lattice_refine_cubic).  The bracket's premises, measured through the debug hook --
     bound >= |cost32 - cost64| candidate by candidate, FREE is free and HIT collides in fp64 -- and bit-identity with the all-fp64 kernel on
-    centred, wall-hugging and obstacle scenes, previous paths included; other station counts and goal grids; more than 256 stations and
-    host goals stay with the all-fp64 kernel"""
+    centred, wall-hugging and obstacle scenes, previous paths included; other station counts and goal grids; host goals (the pair too); more
+    than 256 stations stay with the all-fp64 kernel"""
     rl, img, origin = scene
     res = 0.058
     E, C, S = 768, 256, 50
@@ -191,7 +191,7 @@ def test_cubic_generator_under_the_mixed_schedule(ctx, scene):
                 b.free()
         assert worst < 3.0e-5, worst                                                        # (measured 1.2e-5: sums over 50 stations in f32; the per-candidate bound above is what the bracket rests on)
         ctx.set_grid(img, res, origin, 206)
-        # other shapes: few / many stations, ragged goal grids, more candidates than threads; S > 256 and host goals: all fp64 (same outputs either way)
+        # other shapes: few / many stations, ragged goal grids, more candidates than threads; S > 256: all fp64 (same outputs either way)
         for S2, nl, nw, E2 in ((2, 3, 5, 300), (7, 16, 16, 300), (120, 8, 9, 300), (50, 20, 40, 60), (300, 4, 8, 40)):
             cfg2 = _abi.lattice_cfg(lookaheads=np.linspace(0.5, 3.2, nl), widths=np.linspace(-1.1, 1.1, nw), n_stations=S2, weights=(0.3, 0.2, 0.4, 0.1), generator="cubic")
             p2 = synth.make_egos(rl, E2, seed=S2 + nl, pos_sigma=0.5, yaw_sigma=0.4)
@@ -200,7 +200,24 @@ def test_cubic_generator_under_the_mixed_schedule(ctx, scene):
         rng = np.random.default_rng(5)
         goals = np.stack([np.column_stack([rng.uniform(0.3, 3.0, 64), rng.uniform(-1.2, 1.2, 64), rng.uniform(-1.0, 1.0, 64)]) for _ in range(200)])
         cfgh = _abi.lattice_cfg(lookaheads=[1.0] * 8, widths=[0.0] * 8, n_stations=40, weights=(0.25,) * 4, generator="cubic")
-        _both(ctx, synth.make_egos(rl, 200, seed=9), cfgh, goals=goals)
+        ph = synth.make_egos(rl, 200, seed=9)
+        ah = _both(ctx, ph, cfgh, goals=goals)
+        _both(ctx, ph, cfgh, goals=goals, prev_theta=ah["best_traj"][:, :, 2] + 0.01)
+        # ... host goals take the pair as well since the end of round 5 (k_lattice_filter3<.., host goals, cubic>): it did run, its claims hold
+        d_ph, d_gh = ctx.to_device(ph), ctx.to_device(goals)
+        oh = [ctx.alloc(8 * 200), ctx.alloc(8 * 200), ctx.alloc(4 * 200), ctx.alloc(8 * 200), ctx.alloc(4 * 200), ctx.alloc(4 * 200), ctx.alloc(8 * 200 * 40 * 4)]
+        d_allh, d_sth = ctx.alloc(8 * 200 * 64), ctx.alloc(4 * 200 * 64)
+        ctx.lattice_set_mode(0)
+        ctx.lattice_plan_dev(d_ph, 200, cfgh, *oh, d_goals=d_gh, d_all_cost=d_allh)
+        c64h = d_allh.download(np.float64, (200, 64))
+        ctx.lattice_set_mode(2, None, d_sth)
+        ctx.lattice_plan_dev(d_ph, 200, cfgh, *oh, d_goals=d_gh)
+        sth = d_sth.download(np.int32, (200, 64)); nqh = ctx.lattice_debug_queue(200)
+        ctx.lattice_set_mode(1)
+        assert not ((sth == 0) & ~np.isfinite(c64h)).any() and not ((sth == 1) & np.isfinite(c64h)).any()
+        assert (sth == 0).mean() > 0.2 and 1.0 <= nqh.mean() < 16.0
+        for b in oh + [d_allh, d_sth, d_ph, d_gh]:
+            b.free()
     finally:
         ctx.set_grid(img, res, origin, 206)
         ctx.lattice_set_mode(1); ctx.lattice_debug_bound(None)
