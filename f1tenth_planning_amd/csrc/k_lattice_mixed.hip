@@ -1055,7 +1055,7 @@ __device__ __forceinline__ float atan2_fast_f32(float y, float x) {
 // length outside (1e-6, 1e6), anything non-finite.
 template <int R>
 __device__ __forceinline__ CubBrk bracket_cubic_f32(float gx, float gy, float gth, const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab,
-                                                    const F1P_LDS(float)* pf, bool collide_on) {
+                                                    const F1P_LDS(float)* pf, bool collide_on, float omax = 0.0f) {
     CubBrk o;
     const int S = __builtin_amdgcn_readfirstlane(ep->S), sim_m = __builtin_amdgcn_readfirstlane(ep->sim_m);
     const bool has_prev = ep->prev != nullptr;
@@ -1111,15 +1111,17 @@ __device__ __forceinline__ CubBrk bracket_cubic_f32(float gx, float gy, float gt
     o.trusted = (m > 1e-6f) & (m < 1e6f) & (spmin > 0.0025f * (m * m)) & (thmax < 3.14159265f - 2e-3f) & (fabsf(o.cost) < 1e30f) & (len > 0.f);
     // a clear cell at a tested station proves its R neighbours on each side free while consecutive stations are no farther apart than the
     // spacing the clearance map was built for (distances along the polyline bound the straight-line ones)
-    o.never_free = !(maxch * 1.0001f + 2.0f * e_p <= ep->clear_ds_cap);
+    // (oriented footprint: a disc centre o along the tangent moves by at most chord (1 + |o| kappa_max) between stations; its f32 position adds
+    // |o| e_dir, e_dir <= sqrt 2 e_d / |p'| + 4 u <= 1 200 u for a trusted candidate (|p'| >= 0.05 m))
+    o.never_free = !(maxch * __builtin_fmaf(omax, maxk, 1.0f) * 1.0001f + 2.0f * (e_p + omax * 1200.0f * U) <= ep->clear_ds_cap);
     o.state = collide_on ? F1P_ST_PENDING : F1P_ST_FREE;
     o.cx = cx; o.cy = cy; o.m = m; o.maxch = maxch;
     return o;
 }
 
 // the cell-edge band of a cubic candidate's look-ups: its positions are closed-form (no integration error), within 15 u m of the fp64 ones
-__device__ __forceinline__ float edge_cubic(float m, const F1P_LDS(EgoParamsF2)* ep) {
-    float edge = ep->edge0 + 1.25f * (15.0f * 6.0e-8f) * m * ep->cells_per_m;
+__device__ __forceinline__ float edge_cubic(float m, const F1P_LDS(EgoParamsF2)* ep, float omax = 0.0f) {
+    float edge = ep->edge0 + 1.25f * ((15.0f * 6.0e-8f) * m + omax * (1200.0f * 6.0e-8f)) * ep->cells_per_m;
     if (!(edge == edge)) edge = 2.0f;
     return edge;
 }
@@ -1133,33 +1135,42 @@ __device__ __forceinline__ int cubic_test_station(int q, const PassPlan& pl, int
 }
 
 // a wave takes ONE cubic candidate: lane = test point, its position straight from the basis table
-template <int R>
+template <int R, bool FOOT = false>
 __device__ __forceinline__ int station_pass_wave_cubic(float gx, float gy, float cx, float cy, float m, float edge, bool never_free,
                                                        const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab, const F1P_LDS(unsigned char)* tile,
-                                                       unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all) {
+                                                       unsigned pitch_bytes, int lane, const PassPlan& pl, bool exact_all, const FootF& ft = FootF()) {
     const int S = __builtin_amdgcn_readfirstlane(ep->S);
     const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
     const bool mine = lane < pl.nt;
     const int si = mine ? cubic_test_station<R>(lane, pl, S, exact_all) : 0;
     const F1P_LDS(CubicTab)* t = tab + si;
     const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
-    return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+    if constexpr (!FOOT) return wave_lookup_verdict(x, y, mine, edge, never_free, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+    else {
+        // oriented footprint: the disc centres along the unit tangent p' / |p'| (= (cos theta, sin theta) of cubic_row's heading)
+        const float xd = __builtin_fmaf(t->d10, m, __builtin_fmaf(t->d01, gx, t->d11 * cx)), yd = __builtin_fmaf(t->d01, gy, t->d11 * cy);
+        const float rs = __builtin_amdgcn_rsqf(__builtin_fmaf(xd, xd, yd * yd));
+        const float css = xd * rs, sns = yd * rs;
+        uint32_t fl = 0u;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < ft.nd) fl |= lane_lookup_flags(__builtin_fmaf(ft.o[d], css, x), __builtin_fmaf(ft.o[d], sns, y), mine, edge, ep, tile, pitch_bytes, tile_w, tile_h, exact_all);
+        return wave_verdict(fl, mine, never_free);
+    }
 }
 
 // ... and the lane-per-candidate form (many selected candidates in a wave): the test points one after the other
-template <int R>
+template <int R, bool FOOT = false>
 __device__ __forceinline__ int station_pass_cubic(float gx, float gy, float cx, float cy, float m, float edge, bool never_free,
                                                   const F1P_LDS(EgoParamsF2)* ep, const F1P_LDS(CubicTab)* tab, const F1P_LDS(unsigned char)* tile,
-                                                  unsigned pitch_bytes, const PassPlan& pl, bool exact_all) {
+                                                  unsigned pitch_bytes, const PassPlan& pl, bool exact_all, const FootF& ft = FootF()) {
     const int S = __builtin_amdgcn_readfirstlane(ep->S);
     const unsigned tile_w = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_w), tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ep->tile_h);
     const float txx = ep->txx, txy = ep->txy, tx0 = ep->tx0, tyx = ep->tyx, tyy = ep->tyy, ty0 = ep->ty0;
     const float edge_hi = 1.0f - edge;
     uint32_t flags = 0u;
     bool nan_pos = false;
-    for (int q = 0; q < pl.nt; ++q) {
-        const F1P_LDS(CubicTab)* t = tab + cubic_test_station<R>(q, pl, S, exact_all);
-        const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
+    auto test_point = [&](float x, float y) {
         nan_pos |= !(x == x) | !(y == y);
         const float lxf = __builtin_fmaf(txx, x, __builtin_fmaf(txy, y, tx0)), lyf = __builtin_fmaf(tyx, x, __builtin_fmaf(tyy, y, ty0));
         const int lx = cvt_flr_i32_f32(lxf), ly = cvt_flr_i32_f32(lyf);
@@ -1178,6 +1189,19 @@ __device__ __forceinline__ int station_pass_cubic(float gx, float gy, float cx, 
             fl = (amb | off) ? 1u : (oc << 1);
         }
         flags |= fl;
+    };
+    for (int q = 0; q < pl.nt; ++q) {
+        const F1P_LDS(CubicTab)* t = tab + cubic_test_station<R>(q, pl, S, exact_all);
+        const float x = __builtin_fmaf(t->h10, m, __builtin_fmaf(t->h01, gx, t->h11 * cx)), y = __builtin_fmaf(t->h01, gy, t->h11 * cy);
+        if constexpr (!FOOT) test_point(x, y);
+        else {
+            const float xd = __builtin_fmaf(t->d10, m, __builtin_fmaf(t->d01, gx, t->d11 * cx)), yd = __builtin_fmaf(t->d01, gy, t->d11 * cy);
+            const float rs = __builtin_amdgcn_rsqf(__builtin_fmaf(xd, xd, yd * yd));
+            const float css = xd * rs, sns = yd * rs;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < ft.nd) test_point(__builtin_fmaf(ft.o[d], css, x), __builtin_fmaf(ft.o[d], sns, y));
+        }
     }
     const bool hit_sure = (flags & 2u) != 0u && !nan_pos;
     const bool unsure = never_free | ((flags & 1u) != 0u) | nan_pos;
@@ -1529,7 +1553,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         int why = -1;
         if constexpr (GEN == F1P_GEN_CUBIC) {
             // the six values a candidate keeps for the station pass: its goal, the end tangent, the chord length, its longest station-to-station step
-            const CubBrk b = bracket_cubic_f32<CR>(gx, gy, gth32, ep, (const F1P_LDS(CubicTab)*)ctab, (const F1P_LDS(float)*)pftab, collide_on);
+            const CubBrk b = bracket_cubic_f32<CR>(gx, gy, gth32, ep, (const F1P_LDS(CubicTab)*)ctab, (const F1P_LDS(float)*)pftab, collide_on, ft.omax);
             o.cost = b.cost; o.lo = b.lo; o.hi = b.hi; o.ebound = b.ebound; o.state = F1P_ST_PENDING; o.never_free = b.never_free;
             trusted = r_ok & b.trusted;
             k0 = gx; dk = gy; L = b.cx; ek0 = b.cy; edk = b.m; eL = b.maxch;
@@ -1676,7 +1700,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                     // the selected candidates' cell-edge band, and what it says about their positions (a band of 0.8 cells: they decide nothing)
                     float edge = 2.0f;
                     bool nfree = look == 0 && (st & 0x80) != 0;
-                    if (mine) { edge = GEN == F1P_GEN_CUBIC ? edge_cubic(edk, ep) : edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex, nullptr, ft.omax); nfree |= !(edge < 0.8f); }
+                    if (mine) { edge = GEN == F1P_GEN_CUBIC ? edge_cubic(edk, ep, ft.omax) : edge_f2<CR>(k0, dk, L, ek0, edk, eL, ep, ex, nullptr, ft.omax); nfree |= !(edge < 0.8f); }
                     const int nt = ex ? plan_x.nt : plan.nt;
                     bool coop = false;
 #ifndef F1P_MIX_DEBUG_END
@@ -1697,12 +1721,12 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
                             int r;
                             if constexpr (GEN == F1P_GEN_CUBIC) {
                                 const float ucy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ek0), sl)), um_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(edk), sl));
-                                r = station_pass_wave_cubic<CR>(uk0, udk, uL, ucy, um_, uedge, unf, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, lane, pl, ex);
+                                r = station_pass_wave_cubic<CR, FOOT>(uk0, udk, uL, ucy, um_, uedge, unf, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, lane, pl, ex, ft);
                             } else r = station_pass_wave<CR, FOOT>(uk0, udk, uL, uedge, unf, ep, tile_b, pitch_b, lane, pl, ex, ft);
                             if (lane == sl) ns = r;
                         }
                     } else if (mine) {
-                        if constexpr (GEN == F1P_GEN_CUBIC) ns = station_pass_cubic<CR>(k0, dk, L, ek0, edk, edge, nfree, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, pl, ex);
+                        if constexpr (GEN == F1P_GEN_CUBIC) ns = station_pass_cubic<CR, FOOT>(k0, dk, L, ek0, edk, edge, nfree, ep, (const F1P_LDS(CubicTab)*)ctab, tile_b, pitch_b, pl, ex, ft);
                         else ns = station_pass_f2<CR, FOOT>(k0, dk, L, edge, nfree, ep, tile_b, pitch_b, xe, ye, ex, ft);
                         if (DBG && mx.dbg_pass) atomicAdd(&mx.dbg_pass[4 * (size_t)e + 1], 1);
                     }
@@ -2308,7 +2332,7 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine(LatticeArgs a, f1p_la
 // |kappa| and the similarity terms are formed in parallel, left in LDS, and lanes 0 / 1 / 2 of the group add them up in station order
 // (+ 0.0 past a sum's last term: an identity, the sums start at + 0.0 and their terms are >= 0); the maximum is order-independent.
 // Cost, index and rows are therefore the all-fp64 kernel's, bit for bit.  16 lanes per entry, four entries per wave.
-template <int GS>
+template <int GS, bool FOOT = false>
 __global__ __launch_bounds__(256, 2) void k_lattice_refine_cubic(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs)>();
@@ -2360,16 +2384,27 @@ __global__ __launch_bounds__(256, 2) void k_lattice_refine_cubic(LatticeArgs a, 
             simv[q] = sv;
             maxk = __builtin_fmax(maxk, ak);
             if (run && check_occ) {                              // k_lattice's own cell arithmetic on the ego's tile-relative transform (NaN / off-map: occupied)
-                uint32_t word = 0xffffffffu; int bit = 0;
-                const double lxf = __builtin_floor(__builtin_fma(xf.txx, x, __builtin_fma(xf.txy, y, xf.tx0)));
-                const double lyf = __builtin_floor(__builtin_fma(xf.tyx, x, __builtin_fma(xf.tyy, y, xf.ty0)));
-                const double gxf = lxf + (double)xf.tile_gx0, gyf = lyf + (double)xf.tile_gy0;
-                if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
-                    const int cgx = (int)gxf, cgy = (int)gyf;
-                    word = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
-                    bit = cgx & 31;
+                auto occupied = [&](double qx, double qy) -> bool {
+                    uint32_t word = 0xffffffffu; int bit = 0;
+                    const double lxf = __builtin_floor(__builtin_fma(xf.txx, qx, __builtin_fma(xf.txy, qy, xf.tx0)));
+                    const double lyf = __builtin_floor(__builtin_fma(xf.tyx, qx, __builtin_fma(xf.tyy, qy, xf.ty0)));
+                    const double gxf = lxf + (double)xf.tile_gx0, gyf = lyf + (double)xf.tile_gy0;
+                    if ((gxf >= 0.0) & (gxf < (double)a.grid.w) & (gyf >= 0.0) & (gyf < (double)a.grid.h)) {
+                        const int cgx = (int)gxf, cgy = (int)gyf;
+                        word = a.grid.bits[(size_t)cgy * a.grid.wwords + (cgx >> 5)];
+                        bit = cgx & 31;
+                    }
+                    return ((word >> bit) & 1u) != 0u;
+                };
+                if (!FOOT || mx.n_disc == 0) hit |= occupied(x, y);
+                else {                                           // oriented footprint: the disc centres of station_loop<.., FOOT>
+                    double sn_h, cs_h;
+                    sincos_fast(th, &sn_h, &cs_h);
+                    for (int d = 0; d < mx.n_disc; ++d) {
+                        const double o = mx.disc_off[d];
+                        hit |= occupied(x + o * cs_h, y + o * sn_h);
+                    }
                 }
-                hit |= ((word >> bit) & 1u) != 0u;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -2660,8 +2695,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // one: every look is then the every-station one) and occupancy windows up to 32 words wide: the one-kernel fallback filter is gone, what the
     // pair cannot take (a window or station table beyond LDS) runs all fp64
     const bool tile_ok = a.tile_words + 1 <= 32;
-    // the cubic generator: device- or host-supplied goals, point footprint, a clearance map, up to 256 stations (its basis table lives in LDS); otherwise all fp64
-    const bool cubic_ok = !cubic || (!foot && S <= 256 && (!collide || clear_ok));
+    // the cubic generator: a clearance map, up to 256 stations (its basis table lives in LDS), host-supplied goals only with the point footprint; otherwise all fp64
+    const bool cubic_ok = !cubic || (!(foot && a.goals) && S <= 256 && (!collide || clear_ok));
     if (ctx->lattice_mixed && tile_ok && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
         (E >= F1P_MIX_MIN_EGOS_V3 || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t lds_r16 = sizeof(double) * 16 * (64 + 4 * (size_t)S), lds_r64 = sizeof(double) * 4 * (64 + 4 * (size_t)S);
@@ -2714,7 +2749,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                                              : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CLOTHOID, true>), lds_f3) &&
                                                    lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CLOTHOID, true>), lds_f3));
             if (cubic) {
-                v3 = v3 && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
+                v3 = v3 && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, (k_lattice_refine_cubic<16, true>), lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
+                     (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC, true>), lds_f3) : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC, true>), lds_f3)) &&
                      (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3) &&
                                     lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CUBIC>), lds_f3)
                                        : lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), lds_f3) &&
@@ -2831,7 +2867,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     const unsigned f3_grid = mk.perm ? (unsigned)(F1P_MIX_OREG * mk.perm_rs) : (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
                     const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
                     const unsigned char* recs = (const unsigned char*)ctx->d_rec_scratch;
-                    if (cubic && ak.goals) {                                    // (host goals: one instantiation per clearance mode, hooks included)
+                    if (cubic && mk.n_disc > 0) {                               // (oriented footprint, device goals: one instantiation per clearance mode, hooks included)
+                        if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        else hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                    } else if (cubic && ak.goals) {                             // (host goals: one instantiation per clearance mode, hooks included)
                         if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL((k_lattice_filter3<2, true, true, F1P_GEN_CUBIC>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     } else if (cubic) {
@@ -2872,7 +2911,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 if (rb > rb_max) rb = rb_max;
                 rb = rb & ~(size_t)15;
                 if (rb < 16) rb = 16;
-                if (cubic) hipLaunchKernelGGL(k_lattice_refine_cubic<16>, dim3((unsigned)rb), dim3(256), lds_rc, st, ak, *cfg, mk);
+                if (cubic && mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine_cubic<16, true>), dim3((unsigned)rb), dim3(256), lds_rc, st, ak, *cfg, mk);
+                else if (cubic) hipLaunchKernelGGL(k_lattice_refine_cubic<16>, dim3((unsigned)rb), dim3(256), lds_rc, st, ak, *cfg, mk);
                 else if (groups16) {
                     if (mk.n_disc > 0) hipLaunchKernelGGL((k_lattice_refine<16, true>), dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);
                     else hipLaunchKernelGGL(k_lattice_refine<16>, dim3((unsigned)rb), dim3(256), lds_r16, st, ak, *cfg, mk);

@@ -161,7 +161,7 @@ def test_random_footprints_under_the_mixed_schedule(ctx, seed):
     S = int(rng.choice([3, 5, 17, 50, 64, 100]))
     w = rng.uniform(0, 1, 4)
     cfg = _abi.lattice_cfg(lookaheads=np.sort(rng.uniform(0.4, 3.5, n_l)), widths=np.sort(rng.uniform(-1.2, 1.2, n_w)), n_stations=S, weights=tuple(w),
-                           track_lookahead=float(rng.uniform(0.3, 1.5)))
+                           track_lookahead=float(rng.uniform(0.3, 1.5)), generator="cubic" if seed % 4 == 1 else "clothoid")   # (round 5: cubic candidates with a footprint take the pair too)
     prev = rng.normal(0, 0.3, (E, S)) if seed % 3 == 0 else None
     try:
         ctx.lattice_set_mode(0)

@@ -441,7 +441,8 @@ def test_oriented_footprint_under_the_mixed_schedule(scene):
         c.set_waypoints(rl); c.set_grid(img, 0.058, origin, 206)
         for offsets, radius in (((-0.0, 0.29, 0.58 - 0.145), 0.19), ((0.15,), 0.25), ((-0.2, 0.0, 0.2, 0.4), 0.12)):
             c.set_footprint(offsets, radius)
-            for cfg, sigma in ((synth.bench_lattice_cfg(n_cand=256, n_stations=50), 0.25), (synth.bench_lattice_cfg(n_cand=64, n_stations=23), 0.6)):
+            for cfg, sigma in ((synth.bench_lattice_cfg(n_cand=256, n_stations=50), 0.25), (synth.bench_lattice_cfg(n_cand=64, n_stations=23), 0.6),
+                               (synth.bench_lattice_cfg(n_cand=256, n_stations=50, generator="cubic"), 0.3)):
                 E = 600
                 C, S = cfg.n_lookahead * cfg.n_width, cfg.n_stations
                 poses = synth.make_egos(rl, E, seed=len(offsets), pos_sigma=sigma)

@@ -43,6 +43,8 @@ run("host goals", lambda c: None, cfg, d_goals=True)
 run("cubic generator", lambda c: None, cfg_c)
 run("oriented footprint (3 discs)", lambda c: c.set_footprint(offs, rad), cfg)
 run("no clearance map", lambda c: c.lattice_set_clearance(0), cfg)
+run("cubic + oriented footprint", lambda c: c.set_footprint(offs, rad), cfg_c)
+run("cubic + host goals", lambda c: None, cfg_c, d_goals=True)
 
 
 def run_mat(name, setup, cfg_, Em=1024):
