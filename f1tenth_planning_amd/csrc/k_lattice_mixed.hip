@@ -2695,8 +2695,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // one: every look is then the every-station one) and occupancy windows up to 32 words wide: the one-kernel fallback filter is gone, what the
     // pair cannot take (a window or station table beyond LDS) runs all fp64
     const bool tile_ok = a.tile_words + 1 <= 32;
-    // the cubic generator: a clearance map, up to 256 stations (its basis table lives in LDS), host-supplied goals only with the point footprint; otherwise all fp64
-    const bool cubic_ok = !cubic || (!(foot && a.goals) && S <= 256 && (!collide || clear_ok));
+    // the cubic generator: a clearance map, up to 256 stations (its basis table lives in LDS); otherwise all fp64
+    const bool cubic_ok = !cubic || (S <= 256 && (!collide || clear_ok));
     if (ctx->lattice_mixed && tile_ok && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
         (E >= F1P_MIX_MIN_EGOS_V3 || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
         const size_t lds_r16 = sizeof(double) * 16 * (64 + 4 * (size_t)S), lds_r64 = sizeof(double) * 4 * (64 + 4 * (size_t)S);
@@ -2750,7 +2750,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                                                    lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CLOTHOID, true>), lds_f3));
             if (cubic) {
                 v3 = v3 && S <= 256 && lds_fits(ctx, k_lattice_refine_cubic<16>, lds_rc) && lds_fits(ctx, (k_lattice_refine_cubic<16, true>), lds_rc) && lds_fits(ctx, k_lattice_select<F1P_GEN_CUBIC>, lds_s) &&
-                     (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC, true>), lds_f3) : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC, true>), lds_f3)) &&
+                     (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CUBIC, true>), lds_f3)
+                               : lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true, F1P_GEN_CUBIC, true>), lds_f3)) &&
                      (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CUBIC>), lds_f3) &&
                                     lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CUBIC>), lds_f3)
                                        : lds_fits(ctx, (k_lattice_filter3<2, false, false, F1P_GEN_CUBIC>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, false, F1P_GEN_CUBIC>), lds_f3) &&
@@ -2867,7 +2868,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                     const unsigned f3_grid = mk.perm ? (unsigned)(F1P_MIX_OREG * mk.perm_rs) : (unsigned)((Ek + F1P_MIX_F3_EGOS_PER_WG - 1) / F1P_MIX_F3_EGOS_PER_WG);
                     const bool dbg = mk.dbg_cost32 || mk.dbg_state || mk.dbg_bound || mk.dbg_pass;      // (test hooks: their own instantiation)
                     const unsigned char* recs = (const unsigned char*)ctx->d_rec_scratch;
-                    if (cubic && mk.n_disc > 0) {                               // (oriented footprint, device goals: one instantiation per clearance mode, hooks included)
+                    if (cubic && mk.n_disc > 0 && ak.goals) {                   // (oriented footprint: one instantiation per clearance mode and goal source, hooks included)
+                        if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        else hipLaunchKernelGGL((k_lattice_filter3<2, true, true, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                    } else if (cubic && mk.n_disc > 0) {
                         if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, false, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL((k_lattice_filter3<2, true, false, F1P_GEN_CUBIC, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                     } else if (cubic && ak.goals) {                             // (host goals: one instantiation per clearance mode, hooks included)

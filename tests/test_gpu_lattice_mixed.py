@@ -466,6 +466,16 @@ def test_oriented_footprint_under_the_mixed_schedule(scene):
                     assert (st == 0).mean() > 0.2                     # the filter did run and decided a good share by itself
                     c.lattice_set_mode(2)
                 c.lattice_set_clearance()
+                # host-supplied goals with the footprint (both generators: their own instantiations of the candidate kernel)
+                goals = synth.make_goals(rl, poses[:200], np.linspace(0.6, 3.0, cfg.n_lookahead), np.linspace(-1.0, 1.0, cfg.n_width))
+                c.lattice_set_mode(0); wg = c.lattice_plan(poses[:200], cfg, goals=goals)
+                for r in (1, 2):
+                    c.lattice_set_clearance(r); c.lattice_set_mode(2)
+                    gg = c.lattice_plan(poses[:200], cfg, goals=goals)
+                    for k in wg:
+                        np.testing.assert_array_equal(gg[k], wg[k], err_msg=f"host goals, {offsets} r {r} {k}")
+                    assert c.lattice_debug_queue(200).mean() >= 1.0            # (the mixed schedule did take the plan)
+                c.lattice_set_clearance(); c.lattice_set_mode(2)
             plain_first = want
         c.set_footprint((), 0.0)
         c.lattice_set_mode(2)
