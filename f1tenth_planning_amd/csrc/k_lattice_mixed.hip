@@ -1113,7 +1113,8 @@ __device__ __forceinline__ CubBrk bracket_cubic_f32(float gx, float gy, float gt
     // spacing the clearance map was built for (distances along the polyline bound the straight-line ones)
     // (oriented footprint: a disc centre o along the tangent moves by at most chord (1 + |o| kappa_max) between stations; its f32 position adds
     // |o| e_dir, e_dir <= sqrt 2 e_d / |p'| + 4 u <= 1 200 u for a trusted candidate (|p'| >= 0.05 m))
-    o.never_free = !(maxch * __builtin_fmaf(omax, maxk, 1.0f) * 1.0001f + 2.0f * (e_p + omax * 1200.0f * U) <= ep->clear_ds_cap);
+    // (an ego whose first look is the every-station one -- it stands in a cell that is not clear, or the plan has no clearance map -- has no spacing to respect)
+    o.never_free = __builtin_amdgcn_readfirstlane(ep->exact_all) == 0 && !(maxch * __builtin_fmaf(omax, maxk, 1.0f) * 1.0001f + 2.0f * (e_p + omax * 1200.0f * U) <= ep->clear_ds_cap);
     o.state = collide_on ? F1P_ST_PENDING : F1P_ST_FREE;
     o.cx = cx; o.cy = cy; o.m = m; o.maxch = maxch;
     return o;
@@ -2695,10 +2696,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // one: every look is then the every-station one) and occupancy windows up to 32 words wide: the one-kernel fallback filter is gone, what the
     // pair cannot take (a window or station table beyond LDS) runs all fp64
     const bool tile_ok = a.tile_words + 1 <= 32;
-    // the cubic generator: a clearance map, up to 256 stations (its basis table lives in LDS); otherwise all fp64
-    const bool cubic_ok = !cubic || (S <= 256 && (!collide || clear_ok));
-    if (ctx->lattice_mixed && tile_ok && (!foot || clear_ok) && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
-        (E >= F1P_MIX_MIN_EGOS_V3 || ctx->lattice_mixed > 1) && (!foot || ensure_clear_map(ctx, clear_dist) == F1P_OK)) {
+    // the cubic generator: up to 256 stations (its basis table lives in LDS); otherwise all fp64
+    const bool cubic_ok = !cubic || S <= 256;
+    if (ctx->lattice_mixed && tile_ok && cubic_ok && !d_all_traj && !d_all_cost && mode != LATTICE_EMIT && weights_finite && n_cand <= 4096 &&
+        (E >= F1P_MIX_MIN_EGOS_V3 || ctx->lattice_mixed > 1)) {
         const size_t lds_r16 = sizeof(double) * 16 * (64 + 4 * (size_t)S), lds_r64 = sizeof(double) * 4 * (64 + 4 * (size_t)S);
         const size_t lds_r_static = 1024;                          // k_lattice_refine's static tables (s_gl_wu, s_gl_x) count against the same limit
         const size_t lds_s = sizeof(double) * 16 * (size_t)S;
@@ -2724,10 +2725,10 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             mx.disc_omax_f = 0.f;
             if (clear_ok && ensure_clear_map(ctx, clear_dist) == F1P_OK) {
                 mx.clear_bits = ctx->d_bits_clear; mx.clear_r = clear_r_eff; mx.clear_ds_cap = (float)clear_ds_cap;
-                if (foot) {
-                    mx.n_disc = ctx->n_disc;
-                    for (int d = 0; d < 4; ++d) { mx.disc_off[d] = ctx->disc_off[d]; mx.disc_off_f[d] = (float)ctx->disc_off[d]; if (d < mx.n_disc) mx.disc_omax_f = fmaxf(mx.disc_omax_f, fabsf(mx.disc_off_f[d]) * 1.000001f); }
-                }
+            }
+            if (foot) {                                              // (with or without a clearance map: without one every look tests every station's disc centres)
+                mx.n_disc = ctx->n_disc;
+                for (int d = 0; d < 4; ++d) { mx.disc_off[d] = ctx->disc_off[d]; mx.disc_off_f[d] = (float)ctx->disc_off[d]; if (d < mx.n_disc) mx.disc_omax_f = fmaxf(mx.disc_omax_f, fabsf(mx.disc_off_f[d]) * 1.000001f); }
             }
             const bool prof = ctx->lattice_profile && ctx->ev_prof[0];
             const dim3 fb(F1P_MIX_FILTER_BLOCK);

@@ -207,9 +207,8 @@ int f1p_inflate_grid(f1p_ctx* ctx, double radius);
  * configured with f1p_inflate_grid (one exact dilation by the sum of the two radii) and every
  * station of every lattice candidate tests the n_discs centres (x, y) + o_d (cos theta, sin theta) against it -- a rectangle-aware
  * test for the price of n_discs bit tests.  n_discs = 0 restores the point test on the grid with the caller's inflation alone.  Needs the grid;
- * f1p_set_grid clears it.  Plans with a footprint run the mixed-precision schedule in its clearance mode (f1p_lattice_set_clearance > 0;
- * round 5: the same prologue + candidate kernel pair as point-footprint plans, at every batch size), the all-fp64 exhaustive kernel
- * otherwise; outputs are bit-identical either way. */
+ * f1p_set_grid clears it.  Plans with a footprint run the mixed-precision schedule (round 5: the same prologue + candidate kernel pair as
+ * point-footprint plans, at every batch size, with or without a clearance map); outputs are bit-identical to the all-fp64 kernel. */
 int f1p_set_footprint(f1p_ctx* ctx, int32_t n_discs, const double* offsets, double radius);
 
 /* ------------------------------------------------------------------------------------------------

@@ -68,6 +68,14 @@ def test_random_lattice_configurations(ctx, orc, seed):
         np.testing.assert_array_equal(np.asarray(m[k]), a[k], err_msg=f"mixed precision differs in {k}")
     # the same three schedules on a candidate shard (the multi-GPU split), and with the filter's other occupancy rules
     C = n_l * n_w
+    if kw["generator"] == "cubic":                             # (round 5: cubic candidates with and without the clearance map)
+        for r in (0, 1):
+            ctx.lattice_set_clearance(r)
+            ctx.lattice_set_mode(2)
+            fm = ctx.lattice_plan(poses, full, prev_theta=prev)
+            for k in a:
+                np.testing.assert_array_equal(np.asarray(fm[k]), a[k], err_msg=f"cubic, mixed precision (clearance {r}) differs in {k}")
+        ctx.lattice_set_clearance(); ctx.lattice_set_mode(1)
     if seed % 3 == 2 and C >= 3 and kw["generator"] == "clothoid":
         import copy
         sh = copy.copy(full); sh.cand_begin = int(rng.integers(0, C - 1)); sh.cand_count = int(rng.integers(1, C - sh.cand_begin + 1))
@@ -145,7 +153,7 @@ def test_random_kmpc_configurations(ctx, orc, seed):
 @pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
 def test_random_footprints_under_the_mixed_schedule(ctx, seed):
     """random oriented footprints (1..4 discs, offsets to +-0.6 m, radii 0.05..0.3 m) on random maps and goal grids: the mixed schedule
-    (filter clearance 1 and 2) against the all-fp64 footprint kernel, bit for bit"""
+    (filter clearance 0, 1 and 2) against the all-fp64 footprint kernel, bit for bit"""
     rng = np.random.default_rng(7000 + seed)
     rl = synth.make_raceline(seed=seed, n_pts=int(rng.integers(400, 1400)), spacing=float(rng.uniform(0.1, 0.3)))
     res = float(rng.uniform(0.04, 0.1))
@@ -166,7 +174,7 @@ def test_random_footprints_under_the_mixed_schedule(ctx, seed):
     try:
         ctx.lattice_set_mode(0)
         a = ctx.lattice_plan(poses, cfg, prev_theta=prev)
-        for r in (1, 2):
+        for r in (0, 1, 2):                                       # (0: no clearance map -- every look tests every station's disc centres)
             ctx.lattice_set_clearance(r)
             ctx.lattice_set_mode(2)
             m = ctx.lattice_plan(poses, cfg, prev_theta=prev)

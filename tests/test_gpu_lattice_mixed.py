@@ -453,7 +453,7 @@ def test_oriented_footprint_under_the_mixed_schedule(scene):
                 d_all = c.alloc(8 * E * C)
                 c.lattice_plan_dev(d_poses, E, cfg, *b, d_all_cost=d_all)
                 c64 = d_all.download(np.float64, (E, C))
-                for r in (1, 2):
+                for r in (0, 1, 2):
                     c.lattice_set_clearance(r)
                     d_c, d_s = c.alloc(4 * E * C), c.alloc(4 * E * C)
                     c.lattice_set_mode(2, d_c, d_s)
