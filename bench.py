@@ -724,13 +724,19 @@ def leg_variants(rk, rl, img, res, origin, E, C, S, steps, warmup=10):
                                                            ((n,), (n,), (n,), (n,), (n,), (n,), (n, S, 4)))}
 
     def timed(ctx, fn):
+        """ms per plan, HIP events; the better of two passes of `steps` plans (a one-off stall of the box -- seen once: 87 ms inside one leg -- would
+        otherwise be recorded as that variant's time; the headline's timed region is a single pass, as the contract demands)"""
         for _ in range(warmup):
             fn()
-        ctx.sync()
-        ctx.timer_begin()
-        for _ in range(steps):
-            fn()
-        return ctx.timer_end() / steps
+        best = None
+        for _ in range(2):
+            ctx.sync()
+            ctx.timer_begin()
+            for _ in range(steps):
+                fn()
+            ms = ctx.timer_end() / steps
+            best = ms if best is None else min(best, ms)
+        return best
 
     # ---- host goals ---------------------------------------------------------------------------------------------------------------------
     cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
