@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--scenes", default="")
     ap.add_argument("--ego-order", action="store_true", help="f1p_lattice_set_order(0): the candidate kernel's workgroups in ego order (A/B)")
+    ap.add_argument("--track-seed", type=int, default=0, help="seed of the synthetic raceline (0 = the bench's track)")
     ap.add_argument("--clearance", type=int, default=None, help="f1p_lattice_set_clearance(r): 0 = no clearance map (A/B)")
     ap.add_argument("--lib", default="", help="another build of libf1p.so (A/B runs)")
     a = ap.parse_args()
@@ -26,7 +27,7 @@ def main():
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import bench
     from f1tenth_planning_amd import synth
-    rl = synth.make_raceline(seed=0)
+    rl = synth.make_raceline(seed=a.track_seed)
     img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
     cfg = synth.bench_lattice_cfg(n_cand=a.cands, n_stations=a.stations)
     out = bench.leg_scene_sweep(rl, img, 0.058, origin, cfg, a.egos, a.cands, a.stations, a.steps, scenes=[s for s in a.scenes.split(",") if s] or None, order=not a.ego_order, clearance=a.clearance)
