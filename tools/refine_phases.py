@@ -7,7 +7,10 @@ import numpy as np
 from f1tenth_planning_amd import synth
 from f1tenth_planning_amd.runtime import Context
 E, C, S = 4096, 256, 50
+scene = sys.argv[1] if len(sys.argv) > 1 else "centred"       # centred | obstacles (parked discs on the raceline: the egos behind one refine many candidates)
 rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
+if scene == "obstacles":
+    img, _ = synth.stamp_obstacles(img, origin, 0.058, rl)
 poses = synth.make_egos(rl, E, seed=1)
 cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S)
 names = ["queue count + entry load", "fit: g1_begin (atan2, guess)", "fit: node sincos -> LDS", "fit: moment chains + gather", "fit: model steps (+ further passes) + finish", "interval setup + increments", "prefix sums (positions)", "position hand-over + occupancy words", "per-station cost terms -> LDS", "sequential sums, cost, store"]
