@@ -55,6 +55,122 @@ VALU_CYC = {"fast": 2.5, "slow": 4.3, "trans": 8.3}
 VALU_ISSUE_PEAK_TLANES = VALU_PEAK_SLOW_CLASS      # fp64 kernels (kmpc / all-fp64 lattice lines)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The record.  The driver parses the LAST stdout line and keeps about 8 KB of tail: round 5's 27 KB line did not parse.
+# The line is now a compact object (< 4 KB: contract fields, roofline, cpu_baseline, parity, a bounded set of flat scalars); the full
+# record -- every nested leg -- goes to bench_full.json beside this script (and into gpurun_out/ when that directory exists).
+COMPACT_MAX_BYTES = 4096
+FULL_RECORD_PATH = None          # --full-record
+COMPACT_CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+COMPACT_CONFIG = ("workload", "egos_per_gpu", "candidates", "stations", "generator", "state", "rollouts", "horizon", "parallelism")
+COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "dominant_kernel_ms",
+                    "algorithmic_bytes_per_launch", "shader_clock_mhz")
+COMPACT_CPU = ("value", "unit", "cores", "kind", "sample")
+COMPACT_PARITY = ("egos_checked", "best_idx_mismatches", "max_abs_dsteer", "near_idx_mismatches", "max_abs_steer_diff", "max_abs_dspeed")
+# flat scalars, in the order they are dropped LAST-first should the line ever outgrow COMPACT_MAX_BYTES
+COMPACT_SCALARS = (
+    "per_gpu_value", "rccl_ranks", "exchange_us_p50", "candidate_sharded_ranks", "candidate_sharded_bit_identical", "exchange_selftest_ok",
+    "hsa_ipc_env_zero_on_every_rank", "audit_mismatching_egos", "other_schedules_bit_identical",
+    "host_boundary_p50_ms", "host_boundary_d2h_ms", "host_boundary_no_traj_p50_ms", "closed_loop_step_p50_ms",
+    "kernel_ms_prologue", "kernel_ms_filter3", "kernel_ms_refine", "kernel_ms_select",
+    "valu_instr_per_candidate", "traffic_over_algorithmic_bytes",
+    "scene_sweep_worst_vs_centred", "scene_sweep_all_bit_identical", "scene_sweep_oracle_mismatches",
+    "kmpc_c4_streamed_ms", "kmpc_c4_generated_ms", "kmpc_c4_cache_stream_frac", "kmpc_c4_generated_roofline_frac",
+    "kmpc_stream8192_ms", "kmpc_stream8192_hbm_frac", "kmpc_stream8192_shader_mhz",
+    "all_fp64_ms", "every_station_ms", "first_plan_ms_per_plan", "two_plans_in_flight_ms_per_plan",
+    "host_goals_ms_per_plan", "cubic_ms_per_plan", "footprint_ms_per_plan", "materialised_hbm_frac", "blocked_egos",
+)
+
+
+def _compact_value(v, text=160):
+    """numbers to 6 significant digits, non-finite floats to null (strict JSON), long strings cut"""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.6g" % v)
+    if isinstance(v, str):
+        return v if len(v) <= text else v[:text - 1] + "~"
+    if isinstance(v, (list, tuple)):
+        return [_compact_value(x, text) for x in v[:8]]
+    if hasattr(v, "item"):                       # numpy scalar
+        return _compact_value(v.item(), text)
+    return None
+
+
+def _pick(d, keys, text=160):
+    if not isinstance(d, dict):
+        return None
+    return {k: _compact_value(d[k], text) for k in keys if k in d and not isinstance(d[k], dict)}
+
+
+def compact_record(full, max_bytes=COMPACT_MAX_BYTES):
+    """The one line the driver parses: the contract's fields + roofline + cpu_baseline (+ parity, per-rank times, flat scalars) of `full`."""
+    rec = {k: _compact_value(full.get(k)) for k in COMPACT_CONTRACT}
+    rec["config"] = _pick(full.get("config"), COMPACT_CONFIG, text=200) or {"workload": None}
+    roof = _pick(full.get("roofline"), COMPACT_ROOFLINE, text=96)
+    if roof is not None:
+        if isinstance(roof.get("kernel"), str) and "dominant kernel is " in full["roofline"]["kernel"]:
+            roof["kernel"] = full["roofline"]["kernel"].split("dominant kernel is ")[1].rstrip(")")
+        for k in ("traffic", ):
+            roof.setdefault(k, None)
+    rec["roofline"] = roof
+    rec["cpu_baseline"] = _pick(full.get("cpu_baseline"), COMPACT_CPU, text=200)
+    if isinstance(full.get("cpu_baseline_numpy"), dict):
+        rec["cpu_baseline_numpy"] = _pick(full["cpu_baseline_numpy"], ("value", "cores"))
+    rec["parity"] = _pick(full.get("parity"), COMPACT_PARITY)
+    prk = full.get("per_rank_ms_per_step")
+    if isinstance(prk, dict):
+        rec["per_rank_ms_per_step"] = _pick(prk, ("min", "max", "ranks"))
+    for k in COMPACT_SCALARS:
+        if full.get(k) is not None and not isinstance(full[k], (dict, list)):
+            rec[k] = _compact_value(full[k])
+    rec["full_record"] = os.path.basename(FULL_RECORD_PATH or "bench_full.json")
+    keys = [k for k in reversed(COMPACT_SCALARS) if k in rec]
+    line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
+    while len(line) > max_bytes and keys:
+        rec.pop(keys.pop(0))
+        line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
+    return rec, line
+
+
+def _strict(o):
+    """non-finite floats -> None all the way down, so the side file is strict JSON too"""
+    if isinstance(o, dict):
+        return {str(k): _strict(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_strict(v) for v in o]
+    if hasattr(o, "item") and not isinstance(o, (str, bytes)):
+        o = o.item()
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return None
+    return o
+
+
+def emit(full, stream=None):
+    """rank 0: full record -> bench_full.json (stderr names it), compact record -> the LAST stdout line"""
+    full = _strict(full)
+    _, line = compact_record(full)
+    written = []
+    targets = [FULL_RECORD_PATH or os.path.join(ROOT, "bench_full.json")]
+    if FULL_RECORD_PATH is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    for path in targets:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, allow_nan=False)
+                f.write("\n")
+            written.append(path)
+        except OSError:
+            pass
+    print("bench.py: full record (%d bytes as one line) -> %s" % (len(json.dumps(full)), ", ".join(written) or "nowhere writable"), file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    print(line, file=stream or sys.stdout, flush=True)
+    return line
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +181,8 @@ def parse_args(argv=None):
     ap.add_argument("--stations", type=int, default=50)
     ap.add_argument("--cpu-egos", type=int, default=0, help="egos in the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-record", default=None, help="where rank 0 writes the full record (default: bench_full.json beside this script, and gpurun_out/ "
+                                                        "when it exists); stdout's last line is the compact record either way")
     ap.add_argument("--no-secondary", action="store_true", help="skip the candidate-sharded and kmpc legs of the default run")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs (tools/profile_gpu.sh): nothing but the warm-up and the timed steady-state region touches the GPU, so that "
@@ -123,6 +241,8 @@ def self_launch(args, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    global FULL_RECORD_PATH
+    FULL_RECORD_PATH = os.path.abspath(args.full_record) if args.full_record else None
     # every rank, however it was launched (self-launch above, or the driver's own torchrun): dmabuf IPC before anything loads
     # HIP -- RCCL across processes fails with `hipIpcGetMemHandle: invalid argument` on this pool without it
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -1293,7 +1413,7 @@ def main_lattice(args):
                                              "profiled_kernels_us holds rocprofv3's own per-kernel averages from the committed trace") if mixed_ms else None,
                          "profiled_kernels_us": ({k["kernel"].split("(")[0].replace("void f1p::", "").replace("f1p::", ""): round(k["avg_us"], 2)
                                                   for k in pmc.get("all_kernels", []) if k.get("avg_us") and "lattice" in k.get("kernel", "")} if same_cfg else None),
-                         "hbm": hbm, "valu": valu})
+                         "algorithmic_bytes_per_launch": abytes, "hbm": hbm, "valu": valu})
         steady_state = None
         if steady and not cand_sharded:
             steady_state = {"ms_per_step": elapsed / args.steps * 1e3, "kernel_ms": kernel_ms, "value": value,
@@ -1374,8 +1494,10 @@ def main_lattice(args):
             "valu_instr_per_candidate": _g(valu, "valu_instr_per_candidate"), "valu_frac_of_issue_floor": _g(valu, "frac_of_issue_floor"),
             "traffic_over_algorithmic_bytes": None if traffic is None else traffic / abytes,
             "audit_mismatching_egos": _g(audit, "mismatching_egos"),
+            "candidate_sharded_ranks": _g(cs, "ranks"), "candidate_sharded_bit_identical": _g(cs, "bit_identical_to_unsharded_plan_on_every_rank"),
+            "exchange_selftest_ok": _g(selftest, "matches_np_argmin_on_every_rank"), "hsa_ipc_env_zero_on_every_rank": bool(env_ok),
             "kmpc_c4_streamed_ms": _g(kmpc_c4, "ms_per_plan"), "kmpc_c4_generated_ms": _g(kmpc_c4, "generated_in_kernel", "ms_per_plan"),
-            "kmpc_c4_roofline_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
+            "kmpc_c4_cache_stream_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
         })
         if variants:
             out.update({"host_goals_ms_per_plan": _g(variants, "host_goals", "ms_per_plan"), "host_goals_kernel_ms_filter3": _g(variants, "host_goals", "kernels_ms", "k_lattice_filter3"),
@@ -1397,7 +1519,7 @@ def main_lattice(args):
             leg_cpu_baseline_and_parity(args, out, poses, rl, cfg, img, res, origin, E, C, S, world, prev_in, bidx, steer, materialised)
         if rk.rccl_note:
             out["rccl_init"] = rk.rccl_note
-        print(json.dumps(out), flush=True)
+        emit(out)
     if rk.rccl_hung:                                     # a thread is still inside ncclCommInitRank: no orderly teardown through it
         rk.barrier()
         sys.stdout.flush(); sys.stderr.flush()
@@ -1475,7 +1597,7 @@ def main_pursuit(args):
                                    "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_pure_pursuit_batch"}
             out["parity"] = {"egos_checked": int(n_cpu), "near_idx_mismatches": int((near != want["near_idx"]).sum()),
                              "max_abs_steer_diff": float(np.abs(steer - want["steer"]).max())}
-        print(json.dumps(out), flush=True)
+        emit(out)
     rk.close()
     ctx.close()
 
@@ -1555,7 +1677,7 @@ def main_stmpc(args):
             out["cpu_baseline"] = {"value": float(n_cpu) * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
                                    "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_stmpc_shoot_batch"}
             out["parity"] = {"egos_checked": int(n_cpu), "best_idx_mismatches": int((bi != want["best_idx"]).sum())}
-        print(json.dumps(out), flush=True)
+        emit(out)
     rk.close()
     ctx.close()
 
@@ -1648,7 +1770,7 @@ def main_kmpc(args):
             out["cpu_baseline"] = {"value": n_cpu * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
                                    "sample": f"first {n_cpu} egos, oracle/f1p_oracle.c, {nthr} threads, {cpu_s:.2f} s"}
             out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": int((want["best_idx"] != got).sum())}
-        print(json.dumps(out), flush=True)
+        emit(out)
     rk.close()
     ctx.close()
 

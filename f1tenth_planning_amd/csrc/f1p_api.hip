@@ -315,6 +315,7 @@ void f1p_destroy(f1p_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->h_step) (void)hipHostFree(ctx->h_step);
+    if (ctx->h_kmpc_cfg) (void)hipHostFree(ctx->h_kmpc_cfg);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (auto& ev : ctx->ev_chunk) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->ev_prof) if (ev) (void)hipEventDestroy(ev);

@@ -9,6 +9,7 @@
 #include "../../include/f1p.h"
 #include "f1p_device.h"
 
+#define F1P_KMPC_CFG_SLOTS 8
 struct f1p_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -60,9 +61,10 @@ struct f1p_ctx {
     bool st_q_dirty = true;
 
     // in-kernel control generation of the shooting MPC (f1p_kmpc_plan_*): the warm start lives here, on the device
-    f1p_kmpc_cfg* d_kmpc_cfg = nullptr; // device copy of the last shooting configuration (the kernels' fp64 tails read it with scalar loads)
-    f1p_kmpc_cfg h_kmpc_cfg;            // ... and its host shadow (compared per launch, source of the copy)
-    bool kmpc_cfg_valid = false;
+    f1p_kmpc_cfg* d_kmpc_cfg = nullptr; // device table of the shooting configurations seen (the kernels' fp64 tails read one slot with scalar loads)
+    f1p_kmpc_cfg* h_kmpc_cfg = nullptr; // ... its pinned host shadow (compared per launch, the stable source of each slot's one copy)
+    f1p_kmpc_cfg* d_kmpc_cfg_cur = nullptr; // the slot of the configuration of the launch being issued
+    int kmpc_cfg_used = 0;
     float* d_kmpc_warm = nullptr;      // [E][T][2] f32: previous plan's applied winner shifted by one step
     int kmpc_warm_E = 0, kmpc_warm_T = 0;
     bool kmpc_warm_valid = false;

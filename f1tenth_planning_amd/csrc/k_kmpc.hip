@@ -1127,18 +1127,26 @@ __global__ void k_argmin_reduce(const uint64_t* __restrict__ recs, int N, int E,
 
 static KmpcF32 make_kf(const f1p_kmpc_cfg* cfg);
 
-// the device copy of the configuration the shooting kernels' fp64 tails read (stream-ordered: a changed struct is copied behind the launches
-// that still read the old one)
+// the device copy of the configuration the shooting kernels' fp64 tails read.  A small write-once table (round 6): every distinct
+// configuration gets its own device slot and its own PINNED host shadow, neither is overwritten while a launch that reads it may be in
+// flight -- two planners alternating configurations on one context hit their slots without any copy; a ninth distinct configuration
+// drains the stream and starts the table over.  (The struct has no padding: int32 x 2 then doubles, tests/test_abi.py checks the layout.)
 static int ensure_kmpc_cfg(f1p_ctx* ctx, const f1p_kmpc_cfg* cfg) {
     if (!ctx->d_kmpc_cfg) {
-        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_cfg, sizeof(f1p_kmpc_cfg)));
-        ctx->kmpc_cfg_valid = false;
+        F1P_HIP(ctx, hipMalloc((void**)&ctx->d_kmpc_cfg, sizeof(f1p_kmpc_cfg) * F1P_KMPC_CFG_SLOTS));
+        F1P_HIP(ctx, hipHostMalloc((void**)&ctx->h_kmpc_cfg, sizeof(f1p_kmpc_cfg) * F1P_KMPC_CFG_SLOTS, hipHostMallocDefault));
+        ctx->kmpc_cfg_used = 0;
     }
-    if (!ctx->kmpc_cfg_valid || __builtin_memcmp(&ctx->h_kmpc_cfg, cfg, sizeof(f1p_kmpc_cfg)) != 0) {
-        ctx->h_kmpc_cfg = *cfg;                                   // (the copy's source must outlive the call: the context's own shadow)
-        F1P_HIP(ctx, hipMemcpyAsync(ctx->d_kmpc_cfg, &ctx->h_kmpc_cfg, sizeof(f1p_kmpc_cfg), hipMemcpyHostToDevice, ctx->stream));
-        ctx->kmpc_cfg_valid = true;
+    for (int i = 0; i < ctx->kmpc_cfg_used; ++i)
+        if (__builtin_memcmp(&ctx->h_kmpc_cfg[i], cfg, sizeof(f1p_kmpc_cfg)) == 0) { ctx->d_kmpc_cfg_cur = ctx->d_kmpc_cfg + i; return F1P_OK; }
+    if (ctx->kmpc_cfg_used == F1P_KMPC_CFG_SLOTS) {
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));          // nothing in flight reads the table any more
+        ctx->kmpc_cfg_used = 0;
     }
+    const int i = ctx->kmpc_cfg_used++;
+    ctx->h_kmpc_cfg[i] = *cfg;
+    F1P_HIP(ctx, hipMemcpyAsync(ctx->d_kmpc_cfg + i, &ctx->h_kmpc_cfg[i], sizeof(f1p_kmpc_cfg), hipMemcpyHostToDevice, ctx->stream));
+    ctx->d_kmpc_cfg_cur = ctx->d_kmpc_cfg + i;
     return F1P_OK;
 }
 
@@ -1153,7 +1161,7 @@ int launch_kmpc_shoot(f1p_ctx* ctx, const double* d_x0, const double* d_ref, con
                            sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
         if (const int rc = ensure_kmpc_cfg(ctx, cfg)) return rc;
         hipLaunchKernelGGL(k_kmpc_shoot_mixed, dim3(E), dim3(256), (lds + 15) & ~(size_t)15, ctx->stream, d_x0, d_ref, d_controls, E, *cfg, kf,
-                           d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref, ctx->d_kmpc_cfg);
+                           d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_cost32, ctx->d_dbg_nref, ctx->d_kmpc_cfg_cur);
         return check_hip(ctx, hipGetLastError(), "k_kmpc_shoot_mixed launch");
     }
     const size_t lds = sizeof(double) * (4 * T1 + 4) + sizeof(int) * 4;
@@ -1244,7 +1252,7 @@ int launch_kmpc_plan_gen(f1p_ctx* ctx, const double* d_x0, const double* d_ref, 
     if (lds > (size_t)ctx->prop.sharedMemPerBlock) return set_error(ctx, F1P_EINVAL, "horizon / n_rollouts need more LDS than a workgroup has: use fewer rollouts per plan");
     if (const int rc = ensure_kmpc_cfg(ctx, cfg)) return rc;
     hipLaunchKernelGGL(k_kmpc_plan_gen, dim3((unsigned)((size_t)E * ga.G)), dim3(block), lds, ctx->stream, d_x0, d_ref, E, *cfg, make_kf(cfg), ga,
-                       d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_nref, ctx->d_kmpc_cfg);
+                       d_steer, d_speed, d_best_idx, d_best_cost, d_best_seq, ctx->d_dbg_nref, ctx->d_kmpc_cfg_cur);
     return check_hip(ctx, hipGetLastError(), "k_kmpc_plan_gen launch");
 }
 

@@ -23,6 +23,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _last_json_line(stdout):
+    """what the driver parses: the LAST stdout line that is a JSON object -- strict JSON, under bench.COMPACT_MAX_BYTES"""
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines and len(lines[-1]) <= bench.COMPACT_MAX_BYTES, len(lines[-1]) if lines else "no JSON line"
+
+    def no_constants(tok):
+        raise ValueError("non-strict JSON token " + tok)
+    return json.loads(lines[-1], parse_constant=no_constants)
+
+
 def _scene(ctx):
     rl = synth.make_raceline(seed=0)
     img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
@@ -183,16 +195,19 @@ def test_closed_loop_reaches_the_multi_gpu_replicas():
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_real_rccl_ranks(world):
+def test_real_rccl_ranks(world, tmp_path):
     if _abi.load_library().f1p_device_count() < world:
         pytest.skip(f"needs {world} GPUs")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for shard in ("candidates", "egos"):
+        full = os.path.join(tmp_path, f"full_{shard}.json")
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shard", shard, "--steps", "5",
-                            "--warmup", "2", "--egos", "512", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline"],
+                            "--warmup", "2", "--egos", "512", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline", "--full-record", full],
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert p.returncode == 0, p.stdout[-3000:]
-        line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        compact = _last_json_line(p.stdout)
+        assert compact["n_gpus"] == world and compact["rccl_ranks"] == world and compact["per_rank_ms_per_step"]["ranks"] == world
+        line = json.load(open(full))
         assert line["n_gpus"] == world
         cs = line["candidate_sharded"]
         assert cs["rccl_ranks"] == world and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True
@@ -200,7 +215,7 @@ def test_real_rccl_ranks(world):
 
 
 @pytest.mark.parametrize("workload", ["lattice", "kmpc"])
-def test_two_ranks_share_one_gpu_control_flow(workload):
+def test_two_ranks_share_one_gpu_control_flow(workload, tmp_path):
     """the N-rank control flow of bench.py (launcher -> one process per rank -> gloo barrier / max over ranks -> ONE JSON line from
     rank 0 with n_gpus = N and the whole-job value) on a 1-GPU box: F1P_BENCH_OVERSUBSCRIBE lets the ranks share device 0 (the
     RCCL legs are skipped -- RCCL refuses two ranks on one device; test_real_rccl_ranks covers them where N devices exist)"""
@@ -211,13 +226,18 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
     env["F1P_BENCH_OVERSUBSCRIBE"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
-                        "--workload", workload, "--latency-iters", "0", "--no-cpu-baseline"],
+                        "--workload", workload, "--latency-iters", "0", "--no-cpu-baseline", "--full-record", os.path.join(tmp_path, "full.json")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0
+    compact = _last_json_line(p.stdout)
+    assert compact["n_gpus"] == 2 and compact["steps"] == 20 and compact["value"] > 0 and compact["per_rank_ms_per_step"]["ranks"] == 2
+    line = json.load(open(os.path.join(tmp_path, "full.json")))      # the nested legs live in the full record
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] == pytest.approx(compact["value"], rel=1e-5)
+    if workload == "lattice":
+        assert compact["candidate_sharded_ranks"] == 2 and compact["candidate_sharded_bit_identical"] is True and compact["exchange_selftest_ok"] is True
+        assert compact["hsa_ipc_env_zero_on_every_rank"] is True and "rccl_ranks" not in compact
     assert line["multi_process_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "zero_on_every_rank": True}
     if workload == "lattice":
         assert line["rccl_ranks"] is None and line["exchange_us_p50"] > 0     # no RCCL communicator exists under the test hook: null, not the world size
@@ -231,7 +251,7 @@ def test_two_ranks_share_one_gpu_control_flow(workload):
         assert line["kmpc_c4"]["generated_in_kernel"]["rollout_steps_per_s"] > 0
 
 
-def test_candidate_sharded_mode_with_two_ranks_on_one_gpu():
+def test_candidate_sharded_mode_with_two_ranks_on_one_gpu(tmp_path):
     """bench.py --shard candidates with two ranks sharing device 0 (host stand-in for the RCCL collective): the strong-scaling line"""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -239,10 +259,12 @@ def test_candidate_sharded_mode_with_two_ranks_on_one_gpu():
     env["F1P_BENCH_OVERSUBSCRIBE"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "candidates", "--steps", "10",
-                        "--warmup", "2", "--egos", "600", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline"],
+                        "--warmup", "2", "--egos", "600", "--cands", "512", "--latency-iters", "0", "--no-cpu-baseline",
+                        "--full-record", os.path.join(tmp_path, "full.json")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert _last_json_line(p.stdout)["scaling"] == "strong"
+    line = json.load(open(os.path.join(tmp_path, "full.json")))
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     cs = line["candidate_sharded"]
     assert cs["rccl_ranks"] is None and cs["ranks"] == 2 and cs["bit_identical_to_unsharded_plan_on_every_rank"] is True

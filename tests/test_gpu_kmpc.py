@@ -216,3 +216,67 @@ def test_mixed_precision_filter_is_exact_and_within_margin(ctx, orc):
     same = np.zeros((4, T, 2, R), np.float32)
     out = ctx.kmpc_shoot(states[:4], ref[:4], same, cfg)
     assert (out["best_idx"] == 0).all()
+
+
+def test_config4_full_single_gpu_size_vs_oracle(ctx, orc):
+    """BASELINE configs[4] at its full single-GPU size -- 1024 egos x 512 rollouts x 30 steps (kinematic_mpc.py:208-243, :324-334) -- through both
+    entry points against the oracle: streamed controls (126 MB in HBM) on ALL 1024 egos, and the generated-controls plan (Philox in the
+    kernel, device warm start) against orc.kmpc_plan_batch.  (VERDICT r5 #3 / missing #5: this size used to live in bench.py only.)"""
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(40)
+    E, T, R = 1024, 30, 512
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1] + rng.normal(0, 0.1, E), cl[k, 2] + rng.normal(0, 0.1, E), rng.uniform(0.5, 5.5, E), cl[k, 3] + rng.normal(0, 0.1, E)])
+    ref = ctx.kmpc_ref(states, T)
+    cfg = _abi.kmpc_cfg(horizon=T, n_rollouts=R)
+    ctrl = synth.make_controls(E, T, R, seed=41)
+    got = ctx.kmpc_shoot(states, ref, ctrl, cfg)
+    want = orc.kmpc_shoot_batch(states, ref, ctrl, cfg, nthreads=orc.max_threads())
+    np.testing.assert_array_equal(got["best_idx"], want["best_idx"])
+    np.testing.assert_allclose(got["best_cost"], want["best_cost"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(got["steer"], want["steer"]); np.testing.assert_array_equal(got["speed"], want["speed"])
+    np.testing.assert_array_equal(got["best_seq"], want["best_seq"])
+    assert len(np.unique(got["best_idx"])) > 200
+    # generated controls, two plans of a chain (the second one starts from the first one's winners)
+    ctx.kmpc_warm_reset()
+    warm = None
+    for call in range(2):
+        smp = _abi.kmpc_sampler(seed=4242, call=call, use_warm=True, sigma_accel=1.5, sigma_steer=0.15)
+        gotp = ctx.kmpc_plan(states, cfg, smp)
+        wantp = orc.kmpc_plan_batch(states, ref, cfg, 4242, call, 1.5, 0.15, warm=warm, nthreads=orc.max_threads())
+        np.testing.assert_array_equal(gotp["best_idx"], wantp["best_idx"])
+        for kk in ("steer", "speed", "best_cost", "best_seq"):
+            np.testing.assert_allclose(gotp[kk], wantp[kk], rtol=1e-12, atol=1e-12, err_msg=kk)
+        warm = wantp["warm"]
+        np.testing.assert_array_equal(ctx.kmpc_warm_get(E, T), warm)
+
+
+def test_alternating_configurations_on_one_context(ctx, orc):
+    """two planners with different weights / bounds sharing one context, launches queued back to back without a sync in between (ADVICE r5:
+    the kernels' fp64 tails read the configuration from a device copy -- each launch must read ITS configuration), then more distinct
+    configurations than the context's table holds (F1P_KMPC_CFG_SLOTS = 8: the table is drained and restarted)."""
+    cl = synth.make_centerline(seed=2)
+    ctx.set_waypoints(cl, cols=(1, 2, 5, 3))
+    rng = np.random.default_rng(50)
+    E, T, R = 64, 30, 256
+    k = rng.integers(0, len(cl) - 1, E)
+    states = np.column_stack([cl[k, 1], cl[k, 2], rng.uniform(0.5, 5.5, E), cl[k, 3]])
+    ref = ctx.kmpc_ref(states, T)
+    ctrl = synth.make_controls(E, T, R, seed=51, sigma_a=2.5, sigma_d=0.3)
+    cfgs = [_abi.kmpc_cfg(horizon=T, n_rollouts=R),
+            _abi.kmpc_cfg(horizon=T, n_rollouts=R, q=(1.0, 1.0, 40.0, 0.5), qf=(50.0, 50.0, 1.0, 1.0), r=(5.0, 1.0), rd=(0.5, 300.0), max_steer=0.2, max_accel=1.5)]
+    cfgs += [_abi.kmpc_cfg(horizon=T, n_rollouts=R, q=(13.5, 13.5, 5.5 + j, 13.0), max_speed=3.0 + 0.25 * j) for j in range(10)]
+    want = [orc.kmpc_shoot_batch(states, ref, ctrl, c, nthreads=8) for c in cfgs]
+    assert (want[0]["best_idx"] != want[1]["best_idx"]).mean() > 0.5          # the two configurations do pick different rollouts
+    d_x0, d_ref, d_ctrl = ctx.to_device(states), ctx.to_device(ref), ctx.to_device(ctrl)
+    order = [0, 1, 0, 1, 1, 0] + list(range(2, 12)) + [0, 5, 1, 11]
+    outs = []
+    for j in order:                                                            # all queued on the context's stream, no sync until the downloads
+        o = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E))
+        ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfgs[j], *o)
+        outs.append(o)
+    for j, (d_steer, d_speed, d_bi, d_bc) in zip(order, outs):
+        np.testing.assert_array_equal(d_bi.download(np.int32, (E,)), want[j]["best_idx"], err_msg=f"cfg {j}")
+        np.testing.assert_array_equal(d_steer.download(np.float64, (E,)), want[j]["steer"], err_msg=f"cfg {j}")
+        np.testing.assert_allclose(d_bc.download(np.float64, (E,)), want[j]["best_cost"], rtol=1e-12, atol=1e-9, err_msg=f"cfg {j}")

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX from a tree's root: bash tools/pmc_quick.sh <tag> [bench args]  -- kernel trace + ONE PMC pass of the timed region (A/B of two trees)
 set -u
-TAG=${1:-q}; shift
-OUT=${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out
+TAG=${1:-q}; [ $# -gt 0 ] && shift
+OUT=$(pwd)/gpurun_out
 ARGS="--steps 60 --warmup 10 --no-cpu-baseline --no-secondary --latency-iters 0 --only-timed $*"
 export TMPDIR=/tmp
 mkdir -p $OUT
