@@ -149,8 +149,11 @@ def _strict(o):
     return o
 
 
-def emit(full, stream=None):
+def emit(full, stream=None, rk=None):
     """rank 0: full record -> bench_full.json (stderr names it), compact record -> the LAST stdout line"""
+    if rk is not None and "per_rank_ms_per_step" not in full and getattr(rk, "last_per_rank_s", None) and full.get("steps"):
+        prs = list(rk.last_per_rank_s)                       # every workload's line carries every rank's own time (a straggler is visible)
+        full["per_rank_ms_per_step"] = {"min": min(prs) / full["steps"] * 1e3, "max": max(prs) / full["steps"] * 1e3, "ranks": len(prs)}
     full = _strict(full)
     _, line = compact_record(full)
     written = []
@@ -1519,7 +1522,7 @@ def main_lattice(args):
             leg_cpu_baseline_and_parity(args, out, poses, rl, cfg, img, res, origin, E, C, S, world, prev_in, bidx, steer, materialised)
         if rk.rccl_note:
             out["rccl_init"] = rk.rccl_note
-        emit(out)
+        emit(out, rk=rk)
     if rk.rccl_hung:                                     # a thread is still inside ncclCommInitRank: no orderly teardown through it
         rk.barrier()
         sys.stdout.flush(); sys.stderr.flush()
@@ -1597,7 +1600,7 @@ def main_pursuit(args):
                                    "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_pure_pursuit_batch"}
             out["parity"] = {"egos_checked": int(n_cpu), "near_idx_mismatches": int((near != want["near_idx"]).sum()),
                              "max_abs_steer_diff": float(np.abs(steer - want["steer"]).max())}
-        emit(out)
+        emit(out, rk=rk)
     rk.close()
     ctx.close()
 
@@ -1677,7 +1680,7 @@ def main_stmpc(args):
             out["cpu_baseline"] = {"value": float(n_cpu) * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
                                    "sample": f"{n_cpu} egos, oracle/f1p_oracle.c orc_stmpc_shoot_batch"}
             out["parity"] = {"egos_checked": int(n_cpu), "best_idx_mismatches": int((bi != want["best_idx"]).sum())}
-        emit(out)
+        emit(out, rk=rk)
     rk.close()
     ctx.close()
 
@@ -1770,7 +1773,7 @@ def main_kmpc(args):
             out["cpu_baseline"] = {"value": n_cpu * R * T / cpu_s, "unit": "rollout-steps/s", "cores": nthr, "kind": "port",
                                    "sample": f"first {n_cpu} egos, oracle/f1p_oracle.c, {nthr} threads, {cpu_s:.2f} s"}
             out["parity"] = {"egos_checked": n_cpu, "best_idx_mismatches": int((want["best_idx"] != got).sum())}
-        emit(out)
+        emit(out, rk=rk)
     rk.close()
     ctx.close()
 

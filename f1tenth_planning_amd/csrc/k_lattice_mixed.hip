@@ -101,6 +101,9 @@ namespace f1p {
 #else
 #define F1P_F32_CONTRACT
 #endif
+#ifndef F1P_F3_FIT_PAIRS
+#define F1P_F3_FIT_PAIRS 1           // round 6: the f32 fit's quadrature as eight symmetric node pairs (3 transcendentals per pair) and a cubic model in d (8 moments)
+#endif
 #ifndef F1P_F3_FAST_ATAN
 #define F1P_F3_FAST_ATAN 1           // atan2_fast_f32 (6 u absolute, ~17 instructions) for the chord direction of the f32 fit instead of atan2f (~45): with the
                                      // contraction 37.55 -> 36.6 us, plan 73.95 -> 72.85 us (0: atan2f, A/B builds)
@@ -152,6 +155,24 @@ __constant__ float c_gl16_wuf[16][6] = {
     {4.757925584e-02f, -2.981823145e-03f, 1.868728107e-04f, -1.171144152e-05f, 7.339637150e-07f, -4.599798703e-08f},
     {3.112676197e-02f, -8.386952385e-04f, 2.259822926e-05f, -6.088981340e-07f, 1.640645970e-08f, -4.420639591e-10f},
     {1.357622971e-02f, -7.156638159e-05f, 3.772584204e-07f, -1.988697942e-09f, 1.048331671e-11f, -5.526225325e-14f}};
+
+// Round 6 -- the same rule as eight SYMMETRIC pairs (F1P_F3_FIT_PAIRS).  The phase of the candidate's tangent is a quadratic ph(tau) = a tau^2 + b tau + c and
+// the rule's nodes come in pairs (tau, 1 - tau) that share their weight and their u = tau^2 - tau, so with m = (ph(tau) + ph(1 - tau)) / 2 = a p + (b / 2 + c),
+// p = (tau^2 + (1 - tau)^2) / 2, and h = (ph(tau) - ph(1 - tau)) / 2 = (a + b) q, q = tau - 1/2:
+//     cos ph + cos ph' = 2 cos m cos h,   sin ph + sin ph' = 2 sin m cos h
+// -- three transcendentals and two multiplications per pair instead of four transcendentals, four fused multiply-adds and two additions.  The factor 2
+// lives in the weights (c_gl8_w2 = 2 w u^k, k = 0 .. 3: the model of the residual is a cubic).
+__constant__ float c_gl8_p[8] = {4.947285525e-01f, 4.730554936e-01f, 4.373293446e-01f, 3.926589550e-01f, 3.454427633e-01f, 3.024448422e-01f, 2.698251400e-01f, 2.522568443e-01f};
+__constant__ float c_gl8_q[8] = {-4.947004675e-01f, -4.722875115e-01f, -4.328156012e-01f, -3.777022042e-01f, -3.089381222e-01f, -2.290083888e-01f, -1.408017754e-01f, -4.750625492e-02f};
+__constant__ float c_gl8_w2[8][4] = {
+    {2.715245941e-02f, -1.431327632e-04f, 7.545168408e-07f, -3.977395884e-09f},
+    {6.225352394e-02f, -1.677390477e-03f, 4.519645852e-05f, -1.217796268e-06f},
+    {9.515851168e-02f, -5.963646291e-03f, 3.737456214e-04f, -2.342288303e-05f},
+    {1.246289713e-01f, -1.337780401e-02f, 1.435987461e-03f, -1.541403947e-04f},
+    {1.495959888e-01f, -2.312114265e-02f, 3.573539915e-03f, -5.523164544e-04f},
+    {1.691565194e-01f, -3.341774289e-02f, 6.601847471e-03f, -1.304229019e-03f},
+    {1.826034150e-01f, -4.203071550e-02f, 9.674414058e-03f, -2.226806902e-03f},
+    {1.894506105e-01f, -4.693509209e-02f, 1.162784783e-02f, -2.880719716e-03f}};
 
 struct RefEntry {                 // one fp64 re-evaluation: written by k_lattice_filter3, completed by k_lattice_refine
     int32_t e, c;
@@ -237,6 +258,43 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     // (this translation unit is compiled without the SLP vectoriser: its v_pk_* cost more in the moves that assemble their operand pairs than
     // they save -- filter3 33.4 -> 32.3 us.  The accumulation below written with explicit two-element vectors, 12 v_pk_fma_f32 per two node
     // pairs instead of 24 v_fma_f32, measured 32.55 us: scalar it stays.)
+#if F1P_F3_FIT_PAIRS
+    // Round 6: the residual g(A0 + d) and the chord integral c0(A0 + d) as CUBICS in d, from eight moments.  The published guess A0 is within 0.038 rad of
+    // the root for every goal (2e5 random goals of each test family and the bench scenes: max |d| = 0.0376, min |dg / dA| = 0.051: tools/fit_guess_error.py, profiles/r06_fit_guess_error.txt), and for |d| <= 0.05
+    // the cubic's remainder is |d^4 g / dA^4| d^4 / 24 <= (1/4)^4 x 6.25e-6 / 24 = 1.0e-9 (|u| <= 1/4): far inside e_g below.  A candidate beyond 0.05 (none
+    // seen) is not trusted and goes to fp64.  Newton from the linear root, two steps: with |dg / dA| >= 0.02 (c43; measured >= 0.05) and a second derivative
+    // of at most 0.063 the error recursion e_next <= 1.85 e^2 takes the linear root's 3.9e-3 to 2.8e-5 and then 1.5e-9.
+    float mc[4], ms[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
+    const float bc = __builtin_fmaf(0.5f, br, cr), ab = ar + br;
+#pragma unroll F1P_MIX_FIT_UNROLL
+    for (int j = 0; j < 8; ++j) {
+        const float m = __builtin_fmaf(ar, c_gl8_p[j], bc), h = ab * c_gl8_q[j];
+        const float ch = __builtin_amdgcn_cosf(h);
+        const float cs = __builtin_amdgcn_cosf(m) * ch, sn = __builtin_amdgcn_sinf(m) * ch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mc[k] = __builtin_fmaf(c_gl8_w2[j][k], cs, mc[k]);
+            ms[k] = __builtin_fmaf(c_gl8_w2[j][k], sn, ms[k]);
+        }
+    }
+    const float g0 = ms[0], g1 = mc[1], g2 = -0.5f * ms[2], g3 = mc[3] * (-1.0f / 6.0f);
+    const bool c43 = fabsf(g1) > 0.02f;
+    float d = -g0 * __builtin_amdgcn_rcpf(g1);                                  // 1-ulp reciprocals: the filter's error budget is the margin
+    float dv_last = g1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float pv = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, g3, g2), g1), g0);
+        const float dv = __builtin_fmaf(d, __builtin_fmaf(d, 3.0f * g3, 2.0f * g2), g1);
+        d -= pv * __builtin_amdgcn_rcpf(dv);
+        dv_last = dv;
+    }
+    const bool c44 = fabsf(d) <= 0.05f;
+    const float A = A0 + d;
+    const float q3 = ms[3] * (1.0f / 6.0f), q2 = -0.5f * mc[2], q1 = -ms[1];
+    const float c0 = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, q3, q2), q1), mc[0]);
+#else
     float mc[6], ms[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { mc[k] = 0.f; ms[k] = 0.f; }
@@ -267,6 +325,7 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     const float A = A0 + d;
     const float q5 = ms[5] * (-1.0f / 120.0f), q4 = mc[4] * (1.0f / 24.0f), q3 = ms[3] * (1.0f / 6.0f), q2 = -0.5f * mc[2], q1 = -ms[1];
     const float c0 = __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, __builtin_fmaf(d, q5, q4), q3), q2), q1), mc[0]);
+#endif
     const bool c45 = c0 > 0.05f;                                               // L = r / c0 ill-conditioned or negative: fp64 decides
     const float L = r * __builtin_amdgcn_rcpf(c0), iL = c0 * __builtin_amdgcn_rcpf(r);
     f.L = L; f.k0 = (delta - A) * iL; f.dk = 2.0f * A * (iL * iL);

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""How far is the published initial guess A0 of the G1 clothoid fit from the root?  (CPU, numpy; seconds.)
+
+k_lattice_mixed.hip::g1_fit_f32 models the residual g(A0 + d) as a CUBIC in d (round 6) and takes two Newton steps from the linear root: both rest on
+|d| <= 0.05 and |dg/dA| >= 0.02.  This script measures |d| = |A - A0| and |dg/dA (A0)| over the goal families the tests and the bench use -- the bench
+scene's device-sampled goals (via the oracle's goal sampler), the random goal boxes of tests/test_gpu_lattice.py, tests/test_gpu_lattice_mixed.py and
+tests/test_gpu_lattice_oracle_shapes.py, and a tight / sharp configuration -- with a 64-node Gauss-Legendre rule and ten Newton steps in fp64.
+Output of the run the comment in g1_fit_f32 quotes: profiles/r06_fit_guess_error.txt.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def analyse(x, y, th, name):
+    phi = np.arctan2(y, x); phi0 = -phi; phi1 = th - phi; phi1 = phi1 - 2 * np.pi * np.rint(phi1 / (2 * np.pi))
+    delta = phi1 - phi0; X = phi0 / np.pi; Y = phi1 / np.pi; xy = X * Y; X2 = X * X; Y2 = Y * Y
+    A0 = (phi0 + phi1) * (2.989696028701907 + xy * (0.716228953608281 + xy * -0.458969738821509) + (-0.502821153340377 + xy * 0.261062141752652) * (X2 + Y2)
+                          + -0.045854475238709 * (X2 * X2 + Y2 * Y2))
+    exc = np.abs(A0) + np.abs(delta - A0)
+    xs, ws = np.polynomial.legendre.leggauss(64); t = (xs + 1) / 2; w = ws / 2; u = t * t - t
+    g1 = (w * u * np.cos(A0[:, None] * t ** 2 + (delta - A0)[:, None] * t + phi0[:, None])).sum(1)
+    A = A0.copy()
+    for _ in range(10):
+        ph = A[:, None] * t ** 2 + (delta - A)[:, None] * t + phi0[:, None]
+        A = A - (w * np.sin(ph)).sum(1) / (w * u * np.cos(ph)).sum(1)
+    d = np.abs(A - A0)
+    ok = (exc <= 20) & (np.abs(phi0) < np.pi - 2e-3) & (np.abs(phi1) < np.pi - 2e-3)          # what the f32 fit accepts at all (c41, c42)
+    print(f"{name:<44} n {len(x):>7}  accepted {ok.mean():.4f}  exc p50/p99 {np.percentile(exc[ok], 50):.2f}/{np.percentile(exc[ok], 99):.2f}  "
+          f"max |d| {d[ok].max():.4f}  share |d| > 0.05: {(d[ok] > 0.05).mean():.1e}  min |dg/dA| {np.abs(g1[ok]).min():.4f}")
+
+
+def main():
+    from f1tenth_planning_amd import synth
+    from oracle import oracle
+    oracle.build()
+    rl = synth.make_raceline(seed=0)
+    cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50)
+    for name, poses in (("bench scene, centred (300 egos)", synth.make_egos(rl, 300, seed=1)), ("bench scene, wall-hugging", synth.make_egos(rl, 300, seed=1, pos_sigma=0.9)),
+                        ("bench scene, yaw sigma 0.6", synth.make_egos(rl, 300, seed=3, pos_sigma=0.5, yaw_sigma=0.6))):
+        G = []
+        for p in poses:
+            g, ok = oracle.lattice_goals(p, rl, cfg)
+            G.append(g[ok])
+        G = np.concatenate(G)
+        analyse(G[:, 0], G[:, 1], G[:, 2], name)
+    rng = np.random.default_rng(0)
+    N = 200000
+    analyse(rng.uniform(0.3, 4, N), rng.uniform(-2, 2, N), rng.uniform(-1.3, 1.3, N), "x [0.3, 4] y [-2, 2] th [-1.3, 1.3]")
+    analyse(rng.uniform(-1, 3, N), rng.uniform(-1.5, 1.5, N), rng.uniform(-np.pi, np.pi, N), "x [-1, 3] y [-1.5, 1.5] th [-pi, pi]")
+    analyse(rng.uniform(0.4, 3.2, N), rng.uniform(-1.2, 1.2, N), rng.uniform(-0.7, 0.7, N), "x [0.4, 3.2] y [-1.2, 1.2] th [-0.7, 0.7]")
+    analyse(rng.uniform(-160, 160, N), rng.uniform(-80, 80, N), rng.uniform(-np.pi, np.pi, N), "long clothoids (x 40)")
+    analyse(rng.uniform(0.05, 0.3, N), rng.uniform(-1.5, 1.5, N), rng.uniform(-2.5, 2.5, N), "sharp: x [0.05, 0.3] y [-1.5, 1.5] th [-2.5, 2.5]")
+
+
+if __name__ == "__main__":
+    main()
