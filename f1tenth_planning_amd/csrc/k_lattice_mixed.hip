@@ -104,6 +104,9 @@ namespace f1p {
 #ifndef F1P_F3_FIT_PAIRS
 #define F1P_F3_FIT_PAIRS 1           // round 6: the f32 fit's quadrature as eight symmetric node pairs (3 transcendentals per pair) and a cubic model in d (8 moments)
 #endif
+#ifndef F1P_F3_RAW_SQRT
+#define F1P_F3_RAW_SQRT 1             // round 6: v_sqrt_f32 for the chord length of the f32 fit and the similarity bound
+#endif
 #ifndef F1P_F3_FAST_ATAN
 #define F1P_F3_FAST_ATAN 1           // atan2_fast_f32 (6 u absolute, ~17 instructions) for the chord direction of the f32 fit instead of atan2f (~45): with the
                                      // contraction 37.55 -> 36.6 us, plan 73.95 -> 72.85 us (0: atan2f, A/B builds)
@@ -239,7 +242,11 @@ __device__ __forceinline__ Fit32 g1_fit_f32(float x1, float y1, float th1) {
     // result on its path (~120 v_mov_b32 and ~25 exec-mask branches per candidate, a tenth of the candidate kernel's issue time).  A
     // candidate that fails a test computes garbage behind it (NaN / inf are harmless: nothing traps) and reports ok = false.
     Fit32 f;
+#if F1P_F3_RAW_SQRT
+    const float r = __builtin_amdgcn_sqrtf(x1 * x1 + y1 * y1);               // v_sqrt_f32 itself (1 ulp; the library form's scaling + correction: ~12 instructions, 3 selects on VCC) -- inside eLrel's 4 u
+#else
     const float r = __builtin_sqrtf(x1 * x1 + y1 * y1);
+#endif
     const bool c40 = (r > 1e-6f) & (r < 1e6f);
     const float phi = F1P_F3_FAST_ATAN ? atan2_fast_f32(y1, x1) : atan2f(y1, x1);
     const float PI_F = 3.14159265358979f;
@@ -752,7 +759,11 @@ __device__ __forceinline__ Brk32 bracket_f2(const Fit32& f, const F1P_LDS(EgoPar
         float e4 = 0.0f;
         if (prev) {
             const float TH = fabsf(k0) * L + 0.5f * fabsf(dk) * L * L;
+#if F1P_F3_RAW_SQRT
+            const float rs = __builtin_amdgcn_sqrtf(sim) * 1.000001f;          // (only the bound uses it)
+#else
             const float rs = __builtin_sqrtf(sim);
+#endif
             const float e_th = L * f.ek0 + 0.5f * L * L * f.edk + 2.0f * TH * f.eLrel + U * (4.0f * TH + rs);
             e4 = fabsf(ep->w_sim) * (2.0f * e_th * ep->sqrt_S * rs + fS * e_th * e_th + 2.0f * fS * U * sim);
         }
@@ -1659,6 +1670,10 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
 #endif
         if (DBG && mx.dbg_state && (st & 0x7f) != F1P_ST_PENDING && (st & 0x7f) != F1P_ST_PENDING2) mx.dbg_state[(size_t)e * C + c] = dbg_code >= 0 ? dbg_code : ((st & 0x7f) == F1P_ST_UNSURE && lo == -INF ? 5 : (st & 0x7f));
     }
+#if defined(F1P_F3_ABLATE) && F1P_F3_ABLATE == 1                  // measurement builds (tools/pmc_ablate.sh, profiles/r06_filter3_ablation.txt): the kernel ends behind phase 1 -- NOT a plan
+    if (tid == 0) { mx.ego_base[e] = 0; mx.ego_n[e] = 0; }
+    return;
+#endif
     // ---- the tiles for the station pass: requested now, behind the candidates' arithmetic; the first reduction's barrier publishes them
     {
         const int tile_gx0 = __builtin_amdgcn_readfirstlane(ep->tile_gx0), tile_gy0 = __builtin_amdgcn_readfirstlane(ep->tile_gy0);
@@ -1722,6 +1737,10 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
     F1P_FPH();
     wg_min1(0, thr);
     F1P_FPH();
+#if defined(F1P_F3_ABLATE) && F1P_F3_ABLATE == 3                  // ... behind the window's staging and the first reduction
+    if (tid == 0) { mx.ego_base[e] = 0; mx.ego_n[e] = 0; }
+    return;
+#endif
     int rounds_run = 0;
     for (int round = 0; round < F1P_MIX_ROUNDS; ++round) {
         rounds_run = round + 1;
@@ -1852,6 +1871,10 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         if (!(my_lo_p <= thr) && !(all_states && my_lo_p < INF)) break;   // nothing undecided reaches below T (or nothing is undecided): done, workgroup-uniform (test hook: every state is wanted)
     }
     F1P_FPH();                                                    // (stamps: 0 start, 1 record barrier, 2 phase 1, 3 first reduction, 4 rounds, 5 queue)
+#if defined(F1P_F3_ABLATE) && F1P_F3_ABLATE == 2                  // ... behind the rounds of the station pass
+    if (tid == 0) { mx.ego_base[e] = 0; mx.ego_n[e] = 0; }
+    return;
+#endif
     const float t_min = t_free;                                   // (after its reduction: the workgroup's T)
 
     // ---- the candidates only fp64 can rank: count, reserve queue space, write the entries (goals by the fp64 arithmetic of candidate_goal)
