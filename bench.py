@@ -695,6 +695,76 @@ def leg_kmpc_c4(rk, args, steps):
     return out
 
 
+def read_sclk_mhz():
+    """the shader clock level the driver marks active right now (sysfs pp_dpm_sclk; None when unreadable)"""
+    import re
+    best = None
+    for pth in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(pth):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    if m:
+                        best = max(best or 0, int(m.group(1)))
+        except OSError:
+            pass
+    return best
+
+
+def leg_kmpc_stream8192(rk, args, steps=200, E=8192):
+    """the streamed shooting kernel where its controls are HBM-resident -- 8192 egos x 512 rollouts x 30 steps, a 1.0 GB control buffer
+    (four times the 256 MiB Infinity Cache) read once per launch: k_kmpc_shoot_mixed against the 8 TB/s HBM roofline, in the DEFAULT run so that the driver
+    sees the figure.  The kernel's duration follows the shader clock (LABNOTES R5): the clock level the driver reports while the launches run is sampled
+    from sysfs beside it."""
+    import threading
+    import numpy as np
+    T, R = 30, 512
+    ctx, cfg, states, ref, _ = kmpc_setup(rk, args, E, T, R)
+    try:
+        d_x0, d_ref = ctx.to_device(states), ctx.to_device(ref)
+        d_ctrl = ctx.alloc(4 * E * T * 2 * R)
+        ctx.kmpc_sample_controls_dev(d_ctrl, E, cfg, seed=12)
+        d_steer, d_speed, d_bi = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E)
+
+        def step():
+            ctx.kmpc_shoot_dev(d_x0, d_ref, d_ctrl, E, cfg, d_steer, d_speed, d_bi, None)
+        for _ in range(5):
+            step()
+        ctx.sync()
+        clocks, stop = [], threading.Event()
+
+        def sample():
+            while not stop.is_set():
+                c = read_sclk_mhz()
+                if c:
+                    clocks.append(c)
+                time.sleep(0.002)
+        th = threading.Thread(target=sample, daemon=True)
+        th.start()
+        ctx.timer_begin()
+        for _ in range(steps):
+            step()
+        ms = ctx.timer_end() / steps
+        stop.set(); th.join(1.0)
+        abytes = E * R * T * 8 + E * (T + 1) * 32 + E * 32 + E * 28
+        gbs = abytes / (ms * 1e-3) / 1e9
+        out = {"workload": f"kmpc shooting, controls streamed: {E} egos x {R} rollouts x {T} steps, {abytes / 1e9:.3f} GB per launch (HBM-resident)",
+               "kernel_ms": ms, "steps": steps, "rollout_steps_per_s": float(E) * R * T / (ms * 1e-3),
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": "k_kmpc_shoot_mixed",
+                            "algorithmic_bytes_per_launch": abytes, "bytes_per_rollout_step": abytes / (E * R * T)},
+               "shader_clock_mhz": {"median": float(np.median(clocks)) if clocks else None, "min": min(clocks) if clocks else None, "max": max(clocks) if clocks else None,
+                                    "samples": len(clocks), "source": "sysfs pp_dpm_sclk, sampled every 2 ms while the launches run"}}
+        if not args.no_cpu_baseline:                          # parity on the first egos (the oracle reads the same control buffer)
+            from oracle import oracle
+            n_or = 64                                         # (the buffer's first rows: a prefix download, not the whole gigabyte)
+            ctrl = d_ctrl.download(np.float32, (n_or, T, 2, R))
+            want = oracle.kmpc_shoot_batch(states[:n_or], ref[:n_or], ctrl, cfg, nthreads=oracle.max_threads())
+            out["parity"] = {"egos_checked": n_or, "best_idx_mismatches": int((want["best_idx"] != d_bi.download(np.int32, (E,))[:n_or]).sum())}
+        return out
+    finally:
+        ctx.close()
+
+
 def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True, device=0, clearance=None):
     """the headline workload (E x C x S, steady state of a closed loop, default schedule) on scenes it was NOT tuned on.
       centred       today's bench scene (sigma 0.3 m around the raceline, nothing inside the corridor)
@@ -1361,8 +1431,11 @@ def main_lattice(args):
     two_in_flight = None
     if secondary and not cand_sharded and not (args.all_fp64 or args.prune):
         two_in_flight = leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, max(20, min(args.steps, 200)))
+    kmpc_s8192 = None
     if secondary and not cand_sharded:
         kmpc_c4 = leg_kmpc_c4(rk, args, max(10, min(args.steps, 100)))
+        if rank == 0 and world == 1 and not args.only_timed:
+            kmpc_s8192 = leg_kmpc_stream8192(rk, args)
 
     if rank == 0:
         steps_total = float(E) * C * S * args.steps * (1 if cand_sharded else world)
@@ -1466,6 +1539,7 @@ def main_lattice(args):
             "multi_process_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "zero_on_every_rank": bool(env_ok)},
             "exchange_selftest": selftest,
             "kmpc_c4": kmpc_c4,
+            "kmpc_stream8192": kmpc_s8192,
             "two_plans_in_flight": two_in_flight,
             "audit": audit,
             "scene_sweep": scene_sweep,
@@ -1501,6 +1575,9 @@ def main_lattice(args):
             "exchange_selftest_ok": _g(selftest, "matches_np_argmin_on_every_rank"), "hsa_ipc_env_zero_on_every_rank": bool(env_ok),
             "kmpc_c4_streamed_ms": _g(kmpc_c4, "ms_per_plan"), "kmpc_c4_generated_ms": _g(kmpc_c4, "generated_in_kernel", "ms_per_plan"),
             "kmpc_c4_cache_stream_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
+            "kmpc_stream8192_ms": _g(kmpc_s8192, "kernel_ms"), "kmpc_stream8192_hbm_frac": _g(kmpc_s8192, "roofline", "frac"),
+            "kmpc_stream8192_shader_mhz": _g(kmpc_s8192, "shader_clock_mhz", "median"),
+            "host_boundary_d2h_ms": (lat["p50_ms"] - lat["without_best_traj"]["p50_ms"]) if (lat and _g(lat, "without_best_traj", "p50_ms")) else None,
         })
         if variants:
             out.update({"host_goals_ms_per_plan": _g(variants, "host_goals", "ms_per_plan"), "host_goals_kernel_ms_filter3": _g(variants, "host_goals", "kernels_ms", "k_lattice_filter3"),

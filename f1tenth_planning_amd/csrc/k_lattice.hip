@@ -538,8 +538,10 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
     lds = (lds + 15) & ~(size_t)15;
     a.stage_offset = (int)lds;
     if (d_all_traj) lds += 16 * 4 * 64 * F1P_STAGE_PITCH;
-    // oriented footprint: discs along the heading tested against the bitmap dilated by the disc radius (f1p_set_footprint);
-    // evaluated by the all-fp64 exhaustive kernel (no branch and bound / f32 filter / candidate slices yet)
+    // oriented footprint: discs along the heading tested against the bitmap dilated by the disc radius (f1p_set_footprint).  Since round 5 such a
+    // plan takes the mixed schedule like any other (launch_lattice_mixed: k_lattice_prologue + k_lattice_filter3<.., FOOT> at every batch size, with
+    // or without a clearance map); THIS kernel's FOOT instantiations serve f1p_lattice_set_mode(0), the audit and all_traj / all_cost -- exhaustive,
+    // no branch and bound, no candidate slices
     const bool foot = ctx->n_disc > 0 && cfg->check_collision && ctx->has_grid && mode != LATTICE_EMIT;
     a.n_disc = foot ? ctx->n_disc : 0;
     for (int d = 0; d < 4; ++d) a.disc_off[d] = ctx->disc_off[d];

@@ -2745,7 +2745,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
     // ---- mixed-precision schedule: f32 filter over every candidate, fp64 decision (see the top of this file) -----------------
     auto fin = [](double v) { return v == v && v < HUGE_VAL && v > -HUGE_VAL; };
     const bool weights_finite = fin(cfg->w_length) && fin(cfg->w_max_kappa) && fin(cfg->w_mean_kappa) && fin(cfg->w_similarity);
-    // (an oriented footprint runs here only in the filter's clearance mode: decided below, before anything is launched)
+    // (an oriented footprint takes the prologue + k_lattice_filter3<.., FOOT> pair at every batch size, with or without a clearance map -- without one every look
+    // tests every station's disc centres on the bitmap; the clearance mode's parameters are decided below, before anything is launched)
     double clear_ds_cap = 0.0, clear_dist = 0.0;
     bool clear_ok = false;
     int clear_r_eff = 0;

@@ -364,7 +364,8 @@ int f1p_lattice_debug_bound(f1p_ctx* ctx, float* d_bound);
 /* Dispatch order of the mixed schedule's candidate kernel (round 5).  1 (default): every plan of >= 1024 egos leaves one flag per ego -- its
  * cheapest candidates collided, so its workgroup took the long path -- and the next plan of the same batch size starts those egos' workgroups
  * first, where their longer lifetime overlaps the others instead of ending the kernel (a control loop meets the same obstacle in consecutive
- * plans).  0: ego order.  Outputs are identical either way; the order only moves time. */
+ * plans).  0: ego order.  Outputs are identical either way; the order only moves time.  Applies to UNPIPELINED plans only: a plan cut into chunks of
+ * egos (f1p_lattice_set_pipeline with chunks > 1) runs every chunk in ego order, and plans profiled per kernel (f1p_lattice_profile) are unpipelined. */
 int f1p_lattice_set_order(f1p_ctx* ctx, int32_t heavy_first);
 /* MEASUREMENT HOOK (round 5): d_pass [E][4] i32 (device pointer, nullable; the caller zeroes it) receives, per ego of the following mixed
  * plans, what the candidate kernel's LAZY station pass looked at: [0] candidates whose positions were integrated and looked up (certain

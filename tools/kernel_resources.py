@@ -23,11 +23,14 @@ CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
 #   k_kmpc_*            spills sit in the once-per-workgroup setup blocks and the rarely taken serial fp64 fallback, not in the
 #                       filter loop (tools/isa_loops.py); a lower register cap was measured slower (LABNOTES.md 5b)
 #   k_lattice / g1      the out-of-line fp64 fit's 8-byte frame
-#   k_lattice_filter3<CR, true>   the TEST-HOOK instantiation of the candidate kernel (debug pointers + their stores: never the production launch)
+#   k_lattice_filter3<CR, true, ..>   the instantiations with the test hooks compiled in.  They ARE what launch_lattice_mixed launches for host-supplied
+#                       goals (<CR, true, true>), cubic + footprint and footprint + host goals -- production plan shapes of the add_sample_function
+#                       path -- so those shapes carry this budget (8-24 B of scratch); the spill-free claim holds for the device-goal shapes
+#                       (<CR, false, false, GEN, FOOT = false>: 0 scratch, asserted below by the default budget of 0)
 BUDGET = {"ILb1E": 160, "k_kmpc_plan_gen": 32, "k_kmpc_shoot_mixed": 0, "k_clothoid_g1": 8, "9k_latticeILb0E": 8,
           "k_lattice_filter3ILi1ELb1E": 24, "k_lattice_filter3ILi2ELb1E": 24,
-          "k_lattice_filter3ILi1ELb0ELb0ELi0ELb1E": 8, "k_lattice_filter3ILi2ELb0ELb0ELi0ELb1E": 8}   # (the instantiations WITH test hooks; the production ones: 0)
-# The headline kernels (k_lattice_prologue, k_lattice_filter3 without test hooks) carry NO scratch and no VGPR spills;
+          "k_lattice_filter3ILi1ELb0ELb0ELi0ELb1E": 8, "k_lattice_filter3ILi2ELb0ELb0ELi0ELb1E": 8}   # (the instantiations WITH test hooks -- incl. the host-goal shapes; device goals, point footprint: 0)
+# The headline kernels (k_lattice_prologue, k_lattice_filter3<CR, false, false, GEN, false>) carry NO scratch and no VGPR spills;
 # `make resources` is part of __graft_entry__.build().
 
 
