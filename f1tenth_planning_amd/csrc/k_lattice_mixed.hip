@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         }
     }
     double sn_t = 0.0, cs_t = 1.0;
-    if (lane == 0) sincos(theta, &sn_t, &cs_t);                  // one lane: the library call is long, the other lanes skip it
+    if (lane == 0) sincos(theta, &sn_t, &cs_t);                  // one lane: the library call is long, the other lanes skip it (round 6: sincos_core here and in k_lattice measured 17.06 -> 16.92 us -- inside the noise: the library call stays)
     F1P_PPH();
     // ---- nearest segment and look-ahead centres: the arithmetic of k_lattice (fp64: these decide indices), one wave ---------------
     double nd; int ni;
@@ -2825,8 +2825,8 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
             const size_t lds_rc = sizeof(double) * 16 * 5 * (size_t)S;                      // k_lattice_refine_cubic: five station arrays per group
             // (clearance 0 -- no map -- runs the r = 1 instantiations: every look of theirs is the every-station one then)
             const int cr = mx.clear_r == 2 ? 2 : 1;
-            bool v3 =       (cr == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3)
-                                              : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3));
+            bool v3 =       (cr == 1 ? lds_fits(ctx, k_lattice_filter3<1>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, false, true>), lds_f3)
+                                              : lds_fits(ctx, k_lattice_filter3<2>, lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, true, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<2, false, true>), lds_f3));
             if (mx.n_disc > 0)                                       // oriented footprint: its own instantiations (hooks included)
                 v3 = v3 && (cr == 1 ? lds_fits(ctx, (k_lattice_filter3<1, true, false, F1P_GEN_CLOTHOID, true>), lds_f3) && lds_fits(ctx, (k_lattice_filter3<1, true, true, F1P_GEN_CLOTHOID, true>), lds_f3) &&
                                                    lds_fits(ctx, (k_lattice_filter3<1, false, false, F1P_GEN_CLOTHOID, true>), lds_f3)
@@ -2980,9 +2980,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                             if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, false, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                             else hipLaunchKernelGGL((k_lattice_filter3<2, false, false, F1P_GEN_CLOTHOID, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         }
-                    } else if (ak.goals) {                                      // (host goals: one instantiation per clearance mode, hooks included)
-                        if (cr == 1) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
-                        else hipLaunchKernelGGL((k_lattice_filter3<2, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                    } else if (ak.goals) {                                      // (host goals -- the reference's add_sample_function plug-in: with and, round 6, without the test hooks)
+                        if (cr == 1) {
+                            if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<1, false, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        } else {
+                            if (dbg) hipLaunchKernelGGL((k_lattice_filter3<2, true, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                            else hipLaunchKernelGGL((k_lattice_filter3<2, false, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
+                        }
                     } else if (cr == 1) {
                         if (dbg) hipLaunchKernelGGL((k_lattice_filter3<1, true>), dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
                         else hipLaunchKernelGGL(k_lattice_filter3<1>, dim3(f3_grid), fb, lds_f3, st, ak, *cfg, mk, recs);
