@@ -70,7 +70,7 @@ namespace f1p {
 #define F1P_MIX_FILTER_WAVES 8       // waves per SIMD the filter kernel's register allocation is held to (64 VGPRs: 8 workgroups per CU = two full rounds at 4096 egos; measured 125 -> 120 us against 4)
 #endif
 #ifndef F1P_MIX_FIT_UNROLL
-#define F1P_MIX_FIT_UNROLL 2
+#define F1P_MIX_FIT_UNROLL 4     // node pairs per trip of the f32 fit's loop (round 6, eight pairs: 1: 32.5 us, 2: 31.8, 4: 31.5, 8: 35.8 -- 119 spilled SGPRs)
 #endif
 #ifndef F1P_MIX_COOP_MAX
 #define F1P_MIX_COOP_MAX 4           // selected candidates per wave up to which the station pass runs wave-cooperatively (station_pass_wave), one after the other
