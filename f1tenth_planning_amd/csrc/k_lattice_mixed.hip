@@ -481,7 +481,7 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         const float ax = (float)(sx - px), ay = (float)(sy - py), bx = (float)(ex - px), by = (float)(ey - py);
         const float vx = (float)(ex - sx), vy = (float)(ey - sy);
         F1P_LAT(1);                                                 // the segment rows arrived
-        const float dS = __builtin_sqrtf(ax * ax + ay * ay), dE = __builtin_sqrtf(bx * bx + by * by);
+        const float dS = __builtin_amdgcn_sqrtf(ax * ax + ay * ay), dE = __builtin_amdgcn_sqrtf(bx * bx + by * by);   // (round 6: v_sqrt_f32 itself -- 1 ulp against a 1e-4 m margin; the library form is 12 instructions and three selects more, each)
         const float len2 = vx * vx + vy * vy;
         const float u = -(ax * vx + ay * vy);                       // projection parameter times len2
         float lo = fminf(dS, dE);
@@ -496,11 +496,27 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         unsigned long long mine = 0ull;
         const float lo_s = lo - slack, hi_s = hi + slack;
         const bool nan_seg = !(dS == dS) | !(dE == dE);           // NaN anywhere: flagged (fminf / fmaxf drop a NaN operand)
-        int slot = 0;
-        for (int l = wave; l < nl; l += nwaves, ++slot) {
-            const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r32), slot));
-            const bool flag = (!(r < lo_s) & !(r > hi_s)) | nan_seg;
-            mine |= flag ? (1ull << slot) : 0ull;
+        if (nslots <= 32) {
+            // Round 6: the flag as ARITHMETIC on the sign bits -- neither r - lo_s nor hi_s - r negative iff lo_s <= r <= hi_s (a difference of equal values is + 0) --
+            // shifted into a 32-bit mask: six plain instructions per radius.  The compare-and-select form was nine, two of them v_cndmask on VCC (16
+            // cycles each on this chip): 144 instructions of the prologue's 1 175 for sixteen radii.  (NaN segments are flagged wholesale below; a NaN
+            // radius flags every segment or none by its own sign bit -- the compare form flagged every one: it meets no segment in the exact test either way.)
+            uint32_t m32 = 0u;
+            int slot = 0;
+            for (int l = wave; l < nl; l += nwaves, ++slot) {
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r32), slot));
+                const uint32_t sg = (uint32_t)__float_as_int(r - lo_s) | (uint32_t)__float_as_int(hi_s - r);   // sign bit set iff r < lo_s or r > hi_s
+                m32 |= ((~sg) >> 31) << slot;
+            }
+            if (nan_seg) m32 = nslots >= 32 ? 0xffffffffu : ((1u << nslots) - 1u);
+            mine = (unsigned long long)m32;
+        } else {
+            int slot = 0;
+            for (int l = wave; l < nl; l += nwaves, ++slot) {
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r32), slot));
+                const bool flag = (!(r < lo_s) & !(r > hi_s)) | nan_seg;
+                mine |= flag ? (1ull << slot) : 0ull;
+            }
         }
         const int my_n = __builtin_popcountll(mine);
         const int incl = wave_scan_add_i32(my_n);
@@ -543,7 +559,7 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
         float t = l2 > 0.0f ? (ax * vx + ay * vy) * __builtin_amdgcn_rcpf(l2) : 0.0f;
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         const float qx = ax - t * vx, qy = ay - t * vy;
-        const double dw = (double)__builtin_sqrtf(qx * qx + qy * qy) * (1.0 - 1e-5);
+        const double dw = (double)__builtin_amdgcn_sqrtf(qx * qx + qy * qy) * (1.0 - 1e-5);
         if (!(dw >= dmin)) dmin = dw;                              // (NaN: dmin becomes NaN and nothing is skipped)
     }
     const bool surely_none = my_r < dmin - (1e-4 + 4e-6 * dmin);
