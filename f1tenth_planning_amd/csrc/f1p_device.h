@@ -95,6 +95,31 @@ __device__ __forceinline__ void wave_argmin_dpp(double& d, int& i) {
     i = __builtin_amdgcn_readlane(i, 63);
 }
 
+// Round 6 -- the same (value, index) argmin of a FULLY ACTIVE wave in two steps: the minimum of the values ROUNDED to f32 on order-preserving integer keys
+// (six v_min_i32 with the DPP operand folded + one v_readlane: wave_min_key), then np.argmin's exact rule (argmin_better, fp64) over the few lanes whose
+// key lies within two of that minimum -- every lane whose value is <= the exact minimum is among them (a rounding to nearest moves a key by at most one),
+// usually exactly one.  A NaN takes the smallest key (np.argmin returns the first NaN).  wave_argmin_dpp carries (double, int) pairs through six DPP
+// steps with a compare-and-select each: ~100 instructions, 18 of them v_cndmask on VCC (16 cycles each on gfx950, profiles/r03_valu_issue_cycles.txt);
+// this form is ~45 for one candidate.  Same result in every lane.
+__device__ __forceinline__ void wave_argmin_2step(double& d, int& i) {
+    const int k = (d != d) ? (int)0x80000000 : f32_order_key((float)d);
+    const int kmin = wave_min_key(k);
+    const long long gap = (long long)k - (long long)kmin;             // (>= 0; 64-bit: the NaN key is INT_MIN)
+    unsigned long long m = __ballot(gap <= 2ll);
+    if (__builtin_popcountll(m) > 4) { wave_argmin_dpp(d, i); return; }   // many equal values (a blocked ego: every cost + inf): the carrying reduction, not a 64-trip loop
+    double bd = __builtin_huge_val(); int bi = 0x7fffffff;
+    const long long b = __double_as_longlong(d);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    while (m) {                                                       // (wave-uniform)
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int olo = __builtin_amdgcn_readlane(lo, src), ohi = __builtin_amdgcn_readlane(hi, src), oi = __builtin_amdgcn_readlane(i, src);
+        const double od = __longlong_as_double(((long long)ohi << 32) | (long long)(unsigned int)olo);
+        if (argmin_better(od, oi, bd, bi)) { bd = od; bi = oi; }
+    }
+    d = bd; i = bi;
+}
+
 // block-wide argmin; `sd`/`si` are LDS scratch of >= blockDim.x/64 entries.  All threads get the result.
 __device__ __forceinline__ void block_argmin(double& d, int& i, double* sd, int* si) {
     wave_argmin(d, i);

@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     SegProj ns;
     {
         const int my_i = ni;
-        wave_argmin_dpp(nd, ni);                                   // (every lane of the ego's wave is here)
+        wave_argmin_2step(nd, ni);                                 // (every lane of the ego's wave is here)
         const unsigned long long own = __ballot(my_i == ni);
         ns.t = shfl_d(my_t, own ? __ffsll((long long)own) - 1 : 0); ns.d = nd; ns.qx = 0.0; ns.qy = 0.0;
     }
@@ -2620,7 +2620,7 @@ __global__ __launch_bounds__(256, 3) void k_lattice_select(LatticeArgs a, f1p_la
     int src = 0;
     {   // wave argmin carrying the slot (candidate indices are unique per ego)
         double d = bc; int i = bi;
-        wave_argmin_dpp(d, i);                                     // (wave-uniform code: all 64 lanes active)
+        wave_argmin_2step(d, i);                                   // (wave-uniform code: all 64 lanes active)
         const unsigned long long m = __ballot((bi == i) & (bslot >= 0));
         src = m ? __ffsll((long long)m) - 1 : 0;
         bslot = __shfl(bslot, src, 64);
