@@ -980,7 +980,7 @@ int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S
 
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state) {
     if (!ctx) return F1P_EINVAL;
-    if (mixed < 0 || mixed > 2) return set_error(ctx, F1P_EINVAL, "mixed must be 0 (all fp64), 1 (f32 filter from 256 egos) or 2 (f32 filter always)");
+    if (mixed < 0 || mixed > 3) return set_error(ctx, F1P_EINVAL, "mixed must be 0 (all fp64), 1 (f32 filter, the default), 2 (f32 filter at any batch size) or 3 (as 2, one ego per wave in the per-ego kernels)");
     ctx->lattice_mixed = mixed;
     ctx->d_dbg_lat_cost32 = d_cost32;
     ctx->d_dbg_lat_state = d_state;

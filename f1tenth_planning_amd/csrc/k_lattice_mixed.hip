@@ -1494,6 +1494,469 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     if (lane == 0 && mx.dbg_cost32) { for (int k = 0; k + 1 < npp; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 32 + k] = (float)(pph[k + 1] - pph[k]); mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 31] = (float)(pph[0] & 0xffffff); }
 #endif
 }
+#undef F1P_PPH
+
+// ===================================================================================================================
+// Round 6: k_lattice_prologue2 -- TWO egos per wave (lanes 0..31 / 32..63), VERDICT r5 #2 (i).
+// k_lattice_prologue runs one ego per wave, 4 096 waves = four per SIMD, and is issue-shared: ~570 of a wave's ~1 000 VALU instructions are per-EGO
+// work on one lane or sixteen (sincos(theta), the record, the goal frames, the argmin's bookkeeping, the moments' reduction, the exact hit tests) and
+// cost the full four cycles each.  Here a wave carries two egos: that work is issued ONCE for both, the wave-wide parts (the 64-segment nearest scan,
+// the 64 virtual segments of the look-ahead bracket) take two segments per lane, and there are half as many waves per SIMD.  Every decision is
+// taken by the same fp64 arithmetic on the same operands (seg_project, argmin_better, seg_hit; the f32 brackets and the chunk boxes only decide what
+// is NOT evaluated, with the margins argued at nearest_scan_boxed / wave_lookahead_centres), so the record is the one k_lattice_prologue writes, bit
+// for bit (tests/test_gpu_lattice_mixed.py: mode 2 against mode 3 = this kernel against that one, and both against the all-fp64 kernel).
+// Scope: n_lookahead <= 32 (a half-wave holds a row per lane); beyond that, and in the phase-stamp builds, the launcher takes k_lattice_prologue.
+// ===================================================================================================================
+#ifndef F1P_PRO2
+#define F1P_PRO2 1              // 0: k_lattice_prologue always (A/B)
+#endif
+
+__device__ __forceinline__ int half_last_i32(int v, bool hi_half) {     // lane 31's value in lanes 0..31, lane 63's in lanes 32..63
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return hi_half ? hi : lo;
+}
+__device__ __forceinline__ int half_min_key(int v, bool hi_half) {      // wave_min_key over each half (all 64 lanes active)
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3: lanes 31 / 63 hold their half's minimum
+    return half_last_i32(v, hi_half);
+}
+__device__ __forceinline__ int half_scan_add_i32(int v) {               // inclusive sum over each half (all 64 lanes active)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ double readlane_d(double v, int src) {        // src wave-uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+// wave_argmin_dpp / wave_argmin_2step over each half: np.argmin's (value, index) rule, the same result in every lane of a half
+__device__ __forceinline__ void half_argmin_dpp(double& d, int& i, bool hi_half) {
+#define F1P_HALF_ARGMIN_STEP(CTRL, ROWS)                                                                                        \
+    {                                                                                                                           \
+        const long long b = __double_as_longlong(d);                                                                            \
+        const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);                                                            \
+        const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false), ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false); \
+        const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROWS, 0xf, false);                                               \
+        const double od = __longlong_as_double(((long long)ohi << 32) | (long long)(unsigned int)olo);                          \
+        if (argmin_better(od, oi, d, i)) { d = od; i = oi; }                                                                    \
+    }
+    F1P_HALF_ARGMIN_STEP(0x111, 0xf)
+    F1P_HALF_ARGMIN_STEP(0x112, 0xf)
+    F1P_HALF_ARGMIN_STEP(0x114, 0xf)
+    F1P_HALF_ARGMIN_STEP(0x118, 0xf)
+    F1P_HALF_ARGMIN_STEP(0x142, 0xa)   // lanes 31 / 63 hold their half's winner
+#undef F1P_HALF_ARGMIN_STEP
+    const long long b = __double_as_longlong(d);
+    const int lo = half_last_i32((int)(b & 0xffffffffll), hi_half), hi = half_last_i32((int)(b >> 32), hi_half);
+    d = __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+    i = half_last_i32(i, hi_half);
+}
+__device__ __forceinline__ void half_argmin_2step(double& d, int& i, bool hi_half) {
+    const int k = (d != d) ? (int)0x80000000 : f32_order_key((float)d);
+    const int kmin = half_min_key(k, hi_half);
+    const long long gap = (long long)k - (long long)kmin;
+    const unsigned long long m = __ballot(gap <= 2ll);
+    unsigned int m0 = (unsigned int)m, m1 = (unsigned int)(m >> 32);
+    if (__builtin_popcount(m0) > 4 || __builtin_popcount(m1) > 4) { half_argmin_dpp(d, i, hi_half); return; }
+    const long long b = __double_as_longlong(d);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    double bd0 = __builtin_huge_val(), bd1 = __builtin_huge_val(); int bi0 = 0x7fffffff, bi1 = 0x7fffffff;
+    while (m0) {                                                      // (wave-uniform; usually one trip)
+        const int src = __builtin_ctz(m0);
+        m0 &= m0 - 1;
+        const int olo = __builtin_amdgcn_readlane(lo, src), ohi = __builtin_amdgcn_readlane(hi, src), oi = __builtin_amdgcn_readlane(i, src);
+        const double od = __longlong_as_double(((long long)ohi << 32) | (long long)(unsigned int)olo);
+        if (argmin_better(od, oi, bd0, bi0)) { bd0 = od; bi0 = oi; }
+    }
+    while (m1) {
+        const int src = 32 + __builtin_ctz(m1);
+        m1 &= m1 - 1;
+        const int olo = __builtin_amdgcn_readlane(lo, src), ohi = __builtin_amdgcn_readlane(hi, src), oi = __builtin_amdgcn_readlane(i, src);
+        const double od = __longlong_as_double(((long long)ohi << 32) | (long long)(unsigned int)olo);
+        if (argmin_better(od, oi, bd1, bi1)) { bd1 = od; bi1 = oi; }
+    }
+    d = hi_half ? bd1 : bd0; i = hi_half ? bi1 : bi0;
+}
+
+__global__ __launch_bounds__(256) void k_lattice_prologue2(LatticeArgs a, f1p_lattice_cfg cfg, MixArgs mx, unsigned char* __restrict__ recs) {
+    __shared__ double s_seg[4][2][5][64];                         // per ego: the 64 virtual segments' start x, y, end x, y, start heading
+    __shared__ int s_first[4][2][32];
+    __shared__ int s_pairs[4][2][64];
+    warm_kernargs<sizeof(LatticeArgs) + sizeof(f1p_lattice_cfg) + sizeof(MixArgs) + 8>();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool hh = lane >= 32;
+    const int h = hh ? 1 : 0, hl = lane & 31, hbase = lane & 32;
+    const int e_first = a.e0 + ((blockIdx.x * 4 + wave) << 1);
+    if (e_first >= a.E) return;                                  // wave-uniform
+    const bool valid = e_first + h < a.E;
+    const int e = valid ? e_first + h : a.E - 1;                 // an odd batch's last wave: its second half repeats the last ego and stores nothing
+    const int nl = cfg.n_lookahead, S = cfg.n_stations, n = a.n;
+    double (*seg)[64] = s_seg[wave][h];
+    int* lds_first = s_first[wave][h];
+    int* lds_pairs = s_pairs[wave][h];
+    const double* __restrict__ wx = a.wx; const double* __restrict__ wy = a.wy;
+#ifdef F1P_PRO2_PHASES
+    long long pph[10], lat[5] = {0, 0, 0, 0, 0}; int npp = 0;
+#define F1P_PPH() do { __builtin_amdgcn_s_waitcnt(0); pph[npp++] = clock64(); } while (0)
+#define F1P_LAT(k) do { __builtin_amdgcn_s_waitcnt(0); lat[k] = clock64(); } while (0)
+#else
+#define F1P_PPH() do {} while (0)
+#define F1P_LAT(k) do {} while (0)
+#endif
+    F1P_PPH();
+    // ---- what does not depend on the pose: chunk boxes, sample waypoints (32 per ego: the bound only prunes) ---------------------------------
+    const int nseg = n - 1, nchunk = (nseg + 63) >> 6;
+    double b0x = 0.0, b0X = 0.0, b0y = 0.0, b0Y = 0.0;
+    if (hl < nchunk) { b0x = a.wbox[4 * hl]; b0X = a.wbox[4 * hl + 1]; b0y = a.wbox[4 * hl + 2]; b0Y = a.wbox[4 * hl + 3]; }
+    int sj0 = hl * ((n + 63) >> 6), sj1 = (hl + 32) * ((n + 63) >> 6);   // 64 sample waypoints per ego, two per lane (32: 1.67 scan trips per wave on the bench's track, 64: 1.38)
+    if (sj0 > n - 1) sj0 = n - 1;
+    if (sj1 > n - 1) sj1 = n - 1;
+    const double smx0 = wx[sj0], smy0 = wy[sj0], smx1 = wx[sj1], smy1 = wy[sj1];
+    const double px = a.poses[4 * e], py = a.poses[4 * e + 1], theta = a.poses[4 * e + 2];
+    if (a.pose_copy && hl < 4 && valid) a.pose_copy[4 * e + hl] = a.poses[4 * e + hl];
+    const int sim_m = S - cfg.n_shift - cfg.n_cull;
+    double pm0 = 0.0, pm1 = 0.0, pm2 = 0.0;
+    if (a.prev_theta) {
+        const double* pv = a.prev_theta + (size_t)e * S + cfg.n_shift;
+        for (int j = hl; j < sim_m; j += 32) {
+            const double p = pv[j], fj = (double)j;
+            pm0 = __builtin_fma(p, p, pm0); pm1 = __builtin_fma(fj, p, pm1); pm2 = __builtin_fma(fj * fj, p, pm2);
+        }
+    }
+    const bool collide_on = cfg.check_collision && a.has_grid;
+    int tile_gx0 = 0, tile_gy0 = 0;
+    double txo = 0.0, tyo = 0.0;
+    uint32_t own_word = 0xffffffffu;
+    int own_bit = -1;
+    {
+        const double cxd = (px - a.grid.ox) * a.grid.inv_res, cyd = (py - a.grid.oy) * a.grid.inv_res;
+        if (collide_on) {
+            const double fx = __builtin_floor(cxd), fy = __builtin_floor(cyd);
+            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+            const int half = a.tile_rows / 2;
+            tile_gx0 = ((egx - half) >> 5) << 5;
+            tile_gy0 = egy - half;
+        }
+        txo = cxd - (double)tile_gx0; tyo = cyd - (double)tile_gy0;
+        if (hl == 0 && mx.clear_bits) {
+            const int lx0 = cvt_flr_i32_f32((float)txo), ly0 = cvt_flr_i32_f32((float)tyo);
+            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+                own_bit = lx0 & 31;
+                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
+                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) own_word = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];
+            }
+        }
+    }
+    double sn_t = 0.0, cs_t = 1.0;
+    F1P_PPH();
+    // ---- nearest segment: nearest_scan_boxed per half, two 32-segment passes per surviving chunk -------------------------------------------
+    double nd = __builtin_huge_val(); int ni = 0x7fffffff; double my_t = 0.0;
+    bool pm_done = false;                                        // (wave-uniform)
+    {
+        const double ex0 = px - smx0, ey0 = py - smy0, ex1 = px - smx1, ey1 = py - smy1;
+        const double ub2_a = ex0 * ex0 + ey0 * ey0, ub2_b = ex1 * ex1 + ey1 * ey1;
+        const double ub2_own = ub2_b < ub2_a ? ub2_b : ub2_a;       // (a NaN sample drops out unless both are NaN; then ub2_up's test below keeps every chunk)
+        const float ub2_up = (float)ub2_own * (1.0f + 2.4e-7f);
+        const double ub2 = (double)f32_from_order_key(half_min_key(f32_order_key(ub2_up == ub2_up ? ub2_up : __builtin_nanf("")), hh));
+        const double thr = ub2 * (1.0 + 1e-6) + 1e-9;
+        for (int cb = 0; cb < nchunk; cb += 32) {
+            const int c = cb + hl;
+            bool keep = false;
+            if (c < nchunk) {
+                double xmin = b0x, xmax = b0X, ymin = b0y, ymax = b0Y;
+                if (cb > 0) { xmin = a.wbox[4 * c]; xmax = a.wbox[4 * c + 1]; ymin = a.wbox[4 * c + 2]; ymax = a.wbox[4 * c + 3]; }
+                const double dx = __builtin_fmax(__builtin_fmax(xmin - px, px - xmax), 0.0);
+                const double dy = __builtin_fmax(__builtin_fmax(ymin - py, py - ymax), 0.0);
+                keep = !(dx * dx + dy * dy > thr);               // NaN anywhere keeps the chunk
+            }
+            const unsigned long long m = __ballot(keep);
+            unsigned int m0 = (unsigned int)m, m1 = (unsigned int)(m >> 32);
+            bool first_trip = cb == 0;
+            while (m0 | m1) {                                    // (wave-uniform: each half takes ITS next TWO surviving chunks -- all there are, as a rule -- or idles)
+                const int ca0 = m0 ? __builtin_ctz(m0) : -1, ca1 = m1 ? __builtin_ctz(m1) : -1;
+                m0 &= m0 - 1; m1 &= m1 - 1;
+                const int cc0 = m0 ? __builtin_ctz(m0) : -1, cc1 = m1 ? __builtin_ctz(m1) : -1;
+                m0 &= m0 - 1; m1 &= m1 - 1;
+                const int cmA = hh ? ca1 : ca0, cmB = hh ? cc1 : cc0;
+                const bool anyB = (cc0 >= 0) | (cc1 >= 0);        // (wave-uniform)
+                // every row of the trip is requested before the first projection: one round trip per trip, and almost always one trip
+                double sxv[4], syv[4], exv[4], eyv[4]; int iv[4]; bool onv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cm = u < 2 ? cmA : cmB;
+                    iv[u] = ((cb + cm) << 6) + (u & 1) * 32 + hl;
+                    onv[u] = cm >= 0 && iv[u] < nseg;
+                    sxv[u] = 0.0; syv[u] = 0.0; exv[u] = 0.0; eyv[u] = 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) if (onv[u]) { sxv[u] = wx[iv[u]]; syv[u] = wy[iv[u]]; exv[u] = wx[iv[u] + 1]; eyv[u] = wy[iv[u] + 1]; }
+                if (anyB) {
+#pragma unroll
+                    for (int u = 2; u < 4; ++u) if (onv[u]) { sxv[u] = wx[iv[u]]; syv[u] = wy[iv[u]]; exv[u] = wx[iv[u] + 1]; eyv[u] = wy[iv[u] + 1]; }
+                }
+                if (first_trip && a.prev_theta) {                 // in the shadow of the rows' round trip: the moments' reduction (their loads were requested at the kernel's start)
+#pragma unroll
+                    for (int mm = 16; mm >= 1; mm >>= 1) { pm0 += shfl_xor_d(pm0, mm); pm1 += shfl_xor_d(pm1, mm); pm2 += shfl_xor_d(pm2, mm); }
+                    pm_done = true;
+                }
+                first_trip = false;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (onv[u]) {
+                        const SegProj sp_ = seg_project(px, py, sxv[u], syv[u], exv[u], eyv[u]);
+                        if (argmin_better(sp_.d, iv[u], nd, ni)) { nd = sp_.d; ni = iv[u]; my_t = sp_.t; }
+                    }
+                }
+                if (anyB) {
+#pragma unroll
+                    for (int u = 2; u < 4; ++u) {
+                        if (onv[u]) {
+                            const SegProj sp_ = seg_project(px, py, sxv[u], syv[u], exv[u], eyv[u]);
+                            if (argmin_better(sp_.d, iv[u], nd, ni)) { nd = sp_.d; ni = iv[u]; my_t = sp_.t; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    F1P_PPH();
+    double ns_t;
+    {
+        const int my_i = ni;
+        half_argmin_2step(nd, ni, hh);
+        const unsigned long long ownm = __ballot(my_i == ni);
+        const unsigned int own = hh ? (unsigned int)(ownm >> 32) : (unsigned int)ownm;
+        ns_t = shfl_d(my_t, hbase + (own ? __builtin_ctz(own) : 0));
+    }
+    F1P_PPH();
+    // ---- look-ahead centres: wave_lookahead_centres per half, two of the 64 virtual segments per lane; lane hl ends with row hl's centre -----
+    bool my_found = false;
+    double c_x = 0.0, c_y = 0.0, c_psi = 0.0;
+    if (!a.goals) {                                              // (wave-uniform)
+        const double tstart = (double)ni + ns_t;
+        const int start_i = (int)tstart;
+        const double start_t = tstart - __builtin_trunc(tstart);
+        bool fast = start_i >= 0 && start_i <= n - 2 && n > 130 && nl <= 32;
+        const int nreg = n - 1 - start_i;
+        F1P_LAT(0);
+        const double my_r = hl < nl ? cfg.lookahead[hl] : 0.0;   // (the same radii in both halves)
+        const float my_r32 = (float)my_r;
+        const double wrap_ax = wx[n - 1], wrap_ay = wy[n - 1], wrap_bx = wx[0], wrap_by = wy[0];
+        uint32_t mineA = 0u, mineB = 0u;
+        {
+            // the rows of this lane's two virtual segments are requested first; sincos(theta) -- both egos' calls in ONE pass of lanes 0 and 32, needed only by
+            // the goal frames -- runs in the shadow of their round trip
+            double rsx[2], rsy[2], rex[2], rey[2], rpsi[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = hl + 32 * u;
+                const int vi = j < nreg ? start_i + j : j - nreg - 1;
+                int i0 = vi < 0 ? vi + n : vi, i1 = vi + 1;
+                i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);    // (only a half that is not `fast` can be out of range: its rows are not used)
+                i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+                rpsi[u] = a.wpsi[i0]; rsx[u] = wx[i0]; rsy[u] = wy[i0]; rex[u] = wx[i1]; rey[u] = wy[i1];
+            }
+            if (hl == 0) sincos(theta, &sn_t, &cs_t);
+            typedef float f1p_v2 __attribute__((ext_vector_type(2)));
+            f1p_v2 lo2, hi2; bool nan_seg[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = hl + 32 * u;
+                const double sx = rsx[u], sy = rsy[u], ex = rex[u], ey = rey[u];
+                seg[0][j] = sx; seg[1][j] = sy; seg[2][j] = ex; seg[3][j] = ey; seg[4][j] = rpsi[u];
+                if (u == 1) F1P_LAT(1);
+                const float ax = (float)(sx - px), ay = (float)(sy - py), bx = (float)(ex - px), by = (float)(ey - py);
+                const float vx = (float)(ex - sx), vy = (float)(ey - sy);
+                const float dS = __builtin_amdgcn_sqrtf(ax * ax + ay * ay), dE = __builtin_amdgcn_sqrtf(bx * bx + by * by);
+                const float len2 = vx * vx + vy * vy;
+                const float uu = -(ax * vx + ay * vy);
+                float lo = fminf(dS, dE);
+                if (uu > 0.0f && uu < len2) lo = fminf(lo, fabsf(ax * vy - ay * vx) * __builtin_amdgcn_rsqf(len2));
+                const float hi = fmaxf(dS, dE);
+                const float slack = 1e-4f + 4e-6f * hi;
+                if (u == 0) { lo2.x = lo - slack; hi2.x = hi + slack; } else { lo2.y = lo - slack; hi2.y = hi + slack; }
+                nan_seg[u] = !(dS == dS) | !(dE == dE);
+            }
+            lds_first[hl] = 0x7fffffff;
+            // the flags of both segments by packed arithmetic on the sign bits (wave_lookahead_centres' form, two segments per instruction), collected
+            // by v_alignbit from the LAST radius down so that slot s ends in bit s: seven instructions per radius for two segments
+            uint32_t badA = 0u, badB = 0u;
+            for (int slot = nl - 1; slot >= 0; --slot) {         // (nl <= 32 on this path, checked by the launcher)
+                const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r32), slot));
+                const f1p_v2 rr = {r, r};
+                const f1p_v2 d1 = rr - lo2, d2 = hi2 - rr;
+                const uint32_t sgA = (uint32_t)__float_as_int(d1.x) | (uint32_t)__float_as_int(d2.x);   // sign bit set iff r < lo_s or r > hi_s
+                const uint32_t sgB = (uint32_t)__float_as_int(d1.y) | (uint32_t)__float_as_int(d2.y);
+                badA = __builtin_amdgcn_alignbit(badA, sgA, 31);   // (badA << 1) | (sgA >> 31)
+                badB = __builtin_amdgcn_alignbit(badB, sgB, 31);
+            }
+            const uint32_t all = nl >= 32 ? 0xffffffffu : ((1u << nl) - 1u);
+            mineA = nan_seg[0] ? all : (~badA & all);
+            mineB = nan_seg[1] ? all : (~badB & all);
+        }
+        const int my_n = __builtin_popcount(mineA) + __builtin_popcount(mineB);
+        const int incl = half_scan_add_i32(my_n);
+        const int total = half_last_i32(incl, hh);
+        if (total > 64) fast = false;
+        if (fast) {
+            int idx = incl - my_n;
+            for (uint32_t m = mineA; m; m &= m - 1) lds_pairs[idx++] = (hl << 8) | __builtin_ctz(m);
+            for (uint32_t m = mineB; m; m &= m - 1) lds_pairs[idx++] = ((hl + 32) << 8) | __builtin_ctz(m);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        F1P_LAT(2);
+        {
+            const int t0 = __builtin_amdgcn_readlane(fast ? total : 0, 0), t1 = __builtin_amdgcn_readlane(fast ? total : 0, 32);
+            const int tmax = t0 > t1 ? t0 : t1;
+            for (int q0 = 0; q0 < tmax; q0 += 32) {              // (wave-uniform trip count: one pass unless an ego has more than 32 pairs)
+                const int q = q0 + hl;
+                const bool on = fast && q < total;
+                const int code = on ? lds_pairs[q] : 0;
+                const int off = code >> 8, slot = code & 0xff;
+                const double hx0 = seg[0][off], hy0 = seg[1][off], hx1 = seg[2][off], hy1 = seg[3][off];
+                const double pair_r = shfl_d(my_r, slot);        // lane `slot` of the first half holds cfg.lookahead[slot]
+                if (on) {
+                    const SegHit ht = seg_hit(px, py, pair_r, hx0, hy0, hx1, hy1, off == 0, start_t);
+                    if (ht.hit) atomicMin(&lds_first[slot], off);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        F1P_LAT(3);
+        const int my_first = (fast && hl < nl) ? lds_first[hl] : 0x7fffffff;
+        my_found = my_first != 0x7fffffff;
+        int my_idx = my_first < nreg ? start_i + my_first : my_first - nreg - 1;
+        double dmin = nd;
+        {
+            const float ax = (float)(px - wrap_ax), ay = (float)(py - wrap_ay);
+            const float vx = (float)(wrap_bx - wrap_ax), vy = (float)(wrap_by - wrap_ay), l2 = vx * vx + vy * vy;
+            float t = l2 > 0.0f ? (ax * vx + ay * vy) * __builtin_amdgcn_rcpf(l2) : 0.0f;
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float qx = ax - t * vx, qy = ay - t * vy;
+            const double dw = (double)__builtin_amdgcn_sqrtf(qx * qx + qy * qy) * (1.0 - 1e-5);
+            if (!(dw >= dmin)) dmin = dw;
+        }
+        const bool surely_none = my_r < dmin - (1e-4 + 4e-6 * dmin);
+        unsigned long long rest = __ballot(hl < nl && !my_found && !surely_none);
+        while (rest) {                                            // no hit in the first 64 segments: the general scan by the whole wave, one (ego, radius) at a time
+            const int s = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const int src = s & 32;
+            const Intersect it = wave_intersect_boxed(readlane_d(px, src), readlane_d(py, src), cfg.lookahead[s & 31], wx, wy, a.wbox, n, readlane_d(tstart, src));
+            if (lane == s) { my_found = it.found; my_idx = it.i; }
+        }
+        const bool from_scan = my_found && my_first == 0x7fffffff;
+        if (hl < nl && my_found) {
+            if (from_scan) {
+                const int r = my_idx < 0 ? my_idx + n : my_idx;
+                c_x = wx[r]; c_y = wy[r]; c_psi = a.wpsi[r];
+            } else {
+                c_x = seg[0][my_first]; c_y = seg[1][my_first]; c_psi = seg[4][my_first];
+            }
+        }
+    }
+    else if (hl == 0) sincos(theta, &sn_t, &cs_t);             // (host goals: no look-ahead pass to hide the call behind)
+    F1P_LAT(4);
+    F1P_PPH();
+    sn_t = shfl_d(sn_t, hbase); cs_t = shfl_d(cs_t, hbase);
+    bool disc_not_clear = false;
+    if (mx.n_disc > 0 && mx.clear_bits) {                       // (wave-uniform)
+        bool ncl = false;
+        if (hl < mx.n_disc) {
+            const double o = (hl == 0 ? mx.disc_off[0] : hl == 1 ? mx.disc_off[1] : hl == 2 ? mx.disc_off[2] : mx.disc_off[3]) * a.grid.inv_res;
+            const int lx0 = cvt_flr_i32_f32((float)__builtin_fma(cs_t, o, txo)), ly0 = cvt_flr_i32_f32((float)__builtin_fma(sn_t, o, tyo));
+            ncl = true;
+            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
+                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) ncl = ((mx.clear_bits[(size_t)gy * a.grid.wwords + gw] >> (lx0 & 31)) & 1u) != 0u;
+            }
+        }
+        const unsigned long long bm = __ballot(ncl);
+        disc_not_clear = (hh ? (unsigned int)(bm >> 32) : (unsigned int)bm) != 0u;
+    }
+    if (a.prev_theta && !pm_done) {                             // (no scan trip at all: a raceline without a surviving chunk never happens, but the sums must not depend on it)
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { pm0 += shfl_xor_d(pm0, m); pm1 += shfl_xor_d(pm1, m); pm2 += shfl_xor_d(pm2, m); }
+    }
+    unsigned char* rec = recs + (size_t)e * ego_rec_stride(nl);
+    double* r_cen = reinterpret_cast<double*>(rec + sizeof(EgoRecHdr));
+    GoalFrame32* r_gf = reinterpret_cast<GoalFrame32*>(r_cen + 5 * (size_t)nl);
+    if (hl < nl && !a.goals) {
+        const int l = hl;
+        GoalFrame32 g;
+        g.cx = 0.0; g.cy = 0.0; g.nx = 0.0; g.ny = 0.0; g.gth = 0.f; g.ok = my_found ? 1 : 0;
+        double cxv = 0.0, cyv = 0.0, sp = 0.0, cp = 1.0, gth64 = 0.0;
+        if (g.ok) {
+            cxv = c_x; cyv = c_y;
+            const double cpv = c_psi;
+            sincos_core(cpv, &sp, &cp);
+            const double dx = cxv - px, dy = cyv - py;
+            g.cx = cs_t * dx + sn_t * dy; g.cy = -sn_t * dx + cs_t * dy;
+            g.nx = cs_t * (-sp) + sn_t * cp; g.ny = sn_t * sp + cs_t * cp;
+            gth64 = remainder_2pi(cpv - theta);
+            g.gth = (float)gth64;
+        }
+        if (valid) {
+            __builtin_nontemporal_store(cxv, r_cen + l); __builtin_nontemporal_store(cyv, r_cen + nl + l); __builtin_nontemporal_store(sp, r_cen + 2 * nl + l);
+            __builtin_nontemporal_store(cp, r_cen + 3 * nl + l); __builtin_nontemporal_store(gth64, r_cen + 4 * nl + l);
+            typedef double f1p_d2 __attribute__((ext_vector_type(2)));
+            typedef int f1p_i2 __attribute__((ext_vector_type(2)));
+            double* gd = reinterpret_cast<double*>(r_gf + l);
+            __builtin_nontemporal_store((f1p_d2){g.cx, g.cy}, reinterpret_cast<f1p_d2*>(gd));
+            __builtin_nontemporal_store((f1p_d2){g.nx, g.ny}, reinterpret_cast<f1p_d2*>(gd + 2));
+            __builtin_nontemporal_store((f1p_i2){__float_as_int(g.gth), g.ok}, reinterpret_cast<f1p_i2*>(gd + 4));
+        }
+    }
+    F1P_PPH();
+    if (hl == 0 && valid) {                                      // both egos' records in one pass
+        EgoXform xf;
+        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = txo;
+        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = tyo;
+        xf.tile_gx0 = tile_gx0; xf.tile_gy0 = tile_gy0;
+        mx.xf[e] = xf;
+        mx.ego_ni[e] = ni;
+        EgoRecHdr hd;
+        hd.px = px; hd.py = py; hd.theta = theta; hd.ct = cs_t; hd.st = sn_t;
+        const int den = S - 1 > 1 ? S - 1 : 1;
+        EgoParamsF2& p = hd.p;
+        p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
+        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
+        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
+        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;
+        p.clear_ds_cap = mx.clear_ds_cap;
+        p.inv_den = __builtin_amdgcn_rcpf((float)den);
+        p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
+        p.inv_nw = 1.0f / (float)cfg.n_width; p.pad0 = 0.f;
+        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
+        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+        p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
+        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = tile_gx0; p.tile_gy0 = tile_gy0;
+        p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
+        p.exact_all = (own_bit < 0 || disc_not_clear) ? 1 : (int)((own_word >> own_bit) & 1u);
+        *reinterpret_cast<EgoRecHdr*>(rec) = hd;
+    }
+    F1P_PPH();
+#ifdef F1P_PRO2_PHASES
+    if (hl == 0 && valid && mx.dbg_cost32) {
+        float* o = mx.dbg_cost32 + (size_t)e * nl * cfg.n_width;
+        for (int q = 0; q + 1 < npp; ++q) o[32 + q] = (float)(pph[q + 1] - pph[q]);
+        o[31] = (float)(pph[0] & 0xffffff);
+        o[40] = 0.f; o[41] = 1.f; o[42] = 0.f; o[43] = 0.f;
+        for (int q = 0; q < 4; ++q) o[48 + q] = (float)(lat[q + 1] - lat[q]);
+    }
+#endif
+#undef F1P_PPH
+#undef F1P_LAT
+}
 
 // candidate_goal for a queue entry, from the ego's record in LDS: the SAME fp64 operations in the same order -- the per-row ones
 // (sincos of the path heading, the goal heading's remainder) were done once per row by k_lattice_prologue
@@ -1677,7 +2140,7 @@ __global__ __launch_bounds__(256, F1P_MIX_FILTER_WAVES) void k_lattice_filter3(L
         c_st[c - c0] = (unsigned char)st;
         if ((st & 0x7f) == F1P_ST_PENDING || (st & 0x7f) == F1P_ST_PENDING2) my_hi_p = fminf(my_hi_p, hi);
         if (st == F1P_ST_FREE) t_free = fminf(t_free, hi);           // (only without a collision check)
-#if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES)
+#if !defined(F1P_MIX_DEBUG_END) && !defined(F1P_PRO_PHASES) && !defined(F1P_PRO2_PHASES)
         if (DBG && mx.dbg_cost32) mx.dbg_cost32[(size_t)e * C + c] = o.cost;
         if (DBG && mx.dbg_bound) mx.dbg_bound[(size_t)e * C + c] = o.ebound;
 #elif defined(F1P_MIX_DEBUG_END)
@@ -2958,7 +3421,14 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 if (mx.inc) mk.inc = mx.inc + (size_t)k * (inc_bytes / sizeof(double));
                 {
                     ak.pose_copy = d_pose_copy;
-                    hipLaunchKernelGGL(k_lattice_prologue, dim3((Ek + 3) / 4), dim3(256), 0, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
+                    // two egos per wave (round 6) wherever a half-wave holds the look-ahead rows; f1p_lattice_set_mode(3): the one-ego-per-wave kernels (A/B, tests)
+#ifdef F1P_PRO_PHASES
+                    const bool pro2 = false;
+#else
+                    const bool pro2 = F1P_PRO2 && ctx->lattice_mixed != 3 && cfg->n_lookahead <= 32 && ak.wbox != nullptr;
+#endif
+                    if (pro2) hipLaunchKernelGGL(k_lattice_prologue2, dim3((Ek + 7) / 8), dim3(256), 0, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
+                    else hipLaunchKernelGGL(k_lattice_prologue, dim3((Ek + 3) / 4), dim3(256), 0, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
                     if (d_pose_copy) { ak.poses = d_pose_copy; ak.pose_copy = nullptr; }      // the kernels behind the prologue read HBM
                     if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[1], st));
                     if (nch > 1 && k == 0) {                         // the side stream starts one stage behind (and after everything the caller enqueued before this plan)

@@ -32,11 +32,49 @@ def ctx(scene):
 def _both(ctx, poses, cfg, **kw):
     ctx.lattice_set_mode(0); a = ctx.lattice_plan(poses, cfg, **kw)
     ctx.lattice_set_mode(2); b = ctx.lattice_plan(poses, cfg, **kw)
+    ctx.lattice_set_mode(3); c = ctx.lattice_plan(poses, cfg, **kw)      # the one-ego-per-wave per-ego kernels (round 5's; mode 2 / 1: two egos per wave)
     ctx.lattice_set_mode(1)
-    assert sorted(a) == sorted(b)
+    assert sorted(a) == sorted(b) == sorted(c)
     for k in a:
         np.testing.assert_array_equal(b[k], a[k], err_msg=k)
+        np.testing.assert_array_equal(c[k], a[k], err_msg=k + " (one ego per wave)")
     return a
+
+
+def test_two_egos_per_wave_per_ego_kernels(scene):
+    """Round 6 (VERDICT r5 #2 i): k_lattice_prologue2 carries two egos per wave (half-waves).  Shapes its halves can disagree on: odd batches (the last
+    wave's second half idles), a single ego, egos at the seam of the closed raceline (wrap segments), egos far from it (no hit in the first 64 segments: the
+    whole-wave general scan, one (ego, radius) at a time), NaN / inf poses next to ordinary ones, 1 .. 32 look-ahead rows (33: the one-ego kernel), a short
+    raceline (no fast path), previous paths.  Every output bit-identical to the all-fp64 kernel and to the one-ego-per-wave kernels."""
+    from f1tenth_planning_amd.runtime import Context
+    rl, img, origin = scene
+    rng = np.random.default_rng(9)
+    with Context(0) as ctx:
+        ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+        cfg = synth.bench_lattice_cfg(n_cand=256, n_stations=50)
+        for E in (1, 2, 3, 7, 8, 9, 257, 515):
+            poses = synth.make_egos(rl, E, seed=E, pos_sigma=0.4, yaw_sigma=0.3)
+            a = _both(ctx, poses, cfg)
+            _both(ctx, poses, cfg, prev_theta=a["best_traj"][:, :, 2] + rng.normal(0, 0.05, (E, 50)))
+        E = 301
+        poses = synth.make_egos(rl, E, seed=77, pos_sigma=0.4, yaw_sigma=0.3)
+        seam = np.r_[np.arange(0, 40), np.arange(len(rl) - 80, len(rl))]
+        for k in range(0, 160, 2):                                    # every other ego at the seam: a wave holds one seam ego and one ordinary one
+            w = seam[k % len(seam)]
+            poses[k, :2] = rl[w, :2] + rng.normal(0, 0.2, 2); poses[k, 2] = rl[w, 3] + rng.normal(0, 0.2)
+        poses[161, :2] += [6.0, -5.0]; poses[163, :2] += [25.0, 25.0]; poses[164, :2] += 400.0      # far from the raceline: general scans / nothing at all
+        poses[170, 0] = np.nan; poses[173, 1] = np.inf; poses[176, 2] = np.nan; poses[177, 2] = 1e9
+        a = _both(ctx, poses, cfg)
+        assert (a["status"] == 0).mean() > 0.5 and a["status"][164] != 0
+        for nl, nw in ((1, 16), (5, 8), (31, 8), (32, 8), (33, 4), (64, 4)):
+            c2 = _abi.lattice_cfg(lookaheads=np.linspace(0.5, 4.5, nl), widths=np.linspace(-0.8, 0.8, nw), n_stations=30, weights=(1.0, 0.2, 0.2, 0.5))
+            _both(ctx, poses[:203], c2)
+        wide = _abi.lattice_cfg(lookaheads=np.r_[np.linspace(0.05, 0.3, 6), np.linspace(6.0, 14.0, 10)], widths=np.linspace(-1.0, 1.0, 16), n_stations=40, weights=(0.25,) * 4)
+        _both(ctx, poses, wide)                                          # radii below the distance to the raceline and radii beyond the first 64 segments
+    short = rl[::12][:100]                                                # 100 waypoints: no fast path (n <= 130), every row by the general scan
+    with Context(0) as ctx:
+        ctx.set_waypoints(short); ctx.set_grid(img, 0.058, origin, 206)
+        _both(ctx, synth.make_egos(short, 37, seed=4, pos_sigma=0.3), synth.bench_lattice_cfg(n_cand=64, n_stations=30))
 
 
 def test_bit_identical_to_the_all_fp64_kernel(ctx, scene):

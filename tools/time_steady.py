@@ -17,20 +17,24 @@ with Context(0) as ctx:
     b = (ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(8 * E * S * 4))
     for _ in range(300): ctx.lattice_plan_dev(d_poses, E, cfg, *b)          # clocks up
     line = [os.path.basename(os.environ.get("F1P_LIBRARY", "default")) + " pipe=%d" % PIPE]
-    for state in ("first", "steady"):
+    d_prev = None
+    for state in ("first", "steady", "explicit"):
+        if state == "explicit":                                # the steady state's previous path handed over explicitly (one buffer, read only; nothing kept)
+            d_prev = ctx.to_device(ctx.lattice_closed_loop_prev())
         ctx.lattice_set_closed_loop(state == "steady")
-        for _ in range(20): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+        kw = {"d_prev_theta": d_prev} if d_prev is not None else {}
+        for _ in range(20): ctx.lattice_plan_dev(d_poses, E, cfg, *b, **kw)
         ctx.sync(); ctx.timer_begin()
-        for _ in range(N): ctx.lattice_plan_dev(d_poses, E, cfg, *b)
+        for _ in range(N): ctx.lattice_plan_dev(d_poses, E, cfg, *b, **kw)
         ms = ctx.timer_end() / N
         ctx.lattice_profile(True)
         acc = np.zeros(4)
         for _ in range(50):
-            ctx.lattice_plan_dev(d_poses, E, cfg, *b); acc += np.array(ctx.lattice_profile(True, read=True))
+            ctx.lattice_plan_dev(d_poses, E, cfg, *b, **kw); acc += np.array(ctx.lattice_profile(True, read=True))
         ctx.lattice_profile(False)
         import time
         ts = []
         for _ in range(100):                                   # one plan at a time: launch + sync
-            t1 = time.perf_counter(); ctx.lattice_plan_dev(d_poses, E, cfg, *b); ctx.sync(); ts.append(time.perf_counter() - t1)
+            t1 = time.perf_counter(); ctx.lattice_plan_dev(d_poses, E, cfg, *b, **kw); ctx.sync(); ts.append(time.perf_counter() - t1)
         line.append("%s %.4f ms (one at a time, host: p50 %.4f) [pro %.1f flt %.1f ref %.1f sel %.1f us]" % ((state, ms, 1e3 * float(np.median(ts))) + tuple(1e3 * acc / 50)))
     print("  ".join(line))
