@@ -1,5 +1,5 @@
-"""The mixed-precision lattice schedule (f32 filter over every candidate, fp64 decision; csrc/k_lattice_mixed.hip
-k_lattice_prologue / _filter3 / _refine / _select): outputs bit-identical to the all-fp64 kernel, and the filter's own claims -- its cost
+"""The mixed-precision lattice schedule (f32 filter over every candidate, fp64 decision; csrc/k_lattice_mixed.hip and
+k_lattice_prologue / _filter3 / _refine / _select .hip): outputs bit-identical to the all-fp64 kernel, and the filter's own claims -- its cost
 bracket contains the fp64 cost, FREE candidates are collision-free in fp64, HIT candidates collide in fp64 -- checked through the
 debug hook of f1p_lattice_set_mode."""
 import copy

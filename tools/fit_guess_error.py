@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How far is the published initial guess A0 of the G1 clothoid fit from the root?  (CPU, numpy; seconds.)
 
-k_lattice_mixed.hip::g1_fit_f32 models the residual g(A0 + d) as a CUBIC in d (round 6) and takes two Newton steps from the linear root: both rest on
+k_lattice_filter3.hip::g1_fit_f32 models the residual g(A0 + d) as a CUBIC in d (round 6) and takes two Newton steps from the linear root: both rest on
 |d| <= 0.05 and |dg/dA| >= 0.02.  This script measures |d| = |A - A0| and |dg/dA (A0)| over the goal families the tests and the bench use -- the bench
 scene's device-sampled goals (via the oracle's goal sampler), the random goal boxes of tests/test_gpu_lattice.py, tests/test_gpu_lattice_mixed.py and
 tests/test_gpu_lattice_oracle_shapes.py, and a tight / sharp configuration -- with a 64-node Gauss-Legendre rule and ten Newton steps in fp64.

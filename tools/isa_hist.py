@@ -2,7 +2,7 @@
 """Static instruction-class histogram of one kernel's gfx950 listing, per basic block and in total (the classes the issue-cycle
 table of profiles/r03_valu_issue_cycles.txt prices differently).
 
-    hipcc --offload-arch=gfx950 <flags of the Makefile> -S --cuda-device-only k_lattice_mixed.hip -o /tmp/klm.s
+    hipcc --offload-arch=gfx950 <flags of the Makefile> -S --cuda-device-only k_lattice_filter3.hip -o /tmp/klm.s        (or k_lattice_prologue / _refine / _select .hip)
     python tools/isa_hist.py /tmp/klm.s k_lattice_filter3ILi2ELb0ELb0 [--min 30]
 
 classes: fast (v_add/sub/mul/fmac/fma_f32, and/or/xor, lshrrev, add_u32, mov -- 2.5 cycles), slow (min/max, cvt, cmp, cndmask, bfe, med3,
