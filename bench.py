@@ -1520,7 +1520,7 @@ def main_lattice(args):
             "pcie_inclusive_value": pcie_value,
             "plan_latency_host_boundary": lat,
             "schedule": ("all fp64" + (" + branch and bound" if args.prune else "")) if not default_sched else
-                        ("k_lattice_prologue (fp64, wave per ego: nearest segment, look-ahead centres, goal frames, moments of the previous path) -> "
+                        ("k_lattice_prologue2 (fp64, two egos per wave: nearest segment, look-ahead centres, goal frames, moments of the previous path) -> "
                          "k_lattice_filter3 (f32, thread per candidate: G1 fit on one 16-node pass, closed-form curvature and similarity terms, cost "
                          "bracket; then the station pass -- integrated pieces + clearance look-ups per filter_shape, a wave per selected candidate -- "
                          "for the few candidates whose bracket reaches below the best collision-free one) -> k_lattice_refine (fp64, the reference's "

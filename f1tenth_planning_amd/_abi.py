@@ -179,6 +179,7 @@ PROTOTYPES = {
     "f1p_intersect_point_batch": (C.c_int, [_P, _P, _P, _I, _D, _I, _P, _P, _P, _P]),
     "f1p_pure_pursuit_batch": (C.c_int, [_P, _P, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
     "f1p_pure_pursuit_dev": (C.c_int, [_P, _P, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
+    "f1p_pure_pursuit_set_form": (C.c_int, [_P, _I]),
     "f1p_stanley_batch": (C.c_int, [_P, _P, _I, _D, _D, _P, _P, _P]),
     "f1p_lqr_batch": (C.c_int, [_P, _P, _P, _I, _D, _D, _P, _D, _I, _D, _P, _P, _P]),
     "f1p_lattice_plan_batch": (C.c_int, [_P, _P, _P, _P, _I, C.POINTER(LatticeCfg)] + [_P] * 9),

@@ -987,6 +987,14 @@ int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* 
     return F1P_OK;
 }
 
+int f1p_pure_pursuit_set_form(f1p_ctx* ctx, int32_t egos_per_wave) {
+    if (!ctx) return F1P_EINVAL;
+    if (egos_per_wave != 0 && egos_per_wave != 1 && egos_per_wave != 4 && egos_per_wave != 8 && egos_per_wave != 16)
+        return set_error(ctx, F1P_EINVAL, "egos per wave must be 0 (by batch size), 1, 4, 8 or 16");
+    ctx->pursuit_form = egos_per_wave;
+    return F1P_OK;
+}
+
 int f1p_lattice_set_split(f1p_ctx* ctx, int32_t groups) {
     if (!ctx) return F1P_EINVAL;
     if (groups < 0 || groups > 16) return set_error(ctx, F1P_EINVAL, "groups must be in [0, 16]");

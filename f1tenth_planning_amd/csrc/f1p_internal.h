@@ -79,6 +79,7 @@ struct f1p_ctx {
 
     // mixed-precision lattice schedule (f32 filter + fp64 decision): 0 = off, 1 = from F1P_MIX_MIN_EGOS_V3 egos (default: one), 2 = always
     int lattice_mixed = 1;
+    int pursuit_form = 0;                // f1p_pure_pursuit_set_form: egos per wave (0 = by batch size)
     char* d_mix_scratch = nullptr;     // queue counter | per-ego (base, n, nearest) | refinement queue
     size_t mix_scratch_bytes = 0;
     int mix_last_E = 0;                // batch size of the last mixed-schedule plan (f1p_lattice_debug_queue)

@@ -308,6 +308,10 @@ class Context:
                                                   float(max_reacquire), p(d_steer), p(d_speed), p(d_near_idx), p(d_la_idx),
                                                   p(d_status)))
 
+    def pure_pursuit_set_form(self, egos_per_wave=0):
+        """Egos per wave of the batched pure pursuit: 0 (default) by batch size, 1 = k_pure_pursuit, 4 | 8 | 16 = k_pure_pursuit16<G>.  Identical outputs (A/B, tests)."""
+        self._check(self.lib.f1p_pure_pursuit_set_form(self.h, int(egos_per_wave)))
+
     # ---- Stanley / LQR (SURVEY 8f rank 1) --------------------------------------------------------------------
     def stanley(self, states, wheelbase=0.33, k_path=5.0):
         st = _f64(states, (-1, 4)); E = st.shape[0]

@@ -235,6 +235,11 @@ int f1p_pure_pursuit_batch(f1p_ctx* ctx, const double* poses, int32_t E, double 
 int f1p_pure_pursuit_dev(f1p_ctx* ctx, const double* d_poses, int32_t E, double lookahead, double wheelbase,
                          double max_reacquire, double* d_steer, double* d_speed, int32_t* d_near_idx,
                          int32_t* d_la_idx, int32_t* d_status);
+/* Kernel form of f1p_pure_pursuit_*: egos per wave.  0 (default) = by batch size (1 below 8 192 egos, then 4 / 8 / 16 from 8 192 / 65 536 /
+ * 262 144: a wave takes its egos one after the other through the 64-lane scans and runs plan()'s scalar part for all of them in one pass --
+ * k_pure_pursuit16<G>, racelines of up to 4 097 waypoints), 1 = one ego per wave (k_pure_pursuit), 4 | 8 | 16 = that many.  Identical outputs
+ * in every form (A/B timing; the tests compare them). */
+int f1p_pure_pursuit_set_form(f1p_ctx* ctx, int32_t egos_per_wave);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8f rank 1 -- the two other waypoint trackers, batched on the same nearest-segment kernel.

@@ -98,6 +98,38 @@ def test_pure_pursuit_vs_oracle_4096(ctx, orc):
         assert i[e] == i0 and d[e] == d0 and t[e] == t0 and (pr[e] == p0).all()
 
 
+@pytest.mark.parametrize("n_pts", [2, 3, 66, 400, 1692, 4097, 4200])
+def test_several_egos_per_wave_forms_are_identical(ctx, orc, n_pts):
+    """Round 6: k_pure_pursuit16<G> (G = 4 / 8 / 16 egos per wave: the 64-lane scans ego after ego, PurePursuitPlanner.plan's scalar part -- pure_pursuit.py:70-83,
+    :116-120 -- for all G in one pass) against k_pure_pursuit (one ego per wave) bit for bit and against the oracle, on batches that are no multiple of
+    G, every branch of plan() (intersect / reacquire / none), NaN and inf poses, short racelines and one beyond the 64-chunk limit (the launcher's fallback)."""
+    rng = np.random.default_rng(n_pts)
+    if n_pts >= 300:
+        rl = synth.make_raceline(seed=n_pts % 7, n_pts=n_pts)
+    else:                                                                       # a short open polyline
+        s = np.linspace(0.0, 0.6 * n_pts, n_pts)
+        rl = np.column_stack([s, 0.4 * np.sin(0.3 * s), np.full(n_pts, 3.0), np.zeros(n_pts), np.zeros(n_pts)])
+    ctx.set_waypoints(rl)
+    for E in (1, 15, 16, 17, 333):
+        k = rng.integers(0, len(rl), E)
+        poses = np.column_stack([rl[k, 0] + rng.normal(0, 0.4, E), rl[k, 1] + rng.normal(0, 0.4, E), rng.uniform(-np.pi, np.pi, E)])
+        if E > 20:
+            poses[3, :2] += 9.0; poses[5, :2] += 500.0                         # reacquire / none
+            poses[7, 0] = np.nan; poses[8, 1] = np.inf; poses[9, 2] = np.nan
+        for L in (0.8, 2.5):
+            ctx.pure_pursuit_set_form(1); a = ctx.pure_pursuit(poses, L)
+            for G in (4, 8, 16):
+                ctx.pure_pursuit_set_form(G); b = ctx.pure_pursuit(poses, L)
+                for key in a:
+                    np.testing.assert_array_equal(b[key], a[key], err_msg=f"{key} (E {E}, lookahead {L}, {G} egos per wave)")
+            ctx.pure_pursuit_set_form(0)
+            ok = np.isfinite(poses).all(1)
+            want = orc.pure_pursuit_batch(poses[ok], rl, L, nthreads=4)
+            for key in ("near_idx", "la_idx", "status"):
+                np.testing.assert_array_equal(b[key][ok], want[key])
+            np.testing.assert_allclose(b["steer"][ok], want["steer"], rtol=0, atol=1e-12)
+
+
 def test_edge_cases(ctx):
     rl = synth.make_raceline(seed=0)
     ctx.set_waypoints(rl)
