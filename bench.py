@@ -78,6 +78,7 @@ COMPACT_SCALARS = (
     "scene_sweep_worst_vs_centred", "scene_sweep_all_bit_identical", "scene_sweep_oracle_mismatches",
     "kmpc_c4_streamed_ms", "kmpc_c4_generated_ms", "kmpc_c4_cache_stream_frac", "kmpc_c4_generated_roofline_frac",
     "kmpc_stream8192_ms", "kmpc_stream8192_hbm_frac", "kmpc_stream8192_shader_mhz",
+    "pursuit_65536_ms", "pursuit_plans_per_s", "pursuit_near_idx_mismatches",
     "all_fp64_ms", "every_station_ms", "first_plan_ms_per_plan", "two_plans_in_flight_ms_per_plan",
     "host_goals_ms_per_plan", "cubic_ms_per_plan", "footprint_ms_per_plan", "materialised_hbm_frac", "blocked_egos",
 )
@@ -765,6 +766,38 @@ def leg_kmpc_stream8192(rk, args, steps=200, E=8192):
         ctx.close()
 
 
+def leg_pursuit(rk, rl, steps=200, E=65536):
+    """north_star's first path -- PurePursuitPlanner.plan (control/pure_pursuit/pure_pursuit.py:85-122) -- batched: E egos on the bench's raceline, one
+    k_pure_pursuit16<G> launch per step (G egos per wave by batch size), in the DEFAULT run so that the driver's record carries the row; the nearest
+    indices and the steering against the oracle on the first 4096 egos.  (`--workload pursuit` is the same workload as a line of its own.)"""
+    import numpy as np
+    from f1tenth_planning_amd import synth
+    poses = synth.make_egos(rl, E, seed=3)[:, :3]
+    ctx = rk.open_context()
+    try:
+        ctx.set_waypoints(rl)
+        d_poses = ctx.to_device(poses)
+        d_steer, d_speed, d_near, d_la, d_st = ctx.alloc(8 * E), ctx.alloc(8 * E), ctx.alloc(4 * E), ctx.alloc(4 * E), ctx.alloc(4 * E)
+        for _ in range(20):
+            ctx.pure_pursuit_dev(d_poses, E, 0.8, d_steer, d_speed, d_near, d_la, d_st)
+        ctx.sync(); ctx.timer_begin()
+        for _ in range(steps):
+            ctx.pure_pursuit_dev(d_poses, E, 0.8, d_steer, d_speed, d_near, d_la, d_st)
+        ms = ctx.timer_end() / steps
+        out = {"workload": f"pure pursuit: {E} egos on a {len(rl)}-point raceline (BASELINE configs[0], batched)", "kernel_ms": ms, "steps": steps,
+               "plans_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_launch": 52 * E,
+               "note": "fp64 VALU issue-bound (chunk-pruned nearest scan, intersect_point's 64-segment steps, get_actuation): 52 B per ego of HBM traffic is 1 % of the 8 TB/s roof"}
+        from oracle import oracle
+        n_or = min(E, 4096)
+        want = oracle.pure_pursuit_batch(poses[:n_or], rl, 0.8, nthreads=oracle.max_threads())
+        out["parity"] = {"egos_checked": n_or, "near_idx_mismatches": int((d_near.download(np.int32, (E,))[:n_or] != want["near_idx"]).sum()),
+                         "status_mismatches": int((d_st.download(np.int32, (E,))[:n_or] != want["status"]).sum()),
+                         "max_abs_steer_diff": float(np.abs(d_steer.download(np.float64, (E,))[:n_or] - want["steer"]).max())}
+        return out
+    finally:
+        ctx.close()
+
+
 def leg_scene_sweep(rl, img, res, origin, cfg, E, C, S, steps, warmup=10, scenes=None, oracle_egos=256, order=True, device=0, clearance=None):
     """the headline workload (E x C x S, steady state of a closed loop, default schedule) on scenes it was NOT tuned on.
       centred       today's bench scene (sigma 0.3 m around the raceline, nothing inside the corridor)
@@ -1431,11 +1464,13 @@ def main_lattice(args):
     two_in_flight = None
     if secondary and not cand_sharded and not (args.all_fp64 or args.prune):
         two_in_flight = leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, max(20, min(args.steps, 200)))
-    kmpc_s8192 = None
+    kmpc_s8192 = pursuit = None
     if secondary and not cand_sharded:
         kmpc_c4 = leg_kmpc_c4(rk, args, max(10, min(args.steps, 100)))
         if rank == 0 and world == 1 and not args.only_timed:
             kmpc_s8192 = leg_kmpc_stream8192(rk, args)
+            if not args.no_cpu_baseline:
+                pursuit = leg_pursuit(rk, rl)
 
     if rank == 0:
         steps_total = float(E) * C * S * args.steps * (1 if cand_sharded else world)
@@ -1540,6 +1575,7 @@ def main_lattice(args):
             "exchange_selftest": selftest,
             "kmpc_c4": kmpc_c4,
             "kmpc_stream8192": kmpc_s8192,
+            "pure_pursuit_65536": pursuit,
             "two_plans_in_flight": two_in_flight,
             "audit": audit,
             "scene_sweep": scene_sweep,
@@ -1577,6 +1613,7 @@ def main_lattice(args):
             "kmpc_c4_cache_stream_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
             "kmpc_stream8192_ms": _g(kmpc_s8192, "kernel_ms"), "kmpc_stream8192_hbm_frac": _g(kmpc_s8192, "roofline", "frac"),
             "kmpc_stream8192_shader_mhz": _g(kmpc_s8192, "shader_clock_mhz", "median"),
+            "pursuit_65536_ms": _g(pursuit, "kernel_ms"), "pursuit_plans_per_s": _g(pursuit, "plans_per_s"), "pursuit_near_idx_mismatches": _g(pursuit, "parity", "near_idx_mismatches"),
             "host_boundary_d2h_ms": (lat["p50_ms"] - lat["without_best_traj"]["p50_ms"]) if (lat and _g(lat, "without_best_traj", "p50_ms")) else None,
         })
         if variants:
