@@ -62,8 +62,10 @@ __device__ __forceinline__ bool split_merge(const LatticeArgs& a, int e, int g, 
 }
 
 // FOOT = oriented footprint (f1p_set_footprint): further instantiations, so the point-test kernels keep their register budget.
+// (round 6: the materialised clothoid instantiation with the footprint is held to TWO waves per SIMD -- at three it carried 23 spilled VGPRs / 104 B of scratch;
+// spill-free it is 1 % faster, tools/time_mat_footprint.py 0.2373 -> 0.2349 ms at 1024 egos.  The cubic one, 12 spills at three waves, measured 4 % SLOWER at two and stays.)
 template <bool STAGING, int GEN, bool PRUNE = false, bool FOOT = false>
-__global__ __launch_bounds__(256, (STAGING && GEN != F1P_GEN_CLOTHOID && !FOOT) ? F1P_K3_WAVES_STAGE2 : ((STAGING || FOOT) ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES)) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
+__global__ __launch_bounds__(256, (STAGING && GEN != F1P_GEN_CLOTHOID && !FOOT) ? F1P_K3_WAVES_STAGE2 : ((STAGING && FOOT && GEN == F1P_GEN_CLOTHOID) ? 2 : ((STAGING || FOOT) ? F1P_K3_WAVES_STAGE : F1P_K3_WAVES))) void k_lattice(LatticeArgs a, f1p_lattice_cfg cfg) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // ---- LDS carve-up (all offsets multiples of 8) -------------------------------------------------
     double* red_d = reinterpret_cast<double*>(lds_raw);          // [4]

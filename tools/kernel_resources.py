@@ -19,7 +19,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
 # scratch bytes per lane a kernel may carry (mangled-name substring -> budget).  Everything else must have none.
-#   ILb1E...            the materialising variants (all_traj requested): HBM-write-bound, not VALU-bound
+#   ILb1E...            the materialising variants (all_traj requested): HBM-write-bound, not VALU-bound.  Round 6: 160 -> 56 -- the clothoid + footprint
+#                       instantiation is spill-free at two waves per SIMD (was 104 B); what is left is cubic + footprint's 52 B (12 VGPRs; two waves measured 4 % slower)
 #   k_kmpc_*            spills sit in the once-per-workgroup setup blocks and the rarely taken serial fp64 fallback, not in the
 #                       filter loop (tools/isa_loops.py); a lower register cap was measured slower (LABNOTES.md 5b)
 #   k_lattice / g1      the out-of-line fp64 fit's 8-byte frame
@@ -27,7 +28,7 @@ CSRC = os.path.join(ROOT, "f1tenth_planning_amd", "csrc")
 #                       goals (<CR, true, true>), cubic + footprint and footprint + host goals -- production plan shapes of the add_sample_function
 #                       path -- so those shapes carry this budget (8-24 B of scratch); the spill-free claim holds for the device-goal shapes
 #                       (<CR, false, false, GEN, FOOT = false>: 0 scratch, asserted below by the default budget of 0)
-BUDGET = {"ILb1E": 160, "k_kmpc_plan_gen": 32, "k_kmpc_shoot_mixed": 0, "k_clothoid_g1": 8, "9k_latticeILb0E": 8,
+BUDGET = {"ILb1E": 56, "k_kmpc_plan_gen": 32, "k_kmpc_shoot_mixed": 0, "k_clothoid_g1": 8, "9k_latticeILb0E": 8,
           "k_lattice_filter3ILi1ELb1E": 24, "k_lattice_filter3ILi2ELb1E": 24,
           "k_lattice_filter3ILi1ELb0ELb0ELi0ELb1E": 8, "k_lattice_filter3ILi2ELb0ELb0ELi0ELb1E": 8}   # (the instantiations WITH test hooks -- incl. the host-goal shapes; device goals, point footprint: 0)
 # The headline kernels (k_lattice_prologue, k_lattice_filter3<CR, false, false, GEN, false>) carry NO scratch and no VGPR spills;
