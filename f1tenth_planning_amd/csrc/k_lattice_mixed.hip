@@ -279,7 +279,9 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
 #ifdef F1P_PRO_PHASES
                     const bool pro2 = false;
 #else
-                    const bool pro2 = F1P_PRO2 && ctx->lattice_mixed != 3 && cfg->n_lookahead <= 32 && ak.wbox != nullptr;
+                    // (from F1P_PRO2_MIN_EGOS egos, where the one-ego kernel's waves start taking turns on a SIMD: below, its shorter chain wins -- 1024 egos
+                    // 10.9 against 11.9 us, 2048: 11.6 / 11.9, 4096: 15.4 / 14.3, 8192: 23.3 / 18.9; f1p_lattice_set_mode(2) takes the two-ego kernel at any size)
+                    const bool pro2 = F1P_PRO2 && ctx->lattice_mixed != 3 && cfg->n_lookahead <= 32 && ak.wbox != nullptr && (Ek >= F1P_PRO2_MIN_EGOS || ctx->lattice_mixed == 2);
 #endif
                     mixed_launch_prologue(pro2, Ek, st, ak, *cfg, mk, (unsigned char*)ctx->d_rec_scratch);
                     if (d_pose_copy) { ak.poses = d_pose_copy; ak.pose_copy = nullptr; }      // the kernels behind the prologue read HBM

@@ -132,6 +132,9 @@ namespace f1p {
 #ifndef F1P_PRO2
 #define F1P_PRO2 1              // k_lattice_prologue2 (two egos per wave) where it applies; 0: k_lattice_prologue always (A/B)
 #endif
+#ifndef F1P_PRO2_MIN_EGOS
+#define F1P_PRO2_MIN_EGOS 3072  // ... from this batch (chunk) size in the default mode: more than three one-ego waves per SIMD on 256 CUs
+#endif
 #define F1P_ST_FREE 0
 #define F1P_ST_HIT 1
 #define F1P_ST_UNSURE 2

@@ -418,8 +418,8 @@ class Context:
         return out
 
     def lattice_set_mode(self, mixed=1, d_cost32=None, d_state=None):
-        """0: all fp64; 1 (default): f32 filter + fp64 decision, every plan shape from one ego; 2: always; 3: as 2 with one ego per wave in the
-        per-ego kernels (A/B, tests).  Optional device buffers [E][C] receive
+        """0: all fp64; 1 (default): f32 filter + fp64 decision, every plan shape from one ego (two-egos-per-wave prologue from 3072 egos); 2: always,
+        two-ego prologue at any size; 3: as 2 with the one-ego-per-wave prologue (A/B, tests).  Optional device buffers [E][C] receive
         the filter's costs (f32) and states (i32)."""
         self._check(self.lib.f1p_lattice_set_mode(self.h, int(mixed), None if d_cost32 is None else d_cost32.ptr,
                                                   None if d_state is None else d_state.ptr))

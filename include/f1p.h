@@ -326,9 +326,10 @@ int f1p_lattice_fetch_traj(f1p_ctx* ctx, double* best_traj, int32_t E, int32_t S
  *     occupancy) that brackets each candidate's fp64 cost and classifies its collision status as certain / uncertain; only the
  *     candidates that can still be the minimum (typically 1-3 per ego) are re-evaluated by the fp64 arithmetic of the plain
  *     kernel, and the decision is taken on those fp64 costs -- every output is bit-identical to mixed = 0;
- *   mixed = 2: the same for any batch size;  mixed = 0: all fp64 (with cfg.prune: branch and bound);
- *   mixed = 3: as 2 with the one-ego-per-wave form of the per-ego kernels (k_lattice_prologue instead of k_lattice_prologue2's two egos
- *     per wave): identical outputs, kept for A/B timing and as the tests' second implementation.
+ *   mixed = 2: the same for any batch size, with the two-egos-per-wave prologue (k_lattice_prologue2) at any batch size too (mixed = 1 takes it
+ *     from 3072 egos, where it is the faster one);  mixed = 0: all fp64 (with cfg.prune: branch and bound);
+ *   mixed = 3: as 2 with the one-ego-per-wave prologue (k_lattice_prologue) at any batch size: identical outputs, kept for A/B timing and as
+ *     the tests' second implementation.
  * d_cost32 [E][C] f32 and d_state [E][C] i32 (device pointers, nullable) receive the filter's costs and states
  * (0 free, 1 hit, 2 unsure, 3 infeasible) of the following launches: the hook the tests calibrate the margins with. */
 int f1p_lattice_set_mode(f1p_ctx* ctx, int32_t mixed, float* d_cost32, int32_t* d_state);
