@@ -71,6 +71,25 @@ def test_two_egos_per_wave_per_ego_kernels(scene):
             _both(ctx, poses[:203], c2)
         wide = _abi.lattice_cfg(lookaheads=np.r_[np.linspace(0.05, 0.3, 6), np.linspace(6.0, 14.0, 10)], widths=np.linspace(-1.0, 1.0, 16), n_stations=40, weights=(0.25,) * 4)
         _both(ctx, poses, wide)                                          # radii below the distance to the raceline and radii beyond the first 64 segments
+        # a plan cut into chunks of egos (f1p_lattice_set_pipeline: every chunk's kernels start at its own first ego -- odd chunk ends, a last wave with one ego)
+        for chunks, E in ((2, 515), (3, 301), (4, 1030), (8, 203)):
+            p2 = synth.make_egos(rl, E, seed=50 + chunks, pos_sigma=0.4, yaw_sigma=0.3)
+            ctx.lattice_set_pipeline(chunks)
+            try:
+                a2 = _both(ctx, p2, cfg)
+                _both(ctx, p2, cfg, prev_theta=a2["best_traj"][:, :, 2] + rng.normal(0, 0.05, (E, 50)))
+            finally:
+                ctx.lattice_set_pipeline(1)
+    # long racelines: more chunk boxes than a half-wave holds (41 > 32: the scan's second box pass) and more than a wave holds (68 > 64: the general look-ahead scan)
+    for n_pts in (2600, 4300):
+        long_rl = synth.make_raceline(seed=3, n_pts=n_pts)
+        res = 0.35
+        img2, origin2 = synth.make_grid(long_rl[:, :2], size=(2000, 2000), resolution=res, half_width=1.4)
+        with Context(0) as ctx:
+            ctx.set_waypoints(long_rl); ctx.set_grid(img2, res, origin2, 206)
+            pl = synth.make_egos(long_rl, 131, seed=n_pts, pos_sigma=0.3, yaw_sigma=0.3)
+            al = _both(ctx, pl, synth.bench_lattice_cfg(n_cand=64, n_stations=30))
+            assert len(np.unique(al["near_idx"] // 64)) > 33              # the egos do spread over more chunks than one box pass covers
     short = rl[::12][:100]                                                # 100 waypoints: no fast path (n <= 130), every row by the general scan
     with Context(0) as ctx:
         ctx.set_waypoints(short); ctx.set_grid(img, 0.058, origin, 206)
