@@ -78,7 +78,7 @@ COMPACT_SCALARS = (
     "scene_sweep_worst_vs_centred", "scene_sweep_all_bit_identical", "scene_sweep_oracle_mismatches",
     "kmpc_c4_streamed_ms", "kmpc_c4_generated_ms", "kmpc_c4_cache_stream_frac", "kmpc_c4_generated_roofline_frac",
     "kmpc_stream8192_ms", "kmpc_stream8192_hbm_frac", "kmpc_stream8192_shader_mhz",
-    "pursuit_65536_ms", "pursuit_plans_per_s", "pursuit_near_idx_mismatches",
+    "pursuit_65536_ms", "pursuit_plans_per_s", "pursuit_valu_issue_frac", "pursuit_near_idx_mismatches",
     "all_fp64_ms", "every_station_ms", "first_plan_ms_per_plan", "two_plans_in_flight_ms_per_plan",
     "host_goals_ms_per_plan", "cubic_ms_per_plan", "footprint_ms_per_plan", "materialised_hbm_frac", "blocked_egos",
 )
@@ -611,6 +611,23 @@ def kmpc_valu_roofline(pmc, kernel_ms, E, R, T):
     return v
 
 
+def pursuit_valu_roofline(kernel_ms, E):
+    """roofline of the batched pure pursuit from the newest committed PMC profile of this configuration (profiles/r*_pursuit_pmc.json): fp64 code, so the
+    reference is the one-pass issue rate of an fp64 / VOP3 instruction (4.3 cycles per wave64 instruction per SIMD, profiles/r03_valu_issue_cycles.txt)"""
+    pmc = load_pmc({"egos": E, "workload": "pursuit"})
+    if not (pmc and pmc.get("SQ_INSTS_VALU")):
+        return None
+    tl = pmc["SQ_INSTS_VALU"] * 64.0 / (kernel_ms * 1e-3) / 1e12
+    traffic = None
+    if pmc.get("FETCH_SIZE_KiB") is not None and pmc.get("WRITE_SIZE_KiB") is not None:
+        traffic = int((pmc["FETCH_SIZE_KiB"] * 2 + pmc["WRITE_SIZE_KiB"]) * 1024)      # gfx950 wide-read correction x2 (MI355X_MICROARCH.md)
+    return {"bound": "valu", "achieved": tl, "peak": VALU_PEAK_SLOW_CLASS, "unit": "T lane-instr/s", "frac": tl / VALU_PEAK_SLOW_CLASS,
+            "kernel": pmc["kernel"].split("(")[0].replace("void ", "").replace("f1p::", ""),
+            "kernel_ms": kernel_ms, "valu_instr_per_ego": pmc["SQ_INSTS_VALU"] / float(E), "traffic": traffic, "algorithmic_bytes_per_launch": 52 * E,
+            "traffic_source": pmc["source"],
+            "peak_definition": "fp64 / VOP3 issue rate measured on this chip: one wave64 instruction per 4.3 cycles per SIMD at 2.4 GHz; 52 B per ego of HBM traffic is 1 % of the 8 TB/s roof"}
+
+
 def leg_kmpc_c4(rk, args, steps):
     """BASELINE configs[4]: kinematic-MPC random shooting, 1024 egos x 512 rollouts x 30 steps IN TOTAL, 1024 / N egos per GPU.  Two
     variants: controls streamed from HBM (8 B per rollout-step) and -- the planner's own path, KMPCPlanner.plan -- controls generated in the
@@ -785,7 +802,7 @@ def leg_pursuit(rk, rl, steps=200, E=65536):
             ctx.pure_pursuit_dev(d_poses, E, 0.8, d_steer, d_speed, d_near, d_la, d_st)
         ms = ctx.timer_end() / steps
         out = {"workload": f"pure pursuit: {E} egos on a {len(rl)}-point raceline (BASELINE configs[0], batched)", "kernel_ms": ms, "steps": steps,
-               "plans_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_launch": 52 * E,
+               "plans_per_s": E / (ms * 1e-3), "algorithmic_bytes_per_launch": 52 * E, "roofline": pursuit_valu_roofline(ms, E),
                "note": "fp64 VALU issue-bound (chunk-pruned nearest scan, intersect_point's 64-segment steps, get_actuation): 52 B per ego of HBM traffic is 1 % of the 8 TB/s roof"}
         from oracle import oracle
         n_or = min(E, 4096)
@@ -1613,7 +1630,7 @@ def main_lattice(args):
             "kmpc_c4_cache_stream_frac": _g(kmpc_c4, "roofline", "frac"), "kmpc_c4_generated_roofline_frac": _g(kmpc_c4, "generated_in_kernel", "roofline", "frac"),
             "kmpc_stream8192_ms": _g(kmpc_s8192, "kernel_ms"), "kmpc_stream8192_hbm_frac": _g(kmpc_s8192, "roofline", "frac"),
             "kmpc_stream8192_shader_mhz": _g(kmpc_s8192, "shader_clock_mhz", "median"),
-            "pursuit_65536_ms": _g(pursuit, "kernel_ms"), "pursuit_plans_per_s": _g(pursuit, "plans_per_s"), "pursuit_near_idx_mismatches": _g(pursuit, "parity", "near_idx_mismatches"),
+            "pursuit_65536_ms": _g(pursuit, "kernel_ms"), "pursuit_plans_per_s": _g(pursuit, "plans_per_s"), "pursuit_valu_issue_frac": _g(pursuit, "roofline", "frac"), "pursuit_near_idx_mismatches": _g(pursuit, "parity", "near_idx_mismatches"),
             "host_boundary_d2h_ms": (lat["p50_ms"] - lat["without_best_traj"]["p50_ms"]) if (lat and _g(lat, "without_best_traj", "p50_ms")) else None,
         })
         if variants:
@@ -1701,7 +1718,7 @@ def main_pursuit(args):
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"pure pursuit: {E} egos per GPU on a {len(rl)}-point raceline (BASELINE configs[0], batched)"},
-               "kernel_ms": kernel_ms}
+               "kernel_ms": kernel_ms, "roofline": pursuit_valu_roofline(kernel_ms, E)}
         if not args.no_cpu_baseline:
             from oracle import oracle
             n_cpu = min(E, 65536)
