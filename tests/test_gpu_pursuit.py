@@ -143,6 +143,10 @@ def test_edge_cases(ctx):
         ctx.set_waypoints(np.zeros((10, 2)))                                  # pure_pursuit.py:101-102
     with pytest.raises(ValueError):
         ctx.set_waypoints(np.zeros((1, 3)))
+    with pytest.raises(Exception, match="egos per wave"):                     # f1p_pure_pursuit_set_form: 0 | 1 | 4 | 8 | 16
+        ctx.pure_pursuit_set_form(3)
+    with pytest.raises(Exception, match="mixed must be"):                     # f1p_lattice_set_mode: 0 .. 3
+        ctx.lattice_set_mode(4)
 
 
 def test_planner_class_drop_in(golden, tracks):
