@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-phase shader-clock breakdown of k_lattice_prologue (needs the -DF1P_PRO_PHASES build:
-   make -C f1tenth_planning_amd/csrc LIB=libf1p_pph.so OBJDIR=build_pph EXTRA=-DF1P_PRO_PHASES;  F1P_LIBRARY=.../libf1p_pph.so)."""
+"""Per-phase shader-clock breakdown of the per-ego prologue.  Needs a build with the phase stamps:
+   -DF1P_PRO_PHASES   k_lattice_prologue  (one ego per wave; the launcher takes that kernel in this build)
+   -DF1P_PRO2_PHASES  k_lattice_prologue2 (two egos per wave; both egos of a wave report the wave's stamps)
+   make -C f1tenth_planning_amd/csrc LIB=libf1p_pph.so OBJDIR=build_pph EXTRA=-DF1P_PRO2_PHASES;  F1P_LIBRARY=.../libf1p_pph.so python tools/prologue_phases.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
