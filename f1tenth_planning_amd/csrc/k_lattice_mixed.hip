@@ -300,7 +300,7 @@ int launch_lattice_mixed(f1p_ctx* ctx, LatticeArgs& a, const f1p_lattice_cfg* cf
                 if (prof) F1P_HIP(ctx, hipEventRecord(ctx->ev_prof[2], st));
                 size_t rb = (region + 3) / 4;                            // grid-stride over the queue: a few entries per ego in the usual case
                 rb = (rb + 15) & ~(size_t)15;                            // groups (4 or 16 per workgroup) a multiple of the shard count
-                const size_t rb_max = (size_t)cus * (groups16 ? 4 : 8) / (nch > 1 ? 2 : 1);
+                const size_t rb_max = (size_t)cus * (groups16 ? F1P_MIX_REFINE_WG_PER_CU : 8) / (nch > 1 ? 2 : 1);
                 if (rb > rb_max) rb = rb_max;
                 rb = rb & ~(size_t)15;
                 if (rb < 16) rb = 16;

@@ -129,6 +129,9 @@ namespace f1p {
 #ifndef F1P_MIX_QSHARDS
 #define F1P_MIX_QSHARDS 8    // measured (4096 egos): 1 shard filter 87 us / refine 25 us; 8: 73 / 25; 16: 73 / 26; 32: 73 / 30; 64: 73 / 39 (refinement groups spread over too many half-empty workgroups)
 #endif
+#ifndef F1P_MIX_REFINE_WG_PER_CU
+#define F1P_MIX_REFINE_WG_PER_CU 4   // workgroups of k_lattice_refine<16> per CU the grid is capped at (grid-stride over the queue beyond that; measured: 2 / 3 / 4 -> 65.7 / 65.6 / 65.8 us per plan, no difference)
+#endif
 #ifndef F1P_PRO2
 #define F1P_PRO2 1              // k_lattice_prologue2 (two egos per wave) where it applies; 0: k_lattice_prologue always (A/B)
 #endif
