@@ -20,7 +20,10 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("F1P_FUZZ_SEEDS", "100"))))   # 100 in the driver-run suite; F1P_FUZZ_SEEDS=2000 for a long hunt (logs: profiles/r03_fuzz_*.txt)
+_SEED0 = int(os.environ.get("F1P_FUZZ_SEED0", "0"))      # first seed (a long hunt over seeds no earlier run has seen: F1P_FUZZ_SEED0=8000 F1P_FUZZ_SEEDS=8000)
+
+
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("F1P_FUZZ_SEEDS", "100"))))   # 100 in the driver-run suite; F1P_FUZZ_SEEDS=2000 for a long hunt (logs: profiles/r03_fuzz_*.txt)
 def test_random_lattice_configurations(ctx, orc, seed):
     rng = np.random.default_rng(1000 + seed)
     n_pts = int(rng.integers(300, 1500))
@@ -108,7 +111,7 @@ def test_random_lattice_configurations(ctx, orc, seed):
     np.testing.assert_allclose(a["best_traj"], want["best_traj"], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("F1P_FUZZ_SEEDS", "100"))))
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("F1P_FUZZ_SEEDS", "100"))))
 def test_random_kmpc_configurations(ctx, orc, seed):
     """Random horizons, rollout counts (not multiples of the workgroup), weights (equal position weights in half of the seeds, a
     negative one now and then) and bounds (steering limits on both sides of the polynomial-tan range): the mixed-precision schedule
@@ -150,7 +153,7 @@ def test_random_kmpc_configurations(ctx, orc, seed):
     np.testing.assert_allclose(mixed["speed"], want["speed"], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + max(4, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
 def test_random_footprints_under_the_mixed_schedule(ctx, seed):
     """random oriented footprints (1..4 discs, offsets to +-0.6 m, radii 0.05..0.3 m) on random maps and goal grids: the mixed schedule
     (filter clearance 0, 1 and 2) against the all-fp64 footprint kernel, bit for bit"""
@@ -184,7 +187,7 @@ def test_random_footprints_under_the_mixed_schedule(ctx, seed):
         ctx.lattice_set_clearance(); ctx.lattice_set_mode(1); ctx.set_footprint((), 0.0)
 
 
-@pytest.mark.parametrize("seed", range(max(8, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + max(8, int(os.environ.get("F1P_FUZZ_SEEDS", "100")) // 3)))
 def test_random_stmpc_configurations(ctx, orc, seed):
     """The dynamic-model shooting: f32 filter + time-parallel fp64 decision against the all-fp64 kernel (every output bit for bit) and,
     on a few egos, against the oracle -- random horizons (both refinement kernels), rollout counts, speeds around the trust speed,
