@@ -236,6 +236,82 @@ __device__ __forceinline__ void wave_lookahead_centres(double px, double py, con
 #undef F1P_LAT
 }
 
+// ---- per-ego pieces both prologue kernels share (one ego per wave: `first` = lane 0, `idx` = lane; two egos per wave: first lane / lane index of the half) ----
+struct EgoWindow { int tile_gx0, tile_gy0; double txo, tyo; uint32_t own_word; int own_bit; };
+
+// the ego's occupancy window (its origin is a function of the position alone) and the clearance word of the ego's own cell: no look-up of an ego that stands in a
+// cell that is not clear could say "clear", so the candidate kernel then tests every station against the real bitmap (exact_all).  The word is requested
+// here and consumed when the record is written.  own_bit = -1: outside the window (exact_all)
+__device__ __forceinline__ EgoWindow ego_window(const LatticeArgs& a, const MixArgs& mx, bool collide_on, double px, double py, bool first) {
+    EgoWindow w;
+    w.tile_gx0 = 0; w.tile_gy0 = 0; w.own_word = 0xffffffffu; w.own_bit = -1;
+    const double cxd = (px - a.grid.ox) * a.grid.inv_res, cyd = (py - a.grid.oy) * a.grid.inv_res;
+    if (collide_on) {
+        const double fx = __builtin_floor(cxd), fy = __builtin_floor(cyd);
+        const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
+        const int half = a.tile_rows / 2;
+        w.tile_gx0 = ((egx - half) >> 5) << 5;
+        w.tile_gy0 = egy - half;
+    }
+    w.txo = cxd - (double)w.tile_gx0; w.tyo = cyd - (double)w.tile_gy0;   // the ego's position in cells, relative to the window origin
+    if (first && mx.clear_bits) {
+        const int lx0 = cvt_flr_i32_f32((float)w.txo), ly0 = cvt_flr_i32_f32((float)w.tyo);
+        if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+            w.own_bit = lx0 & 31;
+            const int gw = (w.tile_gx0 >> 5) + (lx0 >> 5), gy = w.tile_gy0 + ly0;
+            if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) w.own_word = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];   // (off the map: not clear)
+        }
+    }
+    return w;
+}
+
+// oriented footprint: lane idx < n_disc looks up ITS disc centre (station 0: o_d along the heading) in the clearance map; true = not clear (outside the window
+// or off the map included).  The caller ballots: the ego "stands in a cell that is not clear" when any of its disc centres does
+__device__ __forceinline__ bool ego_disc_not_clear(const LatticeArgs& a, const MixArgs& mx, const EgoWindow& w, double cs_t, double sn_t, int idx) {
+    bool ncl = false;
+    if (idx < mx.n_disc) {
+        const double o = (idx == 0 ? mx.disc_off[0] : idx == 1 ? mx.disc_off[1] : idx == 2 ? mx.disc_off[2] : mx.disc_off[3]) * a.grid.inv_res;
+        const int lx0 = cvt_flr_i32_f32((float)__builtin_fma(cs_t, o, w.txo)), ly0 = cvt_flr_i32_f32((float)__builtin_fma(sn_t, o, w.tyo));
+        ncl = true;                                              // outside the window or off the map: not clear
+        if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
+            const int gw = (w.tile_gx0 >> 5) + (lx0 >> 5), gy = w.tile_gy0 + ly0;
+            if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) ncl = ((mx.clear_bits[(size_t)gy * a.grid.wwords + gw] >> (lx0 & 31)) & 1u) != 0u;
+        }
+    }
+    return ncl;
+}
+
+// the ego's record header, its cell transform for the refinement kernel and its nearest segment: one lane per ego
+__device__ __forceinline__ void ego_record_write(const LatticeArgs& a, const f1p_lattice_cfg& cfg, const MixArgs& mx, unsigned char* rec, int e, int S, int sim_m,
+                                                 double px, double py, double theta, double cs_t, double sn_t, const EgoWindow& w, double pm0, double pm1, double pm2,
+                                                 bool disc_not_clear, int ni) {
+    EgoXform xf;
+    xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = w.txo;
+    xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = w.tyo;
+    xf.tile_gx0 = w.tile_gx0; xf.tile_gy0 = w.tile_gy0;
+    mx.xf[e] = xf;                                                        // the refinement kernel's fp64 cell arithmetic
+    mx.ego_ni[e] = ni;
+    EgoRecHdr h;
+    h.px = px; h.py = py; h.theta = theta; h.ct = cs_t; h.st = sn_t;
+    const int den = S - 1 > 1 ? S - 1 : 1;
+    EgoParamsF2& p = h.p;
+    p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
+    p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
+    p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
+    p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;
+    p.clear_ds_cap = mx.clear_ds_cap;
+    p.inv_den = __builtin_amdgcn_rcpf((float)den);
+    p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
+    p.inv_nw = 1.0f / (float)cfg.n_width; p.pad0 = 0.f;
+    { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
+    p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
+    p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
+    p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = w.tile_gx0; p.tile_gy0 = w.tile_gy0;
+    p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
+    p.exact_all = (w.own_bit < 0 || disc_not_clear) ? 1 : (int)((w.own_word >> w.own_bit) & 1u);
+    *reinterpret_cast<EgoRecHdr*>(rec) = h;
+}
+
 // ===================================================================================================================
 // Round 3, second step: the filter as TWO kernels.
 //   k_lattice_prologue   one WAVE per ego: nearest segment, look-ahead centres, goal frames, the ego's cell transform -> one
@@ -287,29 +363,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     // -- then no look-up of its candidates could say "clear", and the candidate kernel tests every station against the real bitmap
     // (exact_all).  The word is requested here and consumed when the record is written.
     const bool collide_on = cfg.check_collision && a.has_grid;
-    int tile_gx0 = 0, tile_gy0 = 0;
-    double txo = 0.0, tyo = 0.0;                                 // the ego's position in cells, relative to the window origin
-    uint32_t own_word = 0xffffffffu;
-    int own_bit = -1;                                            // -1: outside the window (exact_all)
-    {
-        const double cxd = (px - a.grid.ox) * a.grid.inv_res, cyd = (py - a.grid.oy) * a.grid.inv_res;
-        if (collide_on) {
-            const double fx = __builtin_floor(cxd), fy = __builtin_floor(cyd);
-            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
-            const int half = a.tile_rows / 2;
-            tile_gx0 = ((egx - half) >> 5) << 5;
-            tile_gy0 = egy - half;
-        }
-        txo = cxd - (double)tile_gx0; tyo = cyd - (double)tile_gy0;
-        if (lane == 0 && mx.clear_bits) {
-            const int lx0 = cvt_flr_i32_f32((float)txo), ly0 = cvt_flr_i32_f32((float)tyo);
-            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
-                own_bit = lx0 & 31;
-                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
-                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) own_word = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];   // (off the map: not clear)
-            }
-        }
-    }
+    const EgoWindow win = ego_window(a, mx, collide_on, px, py, lane == 0);
     double sn_t = 0.0, cs_t = 1.0;
     if (lane == 0) sincos(theta, &sn_t, &cs_t);                  // one lane: the library call is long, the other lanes skip it (round 6: sincos_core here and in k_lattice measured 17.06 -> 16.92 us -- inside the noise: the library call stays)
     F1P_PPH();
@@ -345,16 +399,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
     // oriented footprint: the ego "stands in a cell that is not clear" when any of its disc centres (station 0: o_d along the heading) does
     bool disc_not_clear = false;
     if (mx.n_disc > 0 && mx.clear_bits) {                       // (wave-uniform)
-        bool ncl = false;
-        if (lane < mx.n_disc) {
-            const double o = (lane == 0 ? mx.disc_off[0] : lane == 1 ? mx.disc_off[1] : lane == 2 ? mx.disc_off[2] : mx.disc_off[3]) * a.grid.inv_res;
-            const int lx0 = cvt_flr_i32_f32((float)__builtin_fma(cs_t, o, txo)), ly0 = cvt_flr_i32_f32((float)__builtin_fma(sn_t, o, tyo));
-            ncl = true;                                          // outside the window or off the map: not clear
-            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
-                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
-                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) ncl = ((mx.clear_bits[(size_t)gy * a.grid.wwords + gw] >> (lx0 & 31)) & 1u) != 0u;
-            }
-        }
+        const bool ncl = ego_disc_not_clear(a, mx, win, cs_t, sn_t, lane);
         disc_not_clear = __ballot(ncl) != 0ull;
     }
     if (a.prev_theta) {
@@ -394,33 +439,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue(LatticeArgs a, f1p_lat
         }
     }
     F1P_PPH();
-    if (lane == 0) {
-        EgoXform xf;
-        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = txo;
-        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = tyo;
-        xf.tile_gx0 = tile_gx0; xf.tile_gy0 = tile_gy0;
-        mx.xf[e] = xf;                                                        // the refinement kernel's fp64 cell arithmetic
-        mx.ego_ni[e] = ni;
-        EgoRecHdr h;
-        h.px = px; h.py = py; h.theta = theta; h.ct = cs_t; h.st = sn_t;
-        const int den = S - 1 > 1 ? S - 1 : 1;
-        EgoParamsF2& p = h.p;
-        p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
-        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
-        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
-        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;
-        p.clear_ds_cap = mx.clear_ds_cap;
-        p.inv_den = __builtin_amdgcn_rcpf((float)den);
-        p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
-        p.inv_nw = 1.0f / (float)cfg.n_width; p.pad0 = 0.f;
-        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
-        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
-        p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
-        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = tile_gx0; p.tile_gy0 = tile_gy0;
-        p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
-        p.exact_all = (own_bit < 0 || disc_not_clear) ? 1 : (int)((own_word >> own_bit) & 1u);
-        *reinterpret_cast<EgoRecHdr*>(rec) = h;
-    }
+    if (lane == 0) ego_record_write(a, cfg, mx, rec, e, S, sim_m, px, py, theta, cs_t, sn_t, win, pm0, pm1, pm2, disc_not_clear, ni);
     F1P_PPH();
 #ifdef F1P_PRO_PHASES
     if (lane == 0 && mx.dbg_cost32) { for (int k = 0; k + 1 < npp; ++k) mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 32 + k] = (float)(pph[k + 1] - pph[k]); mx.dbg_cost32[(size_t)e * nl * cfg.n_width + 31] = (float)(pph[0] & 0xffffff); }
@@ -560,29 +579,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue2(LatticeArgs a, f1p_la
         }
     }
     const bool collide_on = cfg.check_collision && a.has_grid;
-    int tile_gx0 = 0, tile_gy0 = 0;
-    double txo = 0.0, tyo = 0.0;
-    uint32_t own_word = 0xffffffffu;
-    int own_bit = -1;
-    {
-        const double cxd = (px - a.grid.ox) * a.grid.inv_res, cyd = (py - a.grid.oy) * a.grid.inv_res;
-        if (collide_on) {
-            const double fx = __builtin_floor(cxd), fy = __builtin_floor(cyd);
-            const int egx = (int)fmin(fmax(fx, -1.0e6), 1.0e6), egy = (int)fmin(fmax(fy, -1.0e6), 1.0e6);
-            const int half = a.tile_rows / 2;
-            tile_gx0 = ((egx - half) >> 5) << 5;
-            tile_gy0 = egy - half;
-        }
-        txo = cxd - (double)tile_gx0; tyo = cyd - (double)tile_gy0;
-        if (hl == 0 && mx.clear_bits) {
-            const int lx0 = cvt_flr_i32_f32((float)txo), ly0 = cvt_flr_i32_f32((float)tyo);
-            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
-                own_bit = lx0 & 31;
-                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
-                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) own_word = mx.clear_bits[(size_t)gy * a.grid.wwords + gw];
-            }
-        }
-    }
+    const EgoWindow win = ego_window(a, mx, collide_on, px, py, hl == 0);
     double sn_t = 0.0, cs_t = 1.0;
     F1P_PPH();
     // ---- nearest segment: nearest_scan_boxed per half, two 32-segment passes per surviving chunk -------------------------------------------
@@ -799,16 +796,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue2(LatticeArgs a, f1p_la
     sn_t = shfl_d(sn_t, hbase); cs_t = shfl_d(cs_t, hbase);
     bool disc_not_clear = false;
     if (mx.n_disc > 0 && mx.clear_bits) {                       // (wave-uniform)
-        bool ncl = false;
-        if (hl < mx.n_disc) {
-            const double o = (hl == 0 ? mx.disc_off[0] : hl == 1 ? mx.disc_off[1] : hl == 2 ? mx.disc_off[2] : mx.disc_off[3]) * a.grid.inv_res;
-            const int lx0 = cvt_flr_i32_f32((float)__builtin_fma(cs_t, o, txo)), ly0 = cvt_flr_i32_f32((float)__builtin_fma(sn_t, o, tyo));
-            ncl = true;
-            if (((unsigned)lx0 < (unsigned)(a.tile_words * 32)) & ((unsigned)ly0 < (unsigned)a.tile_rows)) {
-                const int gw = (tile_gx0 >> 5) + (lx0 >> 5), gy = tile_gy0 + ly0;
-                if (gw >= 0 && gw < a.grid.wwords && gy >= 0 && gy < a.grid.h) ncl = ((mx.clear_bits[(size_t)gy * a.grid.wwords + gw] >> (lx0 & 31)) & 1u) != 0u;
-            }
-        }
+        const bool ncl = ego_disc_not_clear(a, mx, win, cs_t, sn_t, hl);
         const unsigned long long bm = __ballot(ncl);
         disc_not_clear = (hh ? (unsigned int)(bm >> 32) : (unsigned int)bm) != 0u;
     }
@@ -846,33 +834,7 @@ __global__ __launch_bounds__(256) void k_lattice_prologue2(LatticeArgs a, f1p_la
         }
     }
     F1P_PPH();
-    if (hl == 0 && valid) {                                      // both egos' records in one pass
-        EgoXform xf;
-        xf.txx = cs_t * a.grid.inv_res; xf.txy = -sn_t * a.grid.inv_res; xf.tx0 = txo;
-        xf.tyx = sn_t * a.grid.inv_res; xf.tyy = cs_t * a.grid.inv_res; xf.ty0 = tyo;
-        xf.tile_gx0 = tile_gx0; xf.tile_gy0 = tile_gy0;
-        mx.xf[e] = xf;
-        mx.ego_ni[e] = ni;
-        EgoRecHdr hd;
-        hd.px = px; hd.py = py; hd.theta = theta; hd.ct = cs_t; hd.st = sn_t;
-        const int den = S - 1 > 1 ? S - 1 : 1;
-        EgoParamsF2& p = hd.p;
-        p.txx = (float)xf.txx; p.txy = (float)xf.txy; p.tx0 = (float)xf.tx0; p.tyx = (float)xf.tyx; p.tyy = (float)xf.tyy; p.ty0 = (float)xf.ty0;
-        p.w_len = (float)cfg.w_length; p.w_maxk = (float)cfg.w_max_kappa; p.w_meank = (float)cfg.w_mean_kappa; p.w_sim = (float)cfg.w_similarity;
-        p.margin_rel = mx.margin_rel; p.margin_abs = mx.margin_abs;
-        p.edge0 = mx.edge0; p.edge1 = mx.edge1 * (float)a.grid.inv_res;
-        p.clear_ds_cap = mx.clear_ds_cap;
-        p.inv_den = __builtin_amdgcn_rcpf((float)den);
-        p.inv_S = __builtin_amdgcn_rcpf((float)S); p.fS = (float)S;
-        p.inv_nw = 1.0f / (float)cfg.n_width; p.pad0 = 0.f;
-        { const float n2 = p.txx * p.txx + p.txy * p.txy; p.cells_per_m = n2 > 0.f ? __builtin_sqrtf(n2) : 0.f; p.sqrt_S = __builtin_sqrtf((float)S); }
-        p.prev = a.prev_theta ? a.prev_theta + (size_t)e * S : nullptr;
-        p.M0 = pm0; p.M1 = pm1; p.M2 = pm2;
-        p.tile_w = a.tile_words * 32; p.tile_h = a.tile_rows; p.tile_gx0 = tile_gx0; p.tile_gy0 = tile_gy0;
-        p.S = S; p.sim_m = sim_m; p.n_shift = cfg.n_shift;
-        p.exact_all = (own_bit < 0 || disc_not_clear) ? 1 : (int)((own_word >> own_bit) & 1u);
-        *reinterpret_cast<EgoRecHdr*>(rec) = hd;
-    }
+    if (hl == 0 && valid) ego_record_write(a, cfg, mx, rec, e, S, sim_m, px, py, theta, cs_t, sn_t, win, pm0, pm1, pm2, disc_not_clear, ni);   // both egos' records in one pass
     F1P_PPH();
 #ifdef F1P_PRO2_PHASES
     if (hl == 0 && valid && mx.dbg_cost32) {
