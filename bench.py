@@ -1193,7 +1193,7 @@ def leg_host_boundary_latency(ctx, args, poses, cfg, S, steady):
     s50, s95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True))
     ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)
     return {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
-            "includes": "H2D poses + kernels + D2H steer/speed/idx/cost/status/near/best_traj + sync (PCIe-inclusive), page-locked host arrays; "
+            "includes": "poses in + kernels + steer/speed/idx/cost/status/near/best_traj out + sync (PCIe-inclusive), page-locked host arrays: since round 6 the prologue reads the poses and the selection kernel writes every result column and the rows straight from / into them (no hipMemcpy either way); "
                         "closed loop: the similarity term is live (previous headings stay on the device)",
             "closed_loop": {"p50_ms": c50, "p95_ms": c95,
                             "note": "f1p_lattice_step_batch: poses in, (steer, speed, status) out as ONE packed block the selection kernel writes straight "

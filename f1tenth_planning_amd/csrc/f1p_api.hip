@@ -142,6 +142,9 @@ struct Stage {
 #ifndef F1P_TRAJ_ZEROCOPY
 #define F1P_TRAJ_ZEROCOPY 1
 #endif
+#ifndef F1P_IO_ZEROCOPY
+#define F1P_IO_ZEROCOPY 1       // f1p_lattice_plan_batch: page-locked poses / result columns are read / written by the kernels themselves (0: copies, A/B)
+#endif
 #define F1P_PLAN_CHUNK_MIN_EGOS 2048
 #define F1P_PLAN_CHUNKS_MAX 8          // = number of slice events in f1p_ctx
 
@@ -723,13 +726,14 @@ static void cl_commit(f1p_ctx* ctx, const ClosedLoop& cl, int E, int S) {
 static int lattice_plan_dev_impl(f1p_ctx* ctx, const double* d_poses, const double* d_goals, const double* d_prev_theta,
                                  int32_t E, const f1p_lattice_cfg* cfg, double* d_steer, double* d_speed,
                                  int32_t* d_best_idx, double* d_best_cost, int32_t* d_status, int32_t* d_near_idx,
-                                 double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32, double* d_theta_out = nullptr) {
+                                 double* d_best_traj, double* d_all_cost, double* d_all_traj, float* d_best_traj32, double* d_theta_out = nullptr,
+                                 double* d_pose_copy = nullptr) {
     int rc = validate_lattice(ctx, cfg, E, d_goals == nullptr, E == 0 || (d_poses && d_best_idx && (cfg && cfg->cand_count > 0 ? true : (d_steer && d_speed))));
     if (rc) return rc;
     // a candidate shard evaluates only (cost + index); the emit half runs after the cross-rank argmin
     const int mode = cfg->cand_count > 0 ? LATTICE_EVAL : LATTICE_FULL;
     return launch_lattice(ctx, mode, d_poses, d_goals, d_prev_theta, E, cfg, nullptr, nullptr, d_steer, d_speed, d_best_idx,
-                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj, d_best_traj32, d_theta_out);
+                          d_best_cost, d_status, d_near_idx, d_best_traj, d_all_cost, d_all_traj, d_best_traj32, d_theta_out, d_pose_copy);
 }
 
 // the *_dev entry points in closed-loop mode: prev_theta == NULL means "the headings the previous plan left on the device"
@@ -818,7 +822,38 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
                        ? (TRAJ*)pinned_device_ptr(ctx, best_traj, sizeof(TRAJ) * e * S * 4) : nullptr;
     const bool pinned = bt_dev != nullptr;
     const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
+    // Round 6: with the trajectories going straight into the caller's page-locked array, the poses and the per-ego result columns do too when
+    // THEY are page-locked -- k_lattice_prologue reads the poses out of host memory and leaves a device copy (f1p_lattice_step_batch's scheme), the selection
+    // kernel stores steer / speed / index / cost / status / nearest segment where the caller reads them: no hipMemcpy in either direction, each of which is
+    // ~10 us of submission and DMA start-up in front of / behind a 65 us plan.  (All-fp64 mode keeps the copies: k_lattice re-reads the pose per thread.)
+    const double* zp = nullptr; double *zs = nullptr, *zv = nullptr, *zc_ = nullptr; int32_t *zi = nullptr, *zt = nullptr, *zn = nullptr;
+    bool zc_io = F1P_IO_ZEROCOPY && (best_traj ? zero_copy_traj : (E >= F1P_PLAN_CHUNK_MIN_EGOS && E < 8192 && !all_cost && !all_traj)) && !goals && !prev_theta &&
+                 ctx->lattice_mixed != 0 && cfg->cand_count == 0;
+    if (zc_io) {
+        zp = (const double*)pinned_device_ptr(ctx, poses, 32 * e);
+        zs = (double*)pinned_device_ptr(ctx, steer, 8 * e); zv = (double*)pinned_device_ptr(ctx, speed, 8 * e);
+        zi = (int32_t*)pinned_device_ptr(ctx, best_idx, 4 * e);
+        zc_ = best_cost ? (double*)pinned_device_ptr(ctx, best_cost, 8 * e) : nullptr;
+        zt = status ? (int32_t*)pinned_device_ptr(ctx, status, 4 * e) : nullptr;
+        zn = near_idx ? (int32_t*)pinned_device_ptr(ctx, near_idx, 4 * e) : nullptr;
+        zc_io = zp && zs && zv && zi && (!best_cost || zc_) && (!status || zt) && (!near_idx || zn);
+    }
     Stage s(ctx);
+    if (zc_io) {
+        s.need(8 * 4 * e);                                      // the device copy of the poses
+        if ((rc = s.begin())) return rc;
+        double* d_pose_copy = (double*)arena_take(ctx, 8 * 4 * e);
+        ClosedLoop cl;
+        if ((rc = cl_begin(ctx, nullptr, E, (int)S, true, &cl))) return rc;
+        struct HostDst { f1p_ctx* c; ~HostDst() { c->traj_dst_host = false; } } host_dst{ctx};
+        ctx->traj_dst_host = best_traj != nullptr;
+        double* bt64 = nullptr; float* bt32 = nullptr;
+        if (best_traj) { if (F32) bt32 = reinterpret_cast<float*>(bt_dev); else bt64 = reinterpret_cast<double*>(bt_dev); }
+        if ((rc = lattice_plan_dev_impl(ctx, zp, nullptr, cl.prev, E, cfg, zs, zv, zi, zc_, zt, zn, bt64, nullptr, nullptr, bt32, cl.out, d_pose_copy))) return rc;
+        cl_commit(ctx, cl, E, (int)S);
+        F1P_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return F1P_OK;
+    }
     s.need(8 * 4 * e); s.need(8 * e * C * 3, goals); s.need(8 * e * S, prev_theta);
     s.need(8 * e, steer); s.need(8 * e, speed); s.need(4 * e); s.need(8 * e, best_cost); s.need(4 * e, status); s.need(4 * e, near_idx);
     s.need(sizeof(TRAJ) * e * S * 4, best_traj && !zero_copy_traj); s.need(8 * e * C, all_cost); s.need(8 * e * C * S * 4, all_traj);

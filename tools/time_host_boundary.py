@@ -8,6 +8,7 @@ rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=
 cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S); poses = synth.make_egos(rl, E, seed=1)
 with Context(0) as ctx:
     ctx.set_waypoints(rl); ctx.set_grid(img, 0.058, origin, 206)
+    if os.environ.get("PIPE"): ctx.lattice_set_pipeline(int(os.environ["PIPE"]))   # chunks of egos over two streams (A/B: one chunk's rows cross PCIe under the next chunk's kernels)
     def pct(fn):
         for _ in range(20): fn()
         ts = []
