@@ -146,6 +146,9 @@ struct Stage {
 #define F1P_IO_ZEROCOPY 1       // f1p_lattice_plan_batch: page-locked poses / result columns are read / written by the kernels themselves (0: copies, A/B)
 #endif
 #define F1P_PLAN_CHUNK_MIN_EGOS 2048
+#ifndef F1P_ZEROCOPY_MIN_EGOS
+#define F1P_ZEROCOPY_MIN_EGOS 32       // batches from this size hand page-locked caller arrays to the kernels (measured p50 plan(), fp64 rows, copies -> in place: 64 egos 0.075 -> 0.061 ms, 256: 0.090 -> 0.068, 1024: 0.126 -> 0.103, 4096: 0.236 -> 0.218; below 32 the small-call bounce block is as fast)
+#endif
 #define F1P_PLAN_CHUNKS_MAX 8          // = number of slice events in f1p_ctx
 
 // The device-side address of [p, p + bytes) when the WHOLE range lies in page-locked host memory this device can address (hipHostMalloc /
@@ -818,7 +821,7 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
                                           "pass NULL for steer / speed / status / best_traj and emit the global winner with f1p_lattice_emit_dev");
     const size_t C = (size_t)cfg->n_lookahead * cfg->n_width, S = cfg->n_stations, e = E;
     // (page-locked best_traj: see below -- decided here so that the arena does not reserve bytes nobody uses)
-    TRAJ* bt_dev = (best_traj && !all_cost && !all_traj && E >= F1P_PLAN_CHUNK_MIN_EGOS)
+    TRAJ* bt_dev = (best_traj && !all_cost && !all_traj && E >= F1P_ZEROCOPY_MIN_EGOS)
                        ? (TRAJ*)pinned_device_ptr(ctx, best_traj, sizeof(TRAJ) * e * S * 4) : nullptr;
     const bool pinned = bt_dev != nullptr;
     const bool zero_copy_traj = F1P_TRAJ_ZEROCOPY && pinned && E < 8192;
@@ -827,7 +830,7 @@ static int lattice_plan_batch_impl(f1p_ctx* ctx, const double* poses, const doub
     // kernel stores steer / speed / index / cost / status / nearest segment where the caller reads them: no hipMemcpy in either direction, each of which is
     // ~10 us of submission and DMA start-up in front of / behind a 65 us plan.  (All-fp64 mode keeps the copies: k_lattice re-reads the pose per thread.)
     const double* zp = nullptr; double *zs = nullptr, *zv = nullptr, *zc_ = nullptr; int32_t *zi = nullptr, *zt = nullptr, *zn = nullptr;
-    bool zc_io = F1P_IO_ZEROCOPY && (best_traj ? zero_copy_traj : (E >= F1P_PLAN_CHUNK_MIN_EGOS && E < 8192 && !all_cost && !all_traj)) && !goals && !prev_theta &&
+    bool zc_io = F1P_IO_ZEROCOPY && (best_traj ? zero_copy_traj : (E >= F1P_ZEROCOPY_MIN_EGOS && E < 8192 && !all_cost && !all_traj)) && !goals && !prev_theta &&
                  ctx->lattice_mixed != 0 && cfg->cand_count == 0;
     if (zc_io) {
         zp = (const double*)pinned_device_ptr(ctx, poses, 32 * e);

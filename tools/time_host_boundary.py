@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from f1tenth_planning_amd import synth
 from f1tenth_planning_amd.runtime import Context
-E, C, S = 4096, 256, 50
+E, C, S = int(os.environ.get("EGOS", 4096)), 256, 50
 rl = synth.make_raceline(seed=0); img, origin = synth.make_grid(rl[:, :2], size=(2000, 2000), resolution=0.058)
 cfg = synth.bench_lattice_cfg(n_cand=C, n_stations=S); poses = synth.make_egos(rl, E, seed=1)
 with Context(0) as ctx:
