@@ -218,6 +218,45 @@ def test_pinned_pipelined_batch_equals_plain_batch(ctx, scene):
             np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=k)
 
 
+def test_page_locked_arrays_are_read_and_written_in_place(ctx, scene):
+    """Round 6: with page-locked caller arrays (32 <= E < 8192, device goals, no host prev_theta) f1p_lattice_plan_batch hands the kernels the arrays themselves
+    -- the prologue reads the poses out of host memory, the selection kernel stores every result column and the rows where the caller reads them, no hipMemcpy
+    either way.  Every output bit-identical to the staged path (pageable arrays), for batches around the thresholds, odd sizes, blocked egos, NaN poses, with
+    and without the rows, f32 rows, and over the plans of a closed loop (the similarity term from the headings kept on the device)."""
+    rl, img, origin = scene
+    cfg = synth.bench_lattice_cfg(n_cand=128, n_stations=50)
+    for E in (31, 32, 33, 257, 1000, 3071, 3073, 4097):
+        poses = synth.make_egos(rl, E, seed=E, pos_sigma=0.4)
+        poses[0, :2] += 400.0
+        if E > 40:
+            poses[7, 0] = np.nan
+        plain = ctx.lattice_plan(poses, cfg)
+        pinned = ctx.lattice_plan(poses, cfg, reuse_outputs=True)
+        for k in plain:
+            np.testing.assert_array_equal(np.asarray(pinned[k]), plain[k], err_msg=f"{k} (E {E})")
+        no_rows = ctx.lattice_plan(poses, cfg, reuse_outputs=True, want_traj=False)
+        for k in no_rows:
+            np.testing.assert_array_equal(np.asarray(no_rows[k]), plain[k], err_msg=f"{k} without rows (E {E})")
+        f32a = ctx.lattice_plan(poses, cfg, traj_dtype=np.float32)
+        f32b = ctx.lattice_plan(poses, cfg, reuse_outputs=True, traj_dtype=np.float32)
+        for k in f32a:
+            np.testing.assert_array_equal(np.asarray(f32b[k]), f32a[k], err_msg=f"{k} f32 rows (E {E})")
+    E = 777
+    poses = synth.make_egos(rl, E, seed=3, pos_sigma=0.3)
+    chains = []
+    for pinned_arrays in (False, True):
+        ctx.lattice_set_closed_loop(True)
+        try:
+            outs = [{k: np.array(v) for k, v in ctx.lattice_plan(poses, cfg, reuse_outputs=pinned_arrays).items()} for _ in range(3)]
+        finally:
+            ctx.lattice_set_closed_loop(False)
+        chains.append(outs)
+    for a, b in zip(*chains):
+        for k in a:
+            np.testing.assert_array_equal(b[k], a[k], err_msg=k + " (closed loop)")
+    assert not np.array_equal(chains[0][0]["best_cost"], chains[0][1]["best_cost"])     # the second plan does carry the similarity term
+
+
 def _same(a, b):
     for k in a:
         np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
