@@ -137,6 +137,7 @@ class Context:
         self.has_grid = False
         self._pinned = {}        # (tag, shape, dtype) -> numpy view of page-locked memory
         self._pinned_ptrs = []
+        self._bundles = {}       # per batch shape: the page-locked arrays of lattice_plan(reuse_outputs=True) / lattice_step and their addresses
 
     # ---- housekeeping ------------------------------------------------------------------------------
     def _check(self, rc):
@@ -149,6 +150,7 @@ class Context:
                 self.lib.f1p_host_free(self.h, ptr)
             self._pinned_ptrs = []
             self._pinned = {}
+            self._bundles = {}
             self.lib.f1p_destroy(self.h)
             self.h = None
 
@@ -342,14 +344,24 @@ class Context:
         poses = _f64(poses, (-1, 4)); E = poses.shape[0]; Cn = cfg.n_cand; S = cfg.n_stations
         g = None if goals is None else _f64(goals, (E, Cn, 3))
         pt = None if prev_theta is None else _f64(prev_theta, (E, S))
+        ptrs = None
         if reuse_outputs:
-            pin = self.pinned
-            hp = pin("lat_poses", (E, 4), np.float64); hp[...] = poses; poses = hp
-            out = dict(steer=pin("lat_steer", E, np.float64), speed=pin("lat_speed", E, np.float64),
-                       best_idx=pin("lat_bidx", E, np.int32), best_cost=pin("lat_bcost", E, np.float64),
-                       status=pin("lat_status", E, np.int32), near_idx=pin("lat_near", E, np.int32))
-            if want_traj:
-                out["best_traj"] = pin("lat_traj32" if f32 else "lat_traj", (E, S, 4), np.float32 if f32 else np.float64)
+            # the page-locked arrays of this batch shape and their addresses are looked up ONCE (eight pinned() look-ups and nine ctypes pointer objects were
+            # ~15 us of a 0.22 ms call)
+            key = ("plan", E, S, f32, bool(want_traj))
+            b = self._bundles.get(key)
+            if b is None:
+                pin = self.pinned
+                hp = pin("lat_poses", (E, 4), np.float64)
+                o = dict(steer=pin("lat_steer", E, np.float64), speed=pin("lat_speed", E, np.float64),
+                         best_idx=pin("lat_bidx", E, np.int32), best_cost=pin("lat_bcost", E, np.float64),
+                         status=pin("lat_status", E, np.int32), near_idx=pin("lat_near", E, np.int32))
+                if want_traj:
+                    o["best_traj"] = pin("lat_traj32" if f32 else "lat_traj", (E, S, 4), np.float32 if f32 else np.float64)
+                b = self._bundles[key] = (hp, o, {k: _ptr(v) for k, v in o.items()}, _ptr(hp))
+            hp, o, ptrs, php = b
+            hp[...] = poses; poses = hp
+            out = dict(o)
         else:
             out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
                        status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
@@ -360,17 +372,19 @@ class Context:
         if cfg.cand_count > 0:            # a candidate shard only evaluates: (best_idx, best_cost, near_idx)
             for k in ("steer", "speed", "status", "best_traj"):
                 out.pop(k, None)
+        if ptrs is not None and not want_all:
+            P = lambda k: ptrs[k] if k in out else None   # noqa: E731
+            pp = php
+        else:
+            P = lambda k: _ptr(out.get(k))                # noqa: E731
+            pp = _ptr(poses)
         if f32:
-            self._check(self.lib.f1p_lattice_plan_batch_f32(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
-                                                            _ptr(out.get("steer")), _ptr(out.get("speed")), _ptr(out["best_idx"]),
-                                                            _ptr(out["best_cost"]), _ptr(out.get("status")), _ptr(out["near_idx"]),
-                                                            _ptr(out.get("best_traj"))))
+            self._check(self.lib.f1p_lattice_plan_batch_f32(self.h, pp, _ptr(g), _ptr(pt), E, C.byref(cfg),
+                                                            P("steer"), P("speed"), P("best_idx"), P("best_cost"), P("status"), P("near_idx"), P("best_traj")))
             return out
-        self._check(self.lib.f1p_lattice_plan_batch(self.h, _ptr(poses), _ptr(g), _ptr(pt), E, C.byref(cfg),
-                                                    _ptr(out.get("steer")), _ptr(out.get("speed")), _ptr(out["best_idx"]),
-                                                    _ptr(out["best_cost"]), _ptr(out.get("status")), _ptr(out["near_idx"]),
-                                                    _ptr(out.get("best_traj")), _ptr(out.get("all_cost")),
-                                                    _ptr(out.get("all_traj"))))
+        self._check(self.lib.f1p_lattice_plan_batch(self.h, pp, _ptr(g), _ptr(pt), E, C.byref(cfg),
+                                                    P("steer"), P("speed"), P("best_idx"), P("best_cost"), P("status"), P("near_idx"), P("best_traj"),
+                                                    _ptr(out.get("all_cost")), _ptr(out.get("all_traj"))))
         return out
 
     def lattice_plan_dev(self, d_poses, E, cfg: LatticeCfg, d_steer, d_speed, d_best_idx, d_best_cost=None, d_status=None,
@@ -387,13 +401,16 @@ class Context:
         the context (overwritten by the next step of the same batch size).  The previous plan's headings (similarity term) stay on the
         device; keep_traj=True keeps the winners' rows there too (lattice_fetch_traj)."""
         E = int(np.shape(poses)[0])
-        hp = self.pinned("step_poses", (E, 4), np.float64)
+        b = self._bundles.get(("step", E))
+        if b is None:
+            hp = self.pinned("step_poses", (E, 4), np.float64)
+            o = dict(steer=self.pinned("step_steer", E, np.float64), speed=self.pinned("step_speed", E, np.float64),
+                     status=self.pinned("step_status", E, np.int32))
+            b = self._bundles[("step", E)] = (hp, o, (_ptr(hp), _ptr(o["steer"]), _ptr(o["speed"]), _ptr(o["status"])))
+        hp, o, (php, ps, pv, pt) = b
         hp[...] = poses
-        out = dict(steer=self.pinned("step_steer", E, np.float64), speed=self.pinned("step_speed", E, np.float64),
-                   status=self.pinned("step_status", E, np.int32))
-        self._check(self.lib.f1p_lattice_step_batch(self.h, _ptr(hp), E, C.byref(cfg), _ptr(out["steer"]), _ptr(out["speed"]),
-                                                    _ptr(out["status"]), 1 if keep_traj else 0))
-        return out
+        self._check(self.lib.f1p_lattice_step_batch(self.h, php, E, C.byref(cfg), ps, pv, pt, 1 if keep_traj else 0))
+        return dict(o)
 
     def lattice_fetch_traj(self, E, S):
         """the winners' rows [E, S, 4] of the last lattice_step(keep_traj=True)"""
