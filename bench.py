@@ -1191,6 +1191,7 @@ def leg_host_boundary_latency(ctx, args, poses, cfg, S, steady):
     cfg1 = synth.bench_lattice_cfg(n_cand=512, n_stations=S)
     ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)       # another batch shape: re-armed
     s50, s95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True))
+    u50, u95 = percentiles(lambda: ctx.lattice_plan(poses[:1], cfg1, want_traj=True, reuse_outputs=True))
     ctx.lattice_set_closed_loop(False); ctx.lattice_set_closed_loop(steady)
     return {"p50_ms": p50, "p95_ms": p95, "n": args.latency_iters,
             "includes": "poses in + kernels + steer/speed/idx/cost/status/near/best_traj out + sync (PCIe-inclusive), page-locked host arrays: since round 6 the prologue reads the poses and the selection kernel writes every result column and the rows straight from / into them (no hipMemcpy either way); "
@@ -1204,7 +1205,8 @@ def leg_host_boundary_latency(ctx, args, poses, cfg, S, steady):
                               "note": "f1p_lattice_plan_batch_f32: the same fp64 plan, best_traj rounded once to f32 on the device (3.3 MB instead of 6.6 MB down)"},
             "all_fp64": {"p50_ms": f50, "p95_ms": f95},
             "all_fp64_branch_and_bound": {"p50_ms": b50, "p95_ms": b95, "note": "cfg.prune = 1 under f1p_lattice_set_mode(0): bit-identical outputs"},
-            "config1_single_ego": {"p50_ms": s50, "p95_ms": s95, "workload": f"1 ego x 512 candidates x {S} stations (BASELINE configs[1]), Context.lattice_plan"}}
+            "config1_single_ego": {"p50_ms": s50, "p95_ms": s95, "workload": f"1 ego x 512 candidates x {S} stations (BASELINE configs[1]), Context.lattice_plan",
+                                   "reused_page_locked_arrays": {"p50_ms": u50, "p95_ms": u95, "note": "reuse_outputs=True: results in the context's page-locked arrays instead of fresh numpy arrays"}}}
 
 
 def leg_other_schedules(ctx, args, cfg, d_poses, d_prev_in, E, C, S, ref):
