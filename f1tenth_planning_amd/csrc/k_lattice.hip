@@ -563,6 +563,12 @@ int launch_lattice(f1p_ctx* ctx, int mode, const double* d_poses, const double* 
         const int rc = launch_lattice_mixed(ctx, a, cfg, mode, E, foot, cubic, d_pose_copy, &handled);
         if (rc != F1P_OK || handled) return rc;
     }
+    // The plan stays here (all fp64): every thread of an ego's workgroup reads the pose, so poses that live in page-locked HOST memory (d_pose_copy given:
+    // f1p_lattice_step_batch, f1p_lattice_plan_batch with page-locked arrays) are copied to the device first -- one DMA instead of 256 PCIe reads per ego.
+    if (d_pose_copy && E > 0) {
+        F1P_HIP(ctx, hipMemcpyAsync(d_pose_copy, d_poses, sizeof(double) * 4 * (size_t)E, hipMemcpyDefault, ctx->stream));
+        a.poses = d_pose_copy;
+    }
     size_t wl = sizeof(EgoParams) + sizeof(double) * 4 * (size_t)S + sizeof(uint32_t) * (size_t)a.tile_rows * a.tile_words;
     wl = (wl + 15) & ~(size_t)15;
     // the two-kernel schedule needs 4 per-wave LDS blocks in k_lattice_eval; a long station count that does not fit falls back to

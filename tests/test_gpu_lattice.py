@@ -241,6 +241,15 @@ def test_page_locked_arrays_are_read_and_written_in_place(ctx, scene):
         f32b = ctx.lattice_plan(poses, cfg, reuse_outputs=True, traj_dtype=np.float32)
         for k in f32a:
             np.testing.assert_array_equal(np.asarray(f32b[k]), f32a[k], err_msg=f"{k} f32 rows (E {E})")
+    # a plan the mixed schedule declines (cubic candidates with more than 256 stations: all fp64) with page-locked arrays: the poses are copied to the device
+    # once instead of being read across PCIe by every thread, the outputs still land in place
+    slow = synth.bench_lattice_cfg(n_cand=32, n_stations=300, generator="cubic")
+    p64 = synth.make_egos(rl, 64, seed=12, pos_sigma=0.3)
+    a = ctx.lattice_plan(p64, slow)
+    b = ctx.lattice_plan(p64, slow, reuse_outputs=True)
+    for k in a:
+        np.testing.assert_array_equal(np.asarray(b[k]), a[k], err_msg=k + " (all-fp64 fallback)")
+    assert (a["status"] == 0).any()
     E = 777
     poses = synth.make_egos(rl, E, seed=3, pos_sigma=0.3)
     chains = []
