@@ -52,7 +52,8 @@ def _f64(a, shape=None):
 
 
 def _ptr(a):
-    return None if a is None else C.c_void_p(a.ctypes.data)
+    # (`a.ctypes.data` builds a ctypes helper object per call: 2.3 us; the array interface's address is 1.5 us -- nine of them per plan() call)
+    return None if a is None else C.c_void_p(a.__array_interface__["data"][0])
 
 
 try:                      # xxh3 over the bytes: 6 us for a 1692 x 5 raceline
@@ -363,10 +364,19 @@ class Context:
             hp[...] = poses; poses = hp
             out = dict(o)
         else:
-            out = dict(steer=np.empty(E), speed=np.empty(E), best_idx=np.empty(E, np.int32), best_cost=np.empty(E),
-                       status=np.empty(E, np.int32), near_idx=np.empty(E, np.int32))
+            # fresh arrays for the caller: the six result columns are views of ONE buffer, so that one address look-up (1.5 us each) serves all of them
+            cols = np.empty(36 * E + 8, np.uint8)
+            base = cols.__array_interface__["data"][0]
+            o8, o4 = 8 * E, 4 * E
+            out = dict(steer=cols[0:o8].view(np.float64), speed=cols[o8:2 * o8].view(np.float64), best_cost=cols[2 * o8:3 * o8].view(np.float64),
+                       best_idx=cols[3 * o8:3 * o8 + o4].view(np.int32), status=cols[3 * o8 + o4:3 * o8 + 2 * o4].view(np.int32),
+                       near_idx=cols[3 * o8 + 2 * o4:3 * o8 + 3 * o4].view(np.int32))
+            ptrs = dict(steer=C.c_void_p(base), speed=C.c_void_p(base + o8), best_cost=C.c_void_p(base + 2 * o8), best_idx=C.c_void_p(base + 3 * o8),
+                        status=C.c_void_p(base + 3 * o8 + o4), near_idx=C.c_void_p(base + 3 * o8 + 2 * o4))
+            php = None
             if want_traj:
                 out["best_traj"] = np.empty((E, S, 4), np.float32 if f32 else np.float64)
+                ptrs["best_traj"] = _ptr(out["best_traj"])
         if want_all:
             out["all_cost"] = np.empty((E, Cn)); out["all_traj"] = np.empty((E, Cn, S, 4))
         if cfg.cand_count > 0:            # a candidate shard only evaluates: (best_idx, best_cost, near_idx)
@@ -374,7 +384,7 @@ class Context:
                 out.pop(k, None)
         if ptrs is not None and not want_all:
             P = lambda k: ptrs[k] if k in out else None   # noqa: E731
-            pp = php
+            pp = php if php is not None else _ptr(poses)
         else:
             P = lambda k: _ptr(out.get(k))                # noqa: E731
             pp = _ptr(poses)
