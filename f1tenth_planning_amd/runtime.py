@@ -296,11 +296,14 @@ class Context:
     # ---- pure pursuit ------------------------------------------------------------------------------------
     def pure_pursuit(self, poses, lookahead, wheelbase=0.33, max_reacquire=20.0):
         poses = _f64(poses, (-1, 3)); E = poses.shape[0]
-        out = dict(steer=np.empty(E), speed=np.empty(E), near_idx=np.empty(E, np.int32), la_idx=np.empty(E, np.int32),
-                   status=np.empty(E, np.int32))
+        cols = np.empty(28 * E + 8, np.uint8)                     # the five result columns as views of one buffer: one address look-up (lattice_plan does the same)
+        base = cols.__array_interface__["data"][0]
+        o8, o4 = 8 * E, 4 * E
+        out = dict(steer=cols[0:o8].view(np.float64), speed=cols[o8:2 * o8].view(np.float64), near_idx=cols[2 * o8:2 * o8 + o4].view(np.int32),
+                   la_idx=cols[2 * o8 + o4:2 * o8 + 2 * o4].view(np.int32), status=cols[2 * o8 + 2 * o4:2 * o8 + 3 * o4].view(np.int32))
+        V = C.c_void_p
         self._check(self.lib.f1p_pure_pursuit_batch(self.h, _ptr(poses), E, float(lookahead), float(wheelbase),
-                                                    float(max_reacquire), _ptr(out["steer"]), _ptr(out["speed"]),
-                                                    _ptr(out["near_idx"]), _ptr(out["la_idx"]), _ptr(out["status"])))
+                                                    float(max_reacquire), V(base), V(base + o8), V(base + 2 * o8), V(base + 2 * o8 + o4), V(base + 2 * o8 + 2 * o4)))
         return out
 
     def pure_pursuit_dev(self, d_poses, E, lookahead, d_steer, d_speed, d_near_idx=None, d_la_idx=None, d_status=None,
